@@ -1,0 +1,139 @@
+"""Pins for the C restatement of OpenCV's Farnebäck (oracle/farneback_ref.c).
+
+The reference holds no flow values for this path (its tests/test_flow_source.py
+:22-33 check type/shape/dtype only) and cv2 is absent from the build image, so
+these are analytic known-answer tests plus a
+comparison with cv2 that runs wherever ``import cv2`` works.  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import farneback as F
+
+
+def _texture(h, w, tx=0.0, ty=0.0, seed=5):
+    rng = np.random.default_rng(seed)
+    comps = [(rng.uniform(.4, 1), rng.uniform(.01, .08) * rng.choice([-1, 1]), rng.uniform(.01, .08),
+              rng.uniform(0, 6.28)) for _ in range(8)]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    v = sum(a * np.sin(2 * np.pi * (fx * (xx - tx) + fy * (yy - ty)) + ph) for a, fx, fy, ph in comps)
+    return np.clip(np.rint(128 + 25 * v), 0, 255).astype(np.uint8)
+
+
+def test_gaussian_kernels():
+    np.testing.assert_array_equal(F.gaussian_kernel(3, 0.0), np.float32([.25, .5, .25]))
+    for n, s in [(3, .5), (9, 1.5), (19, 3.5), (39, 7.5), (79, 15.5)]:
+        k = F.gaussian_kernel(n, s)
+        assert abs(float(k.astype(np.float64).sum()) - 1) < 1e-6
+        np.testing.assert_array_equal(k, k[::-1])
+        x = np.arange(n) - (n - 1) / 2
+        ref = np.exp(-x * x / (2 * s * s))
+        np.testing.assert_allclose(k, ref / ref.sum(), rtol=2e-7)
+
+
+def test_level_schedule_matches_survey_a1():
+    # 1080p, pyr_scale .5, levels 5 -> scales k=5..0
+    assert F.num_levels(1920, 1080, .5, 5) == 5
+    assert F.num_levels(1920, 1080, .5, 3) == 3
+    assert F.num_levels(1920, 1080, .5, 0) == 0
+    assert F.num_levels(64, 64, .5, 5) == 1          # 32 ok, 16 < min_size
+    assert F.num_levels(854, 480, .5, 3) == 3
+    geo = [F.level_geometry(1920, 1080, .5, k) for k in range(6)]
+    assert [(g[0], g[1], g[2]) for g in geo] == [(1920, 1080, 3), (960, 540, 3), (480, 270, 9), (240, 135, 19),
+                                                 (120, 68, 39), (60, 34, 79)]
+    assert [g[3] for g in geo] == [0.0, 0.5, 1.5, 3.5, 7.5, 15.5]
+    assert F.level_geometry(3840, 2160, .5, 5)[:2] == (120, 68)
+
+
+def test_resize_linear_identity_and_halving():
+    rng = np.random.default_rng(0)
+    a = rng.normal(0, 50, (12, 20)).astype(np.float32)
+    np.testing.assert_array_equal(F.resize_linear(a, 20, 12), a)
+    half = F.resize_linear(a, 10, 6)
+    exp = ((a[0::2, 0::2] * np.float32(.5) + a[0::2, 1::2] * np.float32(.5)) * np.float32(.5)
+           + (a[1::2, 0::2] * np.float32(.5) + a[1::2, 1::2] * np.float32(.5)) * np.float32(.5))
+    np.testing.assert_array_equal(half, exp)
+    # upscaling a 2-channel field: corners replicate
+    f = rng.normal(0, 3, (5, 7, 2)).astype(np.float32)
+    up = F.resize_linear(f, 14, 10)
+    np.testing.assert_array_equal(up[0, 0], f[0, 0] * np.float32(.25) + f[0, 0] * np.float32(.75))
+    np.testing.assert_allclose(up[-1, -1], f[-1, -1], rtol=1e-6)
+
+
+def test_blur_constant_and_reflect():
+    img = np.full((20, 30), 77, np.uint8)
+    for ksz, s in [(3, 0.0), (9, 1.5), (19, 3.5)]:
+        np.testing.assert_allclose(F.gaussian_blur_u8(img, ksz, s), 77, rtol=1e-6)
+    # 3-tap at the border uses REFLECT_101: column -1 == column 1
+    img = np.zeros((4, 6), np.uint8)
+    img[:, 1] = 100
+    out = F.gaussian_blur_u8(img, 3, 0.0)
+    assert out[2, 0] == 50.0 and out[2, 1] == 50.0 and out[2, 2] == 25.0
+
+
+def test_polyexp_reproduces_quadratic():
+    """I = c + a x + b y + d x^2 + e y^2 + f xy  =>  R = (b', a', e, d, f) at every
+    interior pixel, with a', b' the gradient at that pixel (SURVEY A.3 store order:
+    R0 ~ y, R1 ~ x, R2 ~ yy, R3 ~ xx, R4 ~ xy)."""
+    h, w, n = 40, 48, 5
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    c, a, b, d, e, f = 3.0, 0.5, -0.25, 0.02, -0.03, 0.01
+    img = (c + a * xx + b * yy + d * xx * xx + e * yy * yy + f * xx * yy).astype(np.float32)
+    r = F.polyexp(img, n, 1.2)[n:-n, n:-n].astype(np.float64)
+    x, y = xx[n:-n, n:-n], yy[n:-n, n:-n]
+    np.testing.assert_allclose(r[..., 0], b + 2 * e * y + f * x, atol=2e-4)
+    np.testing.assert_allclose(r[..., 1], a + 2 * d * x + f * y, atol=2e-4)
+    np.testing.assert_allclose(r[..., 2], e, atol=2e-5)
+    np.testing.assert_allclose(r[..., 3], d, atol=2e-5)
+    np.testing.assert_allclose(r[..., 4], f, atol=2e-5)
+
+
+def test_identical_frames_zero_flow_in_interior():
+    a = _texture(160, 200)
+    # OpenCV treats R1 as absent on the last row/column (UpdateMatrices' bounds test), so a
+    # small residual exists near the bottom/right edge; the box window (m=7) spreads it
+    # 7 px per iteration at one scale, further through the coarse scales of a pyramid
+    fl = F.calc(a, a, levels=0, iterations=1)
+    assert np.abs(fl[:-8, :-8]).max() == 0.0
+    assert np.abs(fl).max() > 0.0
+    a = _texture(320, 400)
+    fl = F.calc(a, a)
+    assert np.abs(fl[:160, :240]).max() == 0.0
+    assert np.abs(fl).max() < 0.5
+
+
+@pytest.mark.parametrize("t", [(2, 1), (-3, 4), (0.5, -0.25)])
+def test_translation_recovered(t):
+    a, b = _texture(200, 260), _texture(200, 260, *t)
+    fl = F.calc(a, b)[30:-30, 30:-30]
+    tol = 0.01 if all(float(v).is_integer() for v in t) else 0.1
+    assert np.abs(fl[..., 0] - t[0]).max() < tol
+    assert np.abs(fl[..., 1] - t[1]).max() < tol
+
+
+def test_swap_negates():
+    a, b = _texture(160, 200), _texture(160, 200, 2, -1)
+    f1 = F.calc(a, b)[30:-30, 30:-30]
+    f2 = F.calc(b, a)[30:-30, 30:-30]
+    assert np.abs(f1 + f2).max() < 0.02
+
+
+def test_single_scale_and_small_frames():
+    a, b = _texture(48, 64), _texture(48, 64, 1, 0)
+    fl = F.calc(a, b, levels=0)
+    assert fl.shape == (48, 64, 2) and np.isfinite(fl).all()
+    # frames smaller than min_size still run (K=0)
+    fl = F.calc(a[:20, :24].copy(), b[:20, :24].copy(), levels=3)
+    assert np.isfinite(fl).all()
+    with pytest.raises(ValueError):
+        F.calc(a, b, flags=4)
+
+
+def test_against_cv2_when_available():
+    cv2 = pytest.importorskip("cv2")
+    a, b = _texture(240, 320), _texture(240, 320, 2.5, -1.5)
+    for levels in (0, 3):
+        ref = cv2.calcOpticalFlowFarneback(a, b, None, 0.5, levels, 15, 3, 5, 1.2, 0)
+        got = F.calc(a, b, levels=levels)
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= tol

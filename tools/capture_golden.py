@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/remap_*.npz by RUNNING the reference's own code.
+
+Run in the build container only (``/root/reference`` does not exist on the
+GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/capture_golden.py
+
+It imports the importable half of the reference (the
+compositor, ``FlowSource.post_process`` and their helpers), feeds seeded
+inputs, and stores inputs + the reference's outputs as small ``.npz`` files.
+Only DATA is written to the repo -- no reference source.  The Farnebäck half
+cannot be captured (it lives in cv2, absent here): see oracle/farneback_ref.c.
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from transflow.compositor import Compositor  # noqa: E402
+from transflow.compositor.layers.move_reference import MoveReferenceLayer  # noqa: E402
+from transflow.config import LayerConfig  # noqa: E402
+from transflow.flow.sources.source import FlowSource  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+class FakeSource:
+    """Stands in for PixmapSourceInterface (pixmap_source_interface.py:12-37)."""
+
+    def __init__(self, frames, introduction_mask):
+        self.frames = list(frames)
+        self.introduction_mask = introduction_mask
+        self.counter = -1
+
+    def next(self, timeout=1):
+        self.counter += 1
+        return self.frames[self.counter % len(self.frames)]
+
+    @property
+    def frame_number(self):
+        return self.counter
+
+
+def make_fs(direction, h, w):
+    return FlowSource(direction, w, h, 30.0, None, 0, 0, 0)
+
+
+def capture_post_process():
+    out = {}
+    rng = np.random.default_rng(101)
+    idx = 0
+    for (h, w) in [(1, 6), (16, 24), (37, 53)]:
+        for sigma in [0.4, 3.0, 40.0]:
+            for direction in (FlowSource.Direction.FORWARD, FlowSource.Direction.BACKWARD):
+                flow = rng.normal(0, sigma, (h, w, 2)).astype(np.float32)
+                fs = make_fs(direction, h, w)
+                res = fs.post_process(flow.copy())
+                out[f"in_{idx}"] = flow
+                out[f"out_{idx}"] = np.asarray(res, dtype=np.float32)
+                out[f"dir_{idx}"] = np.int32(direction.value)
+                idx += 1
+    # ties: exact halves exercise round-half-even; collisions exercise last-write-wins
+    h, w = 5, 9
+    flow = np.zeros((h, w, 2), np.float32)
+    vals = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, -3.5, 0.49999997]
+    for j, v in enumerate(vals):
+        flow[1, j, 0] = v
+        flow[2, j, 1] = v
+        flow[3, j, :] = (v, -v)
+    flow[0, :, 0] = np.arange(w)[::-1] - np.arange(w)  # every pixel of row 0 lands mirrored
+    flow[4, :, 0] = 4 - np.arange(w)                   # whole row collides on column 4
+    for direction in (FlowSource.Direction.FORWARD, FlowSource.Direction.BACKWARD):
+        fs = make_fs(direction, h, w)
+        res = fs.post_process(flow.copy())
+        out[f"in_{idx}"] = flow
+        out[f"out_{idx}"] = np.asarray(res, dtype=np.float32)
+        out[f"dir_{idx}"] = np.int32(direction.value)
+        idx += 1
+    out["count"] = np.int32(idx)
+    np.savez_compressed(os.path.join(OUT, "remap_post_process.npz"), **out)
+    print("post_process cases:", idx)
+
+
+def smooth_mask(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = 0.5 + 0.5 * np.sin(xx / 3.1 + rng.uniform(0, 6)) * np.cos(yy / 2.3 + rng.uniform(0, 6))
+    return m.astype(np.float32)
+
+
+def run_layer_case(name, h, w, cfg_kwargs, nframes, rng, sigma=2.5, rgba_pixmap=False,
+                   two_sources=False, masks=None, direction=FlowSource.Direction.BACKWARD,
+                   background="#ffffff"):
+    """Runs one MoveReferenceLayer recurrence through the reference and
+    returns a dict of inputs and per-frame outputs."""
+    masks = masks or {}
+    cfg = LayerConfig(0, **cfg_kwargs)
+    layer = MoveReferenceLayer(cfg, h, w, [])
+    # arbitrary mask arrays are installed on the layer object directly; the
+    # reference's loaders (utils.py:51-144) are host-side parsing, not the path
+    for k, v in masks.items():
+        setattr(layer, k, v)
+    c = 4 if rgba_pixmap else 3
+    intro = [np.ones((h, w), dtype=bool)]
+    if two_sources:
+        m1 = np.zeros((h, w), dtype=bool)
+        m1[:, w // 2:] = True
+        m1[h // 3: h // 2, : w // 4] = True
+        intro.append(m1)
+    pixmaps = [rng.integers(0, 256, (nframes, h, w, c), dtype=np.uint8) for _ in intro]
+    sources = [FakeSource(list(pm), im) for pm, im in zip(pixmaps, intro)]
+    layer.set_sources(sources)
+    comp = Compositor(h, w, [layer], background_color=background)
+    fs = make_fs(direction, h, w)
+    d = {
+        "h": np.int32(h), "w": np.int32(w), "nframes": np.int32(nframes),
+        "nsources": np.int32(len(intro)),
+        "mask_src": layer.mask_src.copy(), "mask_dst": layer.mask_dst.copy(),
+        "mask_alpha": layer.mask_alpha.copy(), "reset_mask": layer.reset_mask.copy(),
+        "data_init": layer.data.copy(),
+        "background": np.array(comp.background_color, dtype=np.uint8),
+        "cfg_keys": np.array(sorted(cfg_kwargs.keys())),
+        "cfg_vals": np.array([str(cfg_kwargs[k]) for k in sorted(cfg_kwargs.keys())]),
+    }
+    for s, (pm, im) in enumerate(zip(pixmaps, intro)):
+        d[f"pixmap_{s}"] = pm
+        d[f"intro_{s}"] = im
+    orig_random = np.random.random
+    for t in range(nframes):
+        raw = rng.normal(0, sigma, (h, w, 2)).astype(np.float32)
+        flow = np.asarray(fs.post_process(raw.copy()), dtype=np.float32)
+        u = rng.random((h, w))
+        np.random.random = lambda size=None, _u=u: _u.copy()
+        try:
+            comp.update(flow)
+        finally:
+            np.random.random = orig_random
+        d[f"flow_{t}"] = flow
+        d[f"u_{t}"] = u
+        d[f"data_{t}"] = layer.data.copy()
+        d[f"rgba_{t}"] = layer.rgba.copy()
+        d[f"frame_{t}"] = comp.render().copy()
+        d[f"rgba_after_render_{t}"] = layer.rgba.copy()
+    return d
+
+
+def capture_layers():
+    rng = np.random.default_rng(202)
+    cases = {}
+    # 1. the 2^4 move flags, default masks, no reset (16x24, 3 frames, RGB).
+    #    Transparent pixels only exist once leave_empty_spot made some.
+    for bits in range(16):
+        kw = dict(
+            transparent_pixels_can_move=bool(bits & 1),
+            pixels_can_move_to_empty_spot=bool(bits & 2),
+            pixels_can_move_to_filled_spot=bool(bits & 4),
+            moving_pixels_leave_empty_spot=bool(bits & 8),
+        )
+        cases[f"flags{bits:02d}"] = run_layer_case(f"flags{bits}", 16, 24, kw, 3, rng)
+    # 2. the same flags with an alpha pattern that already has holes (via reset off and
+    #    a first frame run with leave_empty) -- longer recurrence, odd size
+    for bits in (8, 9, 10, 12, 13, 15):
+        kw = dict(
+            transparent_pixels_can_move=bool(bits & 1),
+            pixels_can_move_to_empty_spot=bool(bits & 2),
+            pixels_can_move_to_filled_spot=bool(bits & 4),
+            moving_pixels_leave_empty_spot=bool(bits & 8),
+        )
+        cases[f"holes{bits:02d}"] = run_layer_case(f"holes{bits}", 37, 53, kw, 5, rng, sigma=4.0)
+    # 3. masks
+    h, w = 37, 53
+    msrc = rng.random((h, w)) < 0.7
+    mdst = rng.random((h, w)) < 0.6
+    malpha = smooth_mask(rng, h, w)
+    cases["masks_bool"] = run_layer_case("masks_bool", h, w, {}, 4, rng,
+                                         masks={"mask_src": msrc, "mask_dst": mdst})
+    cases["masks_alpha"] = run_layer_case("masks_alpha", h, w, {}, 3, rng,
+                                          masks={"mask_alpha": malpha}, background="#204060")
+    cases["masks_spec"] = run_layer_case(
+        "masks_spec", h, w,
+        dict(mask_src="border:2", mask_dst="circle:40%", mask_alpha="rect:60%:inv"), 3, rng)
+    # 4. random reset
+    for p in (0.1, 0.5, 1.0):
+        rm = smooth_mask(rng, h, w)
+        cases[f"reset_random_p{int(p * 10):02d}"] = run_layer_case(
+            "reset", h, w, dict(reset_mode="random", reset_random_factor=p), 4, rng,
+            masks={"reset_mask": rm})
+    cases["reset_random_leave"] = run_layer_case(
+        "reset_leave", h, w,
+        dict(reset_mode="random", reset_random_factor=0.3, moving_pixels_leave_empty_spot=True,
+             transparent_pixels_can_move=True), 5, rng,
+        masks={"reset_mask": rng.random((h, w)).astype(np.float32)})
+    cases["reset_random_source"] = run_layer_case(
+        "reset_source", h, w,
+        dict(reset_mode="random", reset_random_factor=0.4, reset_source=True), 4, rng,
+        two_sources=True, masks={"reset_mask": smooth_mask(rng, h, w)})
+    # 5. pixmaps: RGBA, two sources (RGB quirk: only the last source stays opaque)
+    cases["rgba_pixmap"] = run_layer_case("rgba", 16, 24, {}, 3, rng, rgba_pixmap=True)
+    cases["two_sources_rgb"] = run_layer_case("two_rgb", 16, 24, {}, 3, rng, two_sources=True)
+    cases["two_sources_rgba"] = run_layer_case("two_rgba", 16, 24, {}, 3, rng, two_sources=True,
+                                               rgba_pixmap=True)
+    # 6. FORWARD-direction flows feeding the layer
+    cases["forward_dir"] = run_layer_case("fwd", h, w, {}, 4, rng,
+                                          direction=FlowSource.Direction.FORWARD, sigma=3.0)
+    # 7. other reset modes
+    cases["reset_constant"] = run_layer_case(
+        "reset_constant", h, w, dict(reset_mode="constant", reset_constant_step=1.7), 5, rng,
+        masks={"reset_mask": smooth_mask(rng, h, w)})
+    cases["reset_linear"] = run_layer_case(
+        "reset_linear", h, w, dict(reset_mode="linear", reset_linear_factor=0.35), 5, rng,
+        masks={"reset_mask": smooth_mask(rng, h, w)})
+    # 8. bigger frame, default transflow configuration
+    cases["default_72x96"] = run_layer_case("default", 72, 96, {}, 2, rng, sigma=5.0)
+    for name, d in cases.items():
+        np.savez_compressed(os.path.join(OUT, f"remap_layer_{name}.npz"), **d)
+    print("layer cases:", len(cases))
+
+
+def capture_known_answers():
+    """tests/test_compositor.py:20-54 re-run, outputs stored."""
+    d = {}
+    d["basic_render"] = Compositor(1, 1, [], background_color="#ff8000").render()
+    flow = np.array([[[0, 1], [0, 1], [0, 0]], [[0, 0], [0, 0], [0, 0]]]).astype(np.float32)
+    d["flow"] = flow
+    layer = MoveReferenceLayer(LayerConfig(0), 2, 3, [])
+    layer.update(flow)
+    d["moveref_data"] = layer.data.copy()
+    layer = MoveReferenceLayer(LayerConfig(0, reset_mode="random", reset_random_factor=1), 2, 3, [])
+    layer.update(flow)
+    d["moveref_reset_data"] = layer.data.copy()
+    layer = MoveReferenceLayer(LayerConfig(0, reset_mode="random", reset_random_factor=1,
+                                           reset_mask="border-left:1"), 2, 3, [])
+    layer.update(flow)
+    d["moveref_reset_mask_data"] = layer.data.copy()
+    d["moveref_reset_mask"] = layer.reset_mask.copy()
+    np.savez_compressed(os.path.join(OUT, "remap_known_answers.npz"), **d)
+
+
+def capture_multilayer():
+    """Two moveref layers over one background (compositor.py:31-40 order)."""
+    rng = np.random.default_rng(303)
+    h, w = 24, 32
+    l0 = MoveReferenceLayer(LayerConfig(0), h, w, [])
+    l1 = MoveReferenceLayer(LayerConfig(1, moving_pixels_leave_empty_spot=True), h, w, [])
+    l1.mask_alpha = (rng.random((h, w)) < 0.5).astype(np.float32)
+    pm0 = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    pm1 = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    l0.set_sources([FakeSource(list(pm0), np.ones((h, w), bool))])
+    l1.set_sources([FakeSource(list(pm1), np.ones((h, w), bool))])
+    comp = Compositor(h, w, [l0, l1], background_color="#123456")
+    fs = make_fs(FlowSource.Direction.BACKWARD, h, w)
+    d = {"h": np.int32(h), "w": np.int32(w), "pixmap_l0": pm0, "pixmap_l1": pm1,
+         "mask_alpha_l1": l1.mask_alpha.copy(),
+         "background": np.array(comp.background_color, dtype=np.uint8)}
+    for t in range(3):
+        flow = np.asarray(fs.post_process(rng.normal(0, 3, (h, w, 2)).astype(np.float32)), np.float32)
+        comp.update(flow)
+        d[f"flow_{t}"] = flow
+        d[f"frame_{t}"] = comp.render().copy()
+        d[f"data_l0_{t}"] = l0.data.copy()
+        d[f"data_l1_{t}"] = l1.data.copy()
+    np.savez_compressed(os.path.join(OUT, "remap_multilayer.npz"), **d)
+
+
+if __name__ == "__main__":
+    capture_post_process()
+    capture_layers()
+    capture_known_answers()
+    capture_multilayer()
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", total)
