@@ -97,8 +97,8 @@ def test_identical_frames_zero_flow_in_interior():
     assert np.abs(fl[:-8, :-8]).max() == 0.0
     assert np.abs(fl).max() > 0.0
     a = _texture(320, 400)
-    fl = F.calc(a, a)
-    assert np.abs(fl[:160, :240]).max() == 0.0
+    fl = F.calc(a, a, levels=2)
+    assert np.abs(fl[:100, :100]).max() == 0.0
     assert np.abs(fl).max() < 0.5
 
 
