@@ -1,0 +1,192 @@
+/*
+ * tfhip.h -- C ABI of libtfhip.so: the MI355X (gfx950) backend for transflow's
+ * per-frame hot loop (Farnebäck dense optical flow + compositor remap).
+ *
+ * This is the drop-in boundary.  Plain C types only: pointers,
+ * sizes, POD structs.  Host pointers are borrowed for the duration of a call;
+ * the library owns all device memory, tied to the opaque handles.  Every
+ * function returns TF_OK (0) or a negative tf_status; the message of the last
+ * failure on the calling thread is tf_last_error().  No HIP call happens at
+ * load time: the first tf_init()/tf_*_create() initialises the runtime (the
+ * reference runs the flow source in a forked child, pipeline.py:56-64).
+ *
+ * Each entry point cites the reference interface it replaces; paths are
+ * relative to the reference tree (ychalier/transflow v1.11.1).
+ */
+#ifndef TFHIP_H
+#define TFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFHIP_ABI_VERSION 1
+
+typedef enum tf_status {
+    TF_OK = 0,
+    TF_ERR_ARG = -1,     /* bad argument (ValueError on the Python side) */
+    TF_ERR_HIP = -2,     /* a HIP runtime call failed (RuntimeError) */
+    TF_ERR_INDEX = -3,   /* a flow vector leaves the frame: the reference raises IndexError
+                            at compositor/layers/movement.py:33,39 */
+    TF_ERR_STATE = -4,   /* call order / handle state */
+    TF_ERR_UNSUPPORTED = -5
+} tf_status;
+
+/* ---- runtime ------------------------------------------------------------------ */
+int tf_abi_version(void);
+/* Select the GPU for this process/thread and create the library stream.  Idempotent. */
+int tf_init(int device);
+int tf_device_count(int *count);
+const char *tf_last_error(void);
+/* Block until everything queued on the library stream has finished. */
+int tf_sync(void);
+/* The hipStream_t all kernels of this library are launched on (for callers that
+   record their own events or enqueue RCCL work in order with it). */
+int tf_stream(void **hip_stream);
+
+/* Events on the library stream (HIP events; bench.py times with these). */
+typedef struct tf_event tf_event;
+int tf_event_create(tf_event **ev);
+int tf_event_record(tf_event *ev);
+int tf_event_elapsed_ms(tf_event *start, tf_event *stop, float *ms); /* synchronises on stop */
+void tf_event_destroy(tf_event *ev);
+
+/* Per-kernel timing: when enabled every launch is bracketed by HIP events on the
+   library stream.  tf_prof_report writes lines "name count total_ms" into buf. */
+int tf_prof_enable(int on);
+int tf_prof_reset(void);
+int tf_prof_report(char *buf, size_t buf_size);
+
+/* Raw device buffers, for harnesses that keep inputs resident in HBM. */
+int tf_dev_alloc(void **dev, size_t bytes);
+int tf_dev_free(void *dev);
+int tf_dev_upload(void *dev, const void *host, size_t bytes);
+int tf_dev_download(void *host, const void *dev, size_t bytes);
+
+/* ---- Farnebäck dense optical flow ----------------------------------------------
+ * Replaces cv2.calcOpticalFlowFarneback as called at
+ * transflow/flow/sources/cv.py:479-490; parameter struct = the fb_* fields of
+ * CvFlowConfig (cv.py:273-281).  flags: 0 only (transflow's default).
+ */
+typedef struct tf_fb_params {
+    double pyr_scale;  /* fb_pyr_scale  (0.5)  */
+    int levels;        /* fb_levels     (3)    */
+    int winsize;       /* fb_winsize    (15)   */
+    int iterations;    /* fb_iterations (3)    */
+    int poly_n;        /* fb_poly_n     (5)    */
+    double poly_sigma; /* fb_poly_sigma (1.2)  */
+    int flags;         /* fb_flags      (0)    */
+} tf_fb_params;
+
+typedef struct tf_fb tf_fb;
+
+/* frame_slots: how many uint8 grey frames the handle keeps resident in HBM;
+   max_pairs: how many frame pairs one tf_fb_calc_slots call may process. */
+int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params, int frame_slots, int max_pairs);
+void tf_fb_destroy(tf_fb *fb);
+
+/* One pair, host in / host out: flow_out is float32 [height][width][2] (x=dx, y=dy),
+   exactly the array cv.py:479-490 produces.  Strides in bytes. */
+int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint8_t *next, ptrdiff_t next_stride,
+               float *flow_out);
+
+/* Resident path: upload grey frames into slots, compute n pairs in one pass
+   (pairs are independent with flags == 0: cv.py:478,489), read results back or
+   hand the device pointer on. */
+int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t stride);
+int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev);
+int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const int *next_slots);
+int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out);
+int tf_fb_flow_ptr(tf_fb *fb, int pair, void **dev);
+
+/* FlowSource.post_process (transflow/flow/sources/source.py:337-363) without the
+   optional filter/mask/kernel pre-steps: direction 0 = FORWARD (clip, round,
+   scatter-invert with last-write-wins, :349-360), 1 = BACKWARD; both end with the
+   clip to the frame (:361-362).  In place. */
+int tf_fb_post_process(tf_fb *fb, int pair, int direction);                 /* device flow of `pair` */
+int tf_fb_post_process_host(tf_fb *fb, float *flow_inout, int direction);   /* host array, same H,W */
+
+/* Stage-level entry points (debug/parity tests): run one stage of the pyramid on
+   host arrays with exactly the kernels the full path uses.  Layouts as OpenCV's:
+   R and M are [H][W][5] interleaved on the host side. */
+int tf_fb_stage_level_image(tf_fb *fb, const uint8_t *grey, ptrdiff_t stride, int level, float *out /*[Hk][Wk]*/);
+int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out /*[h][w][5]*/);
+int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, const float *flow, int w, int h,
+                                float *m_out /*[h][w][5]*/);
+int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out /*[h][w][2]*/);
+int tf_fb_level_count(tf_fb *fb, int *n_scales); /* K+1 */
+int tf_fb_level_size(tf_fb *fb, int level, int *w, int *h);
+
+/* ---- compositor remap (one `moveref` layer) -------------------------------------
+ * Replaces MoveReferenceLayer (transflow/compositor/layers/move_reference.py:6-14):
+ * MovementLayer.update (movement.py:20-64), ReferenceLayer.update
+ * (reference.py:58-109), Layer.render (layer.py:32-34).  tf_layer_cfg carries the
+ * LayerConfig fields the layer reads (transflow/config.py:88-98).
+ */
+typedef struct tf_layer_cfg {
+    int transparent_pixels_can_move;    /* False */
+    int pixels_can_move_to_empty_spot;  /* True  */
+    int pixels_can_move_to_filled_spot; /* True  */
+    int moving_pixels_leave_empty_spot; /* False */
+    int reset_mode;                     /* 0 off, 1 random, 2 constant, 3 linear (reference.py:16-21) */
+    double reset_random_factor;         /* 1   */
+    double reset_constant_step;         /* 1   */
+    double reset_linear_factor;         /* 0.1 */
+    int reset_source;                   /* False */
+} tf_layer_cfg;
+
+typedef struct tf_remap tf_remap;
+typedef struct tf_comp tf_comp;
+
+/* Masks are [height][width]; NULL = the reference's default (mask_src/mask_dst all
+   true, mask_alpha/reset_mask all 1.0: layer.py:24, movement.py:14-15, reference.py:44).
+   data starts as (i, j, 1, 0) per pixel (reference.py:40-42). */
+int tf_remap_create(tf_remap **out, int height, int width, const tf_layer_cfg *cfg, const uint8_t *mask_src,
+                    const uint8_t *mask_dst, const float *mask_alpha, const float *reset_mask);
+void tf_remap_destroy(tf_remap *layer);
+
+/* ReferenceLayer.set_sources (reference.py:54-56): remembers the introduction masks
+   (uint8 [height][width] each) and writes source index s where mask s is set. */
+int tf_remap_set_sources(tf_remap *layer, int n_sources, const uint8_t *const *introduction_masks);
+
+/* MovementLayer.update + ReferenceLayer._update_reset.  `flow` float32 [H][W][2]
+   (already post-processed).  `uniform`: float64 [H][W] in [0,1) -- the field the
+   reference draws with numpy.random.random (reference.py:59) -- or NULL to draw it
+   on the GPU from `seed` and the handle's frame counter.  Returns TF_ERR_INDEX if a
+   rounded flow vector leaves the frame (state is then unchanged). */
+int tf_remap_update(tf_remap *layer, const float *flow, const double *uniform, uint64_t seed);
+int tf_remap_update_dev(tf_remap *layer, const void *flow_dev, const void *uniform_dev, uint64_t seed);
+/* Deferred form of the range check for the resident path: 1 if any update_dev since
+   the last call saw an out-of-frame vector (those updates were skipped). */
+int tf_remap_check(tf_remap *layer, int *out_of_frame);
+
+/* One iteration of ReferenceLayer._update_rgba's loop (reference.py:94-105) for
+   source `source_index`; pixmap is uint8 [H][W][channels], channels 3 or 4. */
+int tf_remap_gather(tf_remap *layer, int source_index, const uint8_t *pixmap, int channels);
+int tf_remap_gather_dev(tf_remap *layer, int source_index, const void *pixmap_dev, int channels);
+
+/* Layer.render (layer.py:32-34) + this layer's turn in Compositor.render
+   (compositor.py:36-39): alpha := uint8(mask_alpha*alpha) in place, then paint the
+   opaque pixels onto the compositor image. */
+int tf_remap_render(tf_remap *layer, tf_comp *comp);
+
+/* State exchange for checkpoints (pipeline.py:225-242 pickles the compositor) and
+   for extra/control.py:146-162 which reads layer.data.  data int32 [H][W][4]
+   (i, j, alpha, source), rgba uint8 [H][W][4]; either pointer may be NULL. */
+int tf_remap_get_state(tf_remap *layer, int32_t *data, uint8_t *rgba);
+int tf_remap_set_state(tf_remap *layer, const int32_t *data, const uint8_t *rgba);
+
+/* Compositor image (compositor.py:17-40): background colour + output frame. */
+int tf_comp_create(tf_comp **out, int height, int width, const uint8_t background_rgb[3]);
+void tf_comp_destroy(tf_comp *comp);
+int tf_comp_begin(tf_comp *comp);                      /* image = background.copy() (:35) */
+int tf_comp_download(tf_comp *comp, uint8_t *rgb_out); /* uint8 [H][W][3] (:40) */
+int tf_comp_image_ptr(tf_comp *comp, void **dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHIP_H */

@@ -1,0 +1,185 @@
+"""GPU parity, Farnebäck half: libtfhip.so (through the C ABI) against the C oracle
+(oracle/farneback_ref.c).  Stages whose arithmetic order is fixed (pre-blur +
+resize, polynomial expansion, update-matrices) must be bit-identical; the box-blur
+solve sums its window in a different order (double), so it and the whole call are
+held to the tolerance north_star states: max|d| <= 1e-4 * max(1, max|ref|)."""
+import numpy as np
+import pytest
+
+from oracle import farneback as O
+from tests.helpers import synth_pair
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def flow_tol(ref):
+    return TOL * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.fixture(scope="module")
+def FB():
+    from transflow_amd.farneback import Farneback
+    return Farneback
+
+
+@pytest.mark.parametrize("shape,levels", [((270, 480), 3), ((135, 241), 2), ((480, 854), 3), ((1080, 1920), 5)])
+def test_level_images_bit_exact(FB, shape, levels):
+    h, w = shape
+    a, _ = synth_pair(h, w, seed=11)
+    fb = FB(w, h, levels=levels)
+    sizes = fb.level_sizes()
+    assert len(sizes) == O.num_levels(w, h, 0.5, levels) + 1
+    for k, (wk, hk) in enumerate(sizes):
+        assert (wk, hk) == O.level_geometry(w, h, 0.5, k)[:2]
+        np.testing.assert_array_equal(fb.stage_level_image(a, k), O.level_image(a, 0.5, k), err_msg=f"level {k}")
+    fb.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (67, 131), (16, 200), (270, 480), (5, 7)])
+@pytest.mark.parametrize("poly", [(5, 1.2), (7, 1.5), (3, 0.0)])
+def test_polyexp_bit_exact(FB, shape, poly):
+    h, w = shape
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 255, (h, w)).astype(np.float32)
+    fb = FB(max(w, 32), max(h, 32), levels=0, poly_n=poly[0], poly_sigma=poly[1])
+    np.testing.assert_array_equal(fb.stage_polyexp(img), O.polyexp(img, *poly))
+    fb.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (67, 131), (270, 480), (11, 13)])
+def test_update_matrices_bit_exact(FB, shape):
+    h, w = shape
+    rng = np.random.default_rng(4)
+    r0 = rng.normal(0, 3, (h, w, 5)).astype(np.float32)
+    r1 = rng.normal(0, 3, (h, w, 5)).astype(np.float32)
+    flow = rng.normal(0, 4, (h, w, 2)).astype(np.float32)
+    flow[0, 0] = (-3.5, 2.25)          # leaves the frame: the "else" branch
+    flow[h // 2, w // 2] = (1e4, -1e4)
+    fb = FB(max(w, 32), max(h, 32), levels=0)
+    np.testing.assert_array_equal(fb.stage_update_matrices(r0, r1, flow), O.update_matrices(r0, r1, flow))
+    fb.close()
+
+
+@pytest.mark.parametrize("shape,winsize", [((64, 64), 15), ((67, 531), 15), ((270, 480), 15), ((40, 50), 9),
+                                           ((33, 300), 4), ((9, 11), 15)])
+def test_blur_solve_close(FB, shape, winsize):
+    h, w = shape
+    rng = np.random.default_rng(5)
+    r = rng.normal(0, 3, (h, w, 5)).astype(np.float32)
+    # a plausible positive-definite system: M from update_matrices of random R's
+    m = O.update_matrices(r, rng.normal(0, 3, (h, w, 5)).astype(np.float32), np.zeros((h, w, 2), np.float32))
+    ref, _ = O.update_flow_blur(r, r, np.zeros((h, w, 2), np.float32), m, winsize, False)
+    fb = FB(max(w, 32), max(h, 32), levels=0, winsize=winsize)
+    got = fb.stage_blur_solve(m)
+    fb.close()
+    assert np.abs(got - ref).max() <= flow_tol(ref)
+
+
+CASES = [
+    ((270, 480), dict()),                                   # transflow defaults (cv.py:273-281)
+    ((480, 854), dict()),                                   # configs[0] geometry (River.mp4 854x480)
+    ((135, 241), dict(levels=2)),                           # odd sizes: non-integer resize ratios
+    ((200, 260), dict(levels=0)),                           # one scale
+    ((96, 128), dict(levels=5, winsize=9, iterations=2, poly_n=7, poly_sigma=1.5)),
+    ((40, 50), dict(levels=3)),                             # below min_size: K = 0
+    ((64, 300), dict(levels=1, pyr_scale=0.8)),
+]
+
+
+@pytest.mark.parametrize("shape,kw", CASES)
+def test_full_calc_close(FB, shape, kw):
+    h, w = shape
+    a, b = synth_pair(h, w, seed=21)
+    ref = O.calc(a, b, **kw)
+    fb = FB(w, h, **kw)
+    got = fb.calc(a, b)
+    assert got.dtype == np.float32 and got.shape == (h, w, 2)
+    err = np.abs(got - ref).max()
+    assert err <= flow_tol(ref), f"max|d|={err} tol={flow_tol(ref)}"
+    # the call is a pure function of its inputs: replay is bit-identical
+    np.testing.assert_array_equal(fb.calc(a, b), got)
+    fb.close()
+
+
+def test_1080p_default_and_levels5(FB):
+    h, w = 1080, 1920
+    a, b = synth_pair(h, w, seed=31)
+    for kw in (dict(levels=3), dict(levels=5)):
+        ref = O.calc(a, b, **kw)
+        fb = FB(w, h, **kw)
+        got = fb.calc(a, b)
+        fb.close()
+        err = np.abs(got - ref).max()
+        assert err <= flow_tol(ref), f"{kw}: max|d|={err} tol={flow_tol(ref)}"
+
+
+def test_4k_properties(FB):
+    """3840x2160 (BASELINE configs[3]): the oracle takes ~20 s here, so check it once at
+    levels=5, plus size-independent properties: identical frames give zero flow away from
+    the bottom/right edge; swapping the frames negates the field."""
+    h, w = 2160, 3840
+    a, b = synth_pair(h, w, seed=41)
+    fb = FB(w, h, levels=5)
+    got = fb.calc(a, b)
+    ref = O.calc(a, b, levels=5)
+    err = np.abs(got - ref).max()
+    assert err <= flow_tol(ref), f"max|d|={err}"
+    same = fb.calc(a, a)
+    assert np.abs(same[:1000, :2000]).max() == 0.0
+    back = fb.calc(b, a)
+    inner = (slice(200, -200), slice(200, -200))
+    assert np.abs(got[inner] + back[inner]).mean() < 0.05
+    fb.close()
+
+
+def test_batch_equals_single(FB):
+    h, w = 270, 480
+    frames = [synth_pair(h, w, seed=50 + i)[i % 2] for i in range(5)]
+    single = FB(w, h)
+    exp = [single.calc(frames[i], frames[i + 1]) for i in range(4)]
+    single.close()
+    fb = FB(w, h, frame_slots=5, max_pairs=4)
+    for i, f in enumerate(frames):
+        fb.set_frame(i, f)
+    fb.calc_slots([0, 1, 2, 3], [1, 2, 3, 4])
+    for i in range(4):
+        np.testing.assert_array_equal(fb.get_flow(i), exp[i])
+    # BACKWARD ordering (cv.py:470-472): (prev, next) = (current, previous)
+    fb.calc_slots([1], [0])
+    single = FB(w, h)
+    np.testing.assert_array_equal(fb.get_flow(0), single.calc(frames[1], frames[0]))
+    single.close()
+    fb.close()
+
+
+def test_strided_input_and_errors(FB):
+    h, w = 64, 96
+    a, b = synth_pair(h, w + 8, seed=60)
+    fb = FB(w, h)
+    ref = O.calc(np.ascontiguousarray(a[:, :w]), np.ascontiguousarray(b[:, :w]))
+    got = fb.calc(a[:, :w], b[:, :w])        # row stride > width
+    assert np.abs(got - ref).max() <= flow_tol(ref)
+    with pytest.raises(ValueError):
+        fb.calc(a, b)                         # wrong shape
+    with pytest.raises(ValueError):
+        fb.calc(a[:, :w].astype(np.float32), b[:, :w])
+    fb.close()
+    with pytest.raises(NotImplementedError):
+        FB(w, h, flags=4)
+    with pytest.raises(ValueError):
+        FB(w, h, pyr_scale=1.0)
+    with pytest.raises(ValueError):
+        FB(0, 0)
+
+
+def test_against_cv2_when_available(FB):
+    cv2 = pytest.importorskip("cv2")
+    h, w = 480, 854
+    a, b = synth_pair(h, w, seed=70)
+    ref = cv2.calcOpticalFlowFarneback(a, b, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+    fb = FB(w, h)
+    got = fb.calc(a, b)
+    fb.close()
+    assert np.abs(got - ref).max() <= flow_tol(ref)

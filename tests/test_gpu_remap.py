@@ -1,0 +1,211 @@
+"""GPU parity, remap half: libtfhip.so (through the C ABI) against vectors the
+reference itself produced (tests/golden, tools/capture_golden.py) and against the
+numpy oracle on larger seeded inputs.  Bit-exact: integer/byte/index work."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import remap_ref as R
+from tests.helpers import GOLDEN, PRM_KEYS, case_cfg, layer_case_files, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transflow_amd import farneback, remap
+    return farneback, remap
+
+
+def _pp(tf, flow, direction):
+    farneback, _ = tf
+    h, w, _ = flow.shape
+    fb = farneback.Farneback(w, h, levels=0)
+    out = fb.post_process_host(np.ascontiguousarray(flow.copy()), direction)
+    fb.close()
+    return out
+
+
+def test_post_process_golden(tf):
+    z = np.load(os.path.join(GOLDEN, "remap_post_process.npz"))
+    for i in range(int(z["count"])):
+        out = _pp(tf, z[f"in_{i}"], int(z[f"dir_{i}"]))
+        np.testing.assert_array_equal(out, z[f"out_{i}"], err_msg=f"case {i}")
+
+
+@pytest.mark.parametrize("shape,sigma", [((270, 480), 4.0), ((1080, 1920), 6.0), ((37, 1), 2.0), ((1, 1), 1.0)])
+def test_post_process_vs_oracle_large(tf, shape, sigma):
+    rng = np.random.default_rng(7)
+    flow = rng.normal(0, sigma, (*shape, 2)).astype(np.float32)
+    for d in (R.FORWARD, R.BACKWARD):
+        exp = R.post_process(flow.copy(), d)
+        got = _pp(tf, flow, d)
+        np.testing.assert_array_equal(got, exp)
+        # idempotence of the final clip: a BACKWARD pass over the result changes nothing
+        np.testing.assert_array_equal(_pp(tf, got, R.BACKWARD), got)
+
+
+def _make_layer(remap, h, w, cfg, z):
+    kw = {k: v for k, v in cfg.items() if k in PRM_KEYS}
+    return remap.RemapLayer(h, w, mask_src=z["mask_src"], mask_dst=z["mask_dst"], mask_alpha=z["mask_alpha"],
+                            reset_mask=z["reset_mask"], **kw)
+
+
+@pytest.mark.parametrize("path", layer_case_files(), ids=lambda p: os.path.basename(p)[12:-4])
+def test_layer_sequences_golden(tf, path):
+    _, remap = tf
+    z = np.load(path)
+    h, w = int(z["h"]), int(z["w"])
+    cfg = case_cfg(z)
+    ns = int(z["nsources"])
+    layer = _make_layer(remap, h, w, cfg, z)
+    layer.set_sources([z[f"intro_{s}"] for s in range(ns)])
+    comp = remap.CompImage(h, w, tuple(int(v) for v in z["background"]))
+    data, _ = layer.get_state()
+    np.testing.assert_array_equal(data, z["data_init"])
+    for t in range(int(z["nframes"])):
+        layer.update(z[f"flow_{t}"], z[f"u_{t}"])
+        for s in range(ns):
+            layer.gather(s, z[f"pixmap_{s}"][t])
+        data, rgba = layer.get_state()
+        np.testing.assert_array_equal(data, z[f"data_{t}"], err_msg=f"data t={t}")
+        np.testing.assert_array_equal(rgba, z[f"rgba_{t}"], err_msg=f"rgba t={t}")
+        comp.begin()
+        layer.render(comp)
+        np.testing.assert_array_equal(comp.download(), z[f"frame_{t}"], err_msg=f"frame t={t}")
+        _, rgba = layer.get_state()
+        np.testing.assert_array_equal(rgba, z[f"rgba_after_render_{t}"])
+
+
+def test_reference_known_answers(tf):
+    """reference tests/test_compositor.py:20-54 through the C ABI."""
+    _, remap = tf
+    z = np.load(os.path.join(GOLDEN, "remap_known_answers.npz"))
+    comp = remap.CompImage(1, 1, (255, 128, 0))
+    assert tuple(comp.download()[0, 0]) == (255, 128, 0)
+    flow = np.array([[[0, 1], [0, 1], [0, 0]], [[0, 0], [0, 0], [0, 0]]], np.float32)
+    layer = remap.RemapLayer(2, 3)
+    layer.update(flow)
+    data, _ = layer.get_state()
+    assert tuple(data[0, 0, :2]) == (1, 0) and tuple(data[0, 1, :2]) == (1, 1)
+    np.testing.assert_array_equal(data, z["moveref_data"])
+    layer = remap.RemapLayer(2, 3, reset_mode="random", reset_random_factor=1)
+    layer.update(flow, seed=123)   # on-device uniform field: u < 1 always
+    np.testing.assert_array_equal(layer.get_state()[0], z["moveref_reset_data"])
+    layer = remap.RemapLayer(2, 3, reset_mode="random", reset_random_factor=1, reset_mask=z["moveref_reset_mask"])
+    layer.update(flow, seed=5)
+    np.testing.assert_array_equal(layer.get_state()[0], z["moveref_reset_mask_data"])
+
+
+def test_multilayer_golden(tf):
+    _, remap = tf
+    z = np.load(os.path.join(GOLDEN, "remap_multilayer.npz"))
+    h, w = int(z["h"]), int(z["w"])
+    l0 = remap.RemapLayer(h, w)
+    l1 = remap.RemapLayer(h, w, moving_pixels_leave_empty_spot=True, mask_alpha=z["mask_alpha_l1"])
+    ones = np.ones((h, w), np.uint8)
+    l0.set_sources([ones])
+    l1.set_sources([ones])
+    comp = remap.CompImage(h, w, tuple(int(v) for v in z["background"]))
+    for t in range(3):
+        for layer, pm in ((l0, z["pixmap_l0"]), (l1, z["pixmap_l1"])):
+            layer.update(z[f"flow_{t}"])
+            layer.gather(0, pm[t])
+        np.testing.assert_array_equal(l0.get_state()[0], z[f"data_l0_{t}"])
+        np.testing.assert_array_equal(l1.get_state()[0], z[f"data_l1_{t}"])
+        comp.begin()
+        l0.render(comp)
+        l1.render(comp)
+        np.testing.assert_array_equal(comp.download(), z[f"frame_{t}"])
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (2160, 3840), (479, 853)])
+def test_full_size_recurrence_vs_oracle(tf, h, w):
+    """BASELINE sizes: 3-frame recurrence with every mask, random reset, leave-empty
+    and transparent moves, against the numpy oracle; then size-independent
+    properties (zero flow is the identity; state round-trips)."""
+    _, remap = tf
+    rng = np.random.default_rng(h * 7 + w)
+    prm = R.LayerParams(transparent_pixels_can_move=True, moving_pixels_leave_empty_spot=True,
+                        reset_mode="random", reset_random_factor=0.5)
+    msrc = rng.random((h, w)) < 0.9
+    mdst = rng.random((h, w)) < 0.9
+    malpha = rng.random((h, w)).astype(np.float32)
+    rmask = rng.random((h, w)).astype(np.float32)
+    ones = np.ones((h, w), bool)
+    ora = R.MoveRefLayer(h, w, prm, msrc, mdst, malpha, rmask, [ones])
+    gpu = remap.RemapLayer(h, w, transparent_pixels_can_move=True, moving_pixels_leave_empty_spot=True,
+                           reset_mode="random", reset_random_factor=0.5, mask_src=msrc, mask_dst=mdst,
+                           mask_alpha=malpha, reset_mask=rmask)
+    gpu.set_sources([ones])
+    comp = remap.CompImage(h, w, (10, 20, 30))
+    bg = np.broadcast_to(np.uint8([10, 20, 30]), (h, w, 3))
+    for t in range(3):
+        flow = R.post_process(rng.normal(0, 5, (h, w, 2)).astype(np.float32), R.BACKWARD)
+        u = rng.random((h, w))
+        pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ora.update(flow, [pm], u)
+        gpu.update(flow, u)
+        gpu.gather(0, pm)
+        data, rgba = gpu.get_state()
+        np.testing.assert_array_equal(data, ora.data)
+        np.testing.assert_array_equal(rgba, ora.rgba)
+        comp.begin()
+        gpu.render(comp)
+        np.testing.assert_array_equal(comp.download(), R.composite(bg, [ora.render()]))
+    # zero flow + no reset leaves data untouched
+    still = remap.RemapLayer(h, w)
+    still.set_state(data=ora.data)
+    still.update(np.zeros((h, w, 2), np.float32))
+    np.testing.assert_array_equal(still.get_state()[0], ora.data)
+
+
+def test_on_device_uniform_statistics(tf):
+    """With uniform=None the field is drawn on the GPU: the reset fraction must match
+    reset_random_factor * mean(mask) and differ from frame to frame."""
+    _, remap = tf
+    h, w = 512, 512
+    layer = remap.RemapLayer(h, w, reset_mode="random", reset_random_factor=0.25)
+    flow = np.zeros((h, w, 2), np.float32)
+    flow[..., 0] = 1.0
+    flow = R.post_process(flow, R.BACKWARD)
+    base = R.init_data(h, w)
+    fracs = []
+    prev = None
+    for t in range(3):
+        layer.set_state(data=np.where(np.ones((h, w, 1), bool), base + np.int32([1, 1, 0, 0]), base))
+        layer.update(np.zeros((h, w, 2), np.float32), seed=99)
+        data, _ = layer.get_state()
+        was_reset = (data[..., 0] == base[..., 0]) & (data[..., 1] == base[..., 1])
+        fracs.append(was_reset.mean())
+        if prev is not None:
+            assert (was_reset != prev).any()
+        prev = was_reset
+    assert all(abs(f - 0.25) < 0.01 for f in fracs), fracs
+
+
+def test_out_of_frame_is_index_error(tf):
+    _, remap = tf
+    layer = remap.RemapLayer(4, 4)
+    flow = np.zeros((4, 4, 2), np.float32)
+    flow[3, 3] = (2, 0)
+    before = layer.get_state()[0]
+    with pytest.raises(IndexError):
+        layer.update(flow)
+    np.testing.assert_array_equal(layer.get_state()[0], before)
+
+
+def test_argument_errors(tf):
+    _, remap = tf
+    with pytest.raises(ValueError):
+        remap.RemapLayer(4, 4, reset_mode="sometimes")
+    layer = remap.RemapLayer(4, 4)
+    with pytest.raises(ValueError):
+        layer.update(np.zeros((4, 5, 2), np.float32))
+    with pytest.raises(ValueError):
+        layer.gather(0, np.zeros((4, 4, 2), np.uint8))
+    # empty frame: every call is a no-op
+    empty = remap.RemapLayer(0, 0)
+    empty.update(np.zeros((0, 0, 2), np.float32))
+    assert empty.get_state()[0].shape == (0, 0, 4)

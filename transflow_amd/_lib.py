@@ -1,0 +1,139 @@
+"""ctypes binding of libtfhip.so (include/tfhip.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this
+module does not touch the GPU (the reference forks its flow source into a child
+process, pipeline.py:56-64); the first call does.  A missing or unloadable
+library raises ImportError loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfhip.so")
+
+TF_OK = 0
+TF_ERR_ARG = -1
+TF_ERR_HIP = -2
+TF_ERR_INDEX = -3
+TF_ERR_STATE = -4
+TF_ERR_UNSUPPORTED = -5
+
+
+class TfFbParams(C.Structure):
+    _fields_ = [("pyr_scale", C.c_double), ("levels", C.c_int), ("winsize", C.c_int),
+                ("iterations", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double),
+                ("flags", C.c_int)]
+
+
+class TfLayerCfg(C.Structure):
+    _fields_ = [("transparent_pixels_can_move", C.c_int), ("pixels_can_move_to_empty_spot", C.c_int),
+                ("pixels_can_move_to_filled_spot", C.c_int), ("moving_pixels_leave_empty_spot", C.c_int),
+                ("reset_mode", C.c_int), ("reset_random_factor", C.c_double),
+                ("reset_constant_step", C.c_double), ("reset_linear_factor", C.c_double),
+                ("reset_source", C.c_int)]
+
+
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_I = C.c_int
+_PI = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol include/tfhip.h declares
+PROTOTYPES = {
+    "tf_abi_version": (_I, []),
+    "tf_init": (_I, [_I]),
+    "tf_device_count": (_I, [_PI]),
+    "tf_last_error": (C.c_char_p, []),
+    "tf_sync": (_I, []),
+    "tf_stream": (_I, [_PP]),
+    "tf_event_create": (_I, [_PP]),
+    "tf_event_record": (_I, [_P]),
+    "tf_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
+    "tf_event_destroy": (None, [_P]),
+    "tf_prof_enable": (_I, [_I]),
+    "tf_prof_reset": (_I, []),
+    "tf_prof_report": (_I, [C.c_char_p, C.c_size_t]),
+    "tf_dev_alloc": (_I, [_PP, C.c_size_t]),
+    "tf_dev_free": (_I, [_P]),
+    "tf_dev_upload": (_I, [_P, _P, C.c_size_t]),
+    "tf_dev_download": (_I, [_P, _P, C.c_size_t]),
+    "tf_fb_create": (_I, [_PP, _I, _I, C.POINTER(TfFbParams), _I, _I]),
+    "tf_fb_destroy": (None, [_P]),
+    "tf_fb_calc": (_I, [_P, _P, C.c_ssize_t, _P, C.c_ssize_t, _P]),
+    "tf_fb_set_frame": (_I, [_P, _I, _P, C.c_ssize_t]),
+    "tf_fb_frame_ptr": (_I, [_P, _I, _PP]),
+    "tf_fb_calc_slots": (_I, [_P, _I, _PI, _PI]),
+    "tf_fb_get_flow": (_I, [_P, _I, _P]),
+    "tf_fb_flow_ptr": (_I, [_P, _I, _PP]),
+    "tf_fb_post_process": (_I, [_P, _I, _I]),
+    "tf_fb_post_process_host": (_I, [_P, _P, _I]),
+    "tf_fb_stage_level_image": (_I, [_P, _P, C.c_ssize_t, _I, _P]),
+    "tf_fb_stage_polyexp": (_I, [_P, _P, _I, _I, _P]),
+    "tf_fb_stage_update_matrices": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "tf_fb_stage_blur_solve": (_I, [_P, _P, _I, _I, _P]),
+    "tf_fb_level_count": (_I, [_P, _PI]),
+    "tf_fb_level_size": (_I, [_P, _I, _PI, _PI]),
+    "tf_remap_create": (_I, [_PP, _I, _I, C.POINTER(TfLayerCfg), _P, _P, _P, _P]),
+    "tf_remap_destroy": (None, [_P]),
+    "tf_remap_set_sources": (_I, [_P, _I, C.POINTER(C.c_void_p)]),
+    "tf_remap_update": (_I, [_P, _P, _P, C.c_uint64]),
+    "tf_remap_update_dev": (_I, [_P, _P, _P, C.c_uint64]),
+    "tf_remap_check": (_I, [_P, _PI]),
+    "tf_remap_gather": (_I, [_P, _I, _P, _I]),
+    "tf_remap_gather_dev": (_I, [_P, _I, _P, _I]),
+    "tf_remap_render": (_I, [_P, _P]),
+    "tf_remap_get_state": (_I, [_P, _P, _P]),
+    "tf_remap_set_state": (_I, [_P, _P, _P]),
+    "tf_comp_create": (_I, [_PP, _I, _I, C.POINTER(C.c_uint8)]),
+    "tf_comp_destroy": (None, [_P]),
+    "tf_comp_begin": (_I, [_P]),
+    "tf_comp_download": (_I, [_P, _P]),
+    "tf_comp_image_ptr": (_I, [_P, _PP]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libtfhip.so and binds every prototype.  No GPU call is made."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C transflow_amd/csrc` (hipcc, gfx950). transflow_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as err:
+        raise ImportError(f"cannot load {LIB_PATH}: {err}") from err
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as err:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from err
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class TfError(RuntimeError):
+    """A HIP/runtime failure inside libtfhip.so."""
+
+
+def check(rc: int) -> None:
+    """Maps tf_status to the exception the reference's code would have raised
+    at that point, so pipeline.py's handlers fire (Errors)."""
+    if rc == TF_OK:
+        return
+    msg = (load().tf_last_error() or b"").decode("utf8", "replace")
+    if rc == TF_ERR_ARG:
+        raise ValueError(msg)
+    if rc == TF_ERR_INDEX:
+        raise IndexError(msg)
+    if rc == TF_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise TfError(f"tfhip error {rc}: {msg}")

@@ -1,0 +1,81 @@
+// Internal helpers shared by the translation units of libtfhip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/tfhip.h"
+
+#define TF_API extern "C" __attribute__((visibility("default")))
+
+namespace tf {
+
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+hipStream_t stream();
+int ensure_init();
+
+#define TF_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return tf::set_error(TF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                 __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define TF_TRY(expr)        \
+    do {                    \
+        int _rc = (expr);   \
+        if (_rc != TF_OK)   \
+            return _rc;     \
+    } while (0)
+
+#define TF_REQUIRE(cond, ...)                         \
+    do {                                              \
+        if (!(cond))                                  \
+            return tf::set_error(TF_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// Per-kernel profiler: brackets a launch with events when enabled.
+struct ProfScope {
+    explicit ProfScope(const char *name);
+    ~ProfScope();
+    int slot;
+};
+bool prof_enabled();
+
+// All launches go through this so that profiling and error capture are uniform.
+template <typename K, typename... Args>
+inline int launch(const char *name, K kernel, dim3 grid, dim3 block, size_t smem, Args... args)
+{
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0)
+        return TF_OK;
+    {
+        ProfScope ps(name);
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream(), args...);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return set_error(TF_ERR_HIP, "launch %s failed: %s", name, hipGetErrorString(e));
+    return TF_OK;
+}
+
+// Simple owning device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t n);
+    void release();
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+} // namespace tf

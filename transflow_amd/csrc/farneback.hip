@@ -1,0 +1,1079 @@
+// Farnebäck dense optical flow on gfx950 (hand-written HIP, no library calls).
+//
+// Replaces cv2.calcOpticalFlowFarneback as the reference calls it
+// (transflow/flow/sources/cv.py:479-490, parameters cv.py:273-281).  The stages are
+// those of OpenCV 4.x's CPU path (modules/video/src/optflowgf.cpp), restated in
+// SURVEY.md Appendix A:
+//   A1 pre-blur at full resolution + bilinear resize to the pyramid level
+//   A2 polynomial expansion (separable, float vertical pass, double horizontal pass)
+//   A3 update-matrices (bilinear gather of R1 at x+flow, 2x2 system per pixel)
+//   A4 box blur of the system (double sums) + 2x2 solve, fused with the next A3
+//   A5 coarse-to-fine flow upsampling, fused into the first A3 of each level
+//
+// Arithmetic discipline: every float/double operation is written in the order of
+// the CPU path and the file is compiled with -ffp-contract=off, so A1-A3 are
+// bit-identical to the scalar CPU statement; A4 sums the window directly in
+// double instead of OpenCV's running sums (differences ~1e-16 relative).
+//
+// HBM layout (per handle, sized for `max_pairs` frame pairs):
+//   frames  u8  [slot][H][W]
+//   img     f32 [pair][2][Hk*Wk]          level image of both frames
+//   R       f32 [pair][2][5][Hk*Wk]       polynomial coefficients, planar (SoA)
+//   M[2]    f32 [pair][5][Hk*Wk]          2x2 systems, planar, ping-pong
+//   lflow   f32 [2][pair][Hk*Wk][2]       per-level flow, ping-pong between levels
+// All stages are HBM-bound (<= ~60 flop/B); MFMA is not applicable.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int MAX_POLY_N = 15;
+
+struct PolyConst {
+    int n;
+    float g[MAX_POLY_N + 1], xg[MAX_POLY_N + 1], xxg[MAX_POLY_N + 1];
+    double ig11, ig03, ig33, ig55;
+};
+
+__host__ __device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len)
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------
+// A1, level 0 (and any level whose size equals the frame's): kszxksz blur with a
+// small kernel, fused row+column pass through LDS.  Tile 64x16, 256 threads.
+// ---------------------------------------------------------------------------------
+constexpr int B3_TW = 64, B3_TH = 16;
+
+__global__ void k_blur_small_u8(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs,
+                                float *__restrict__ img, int W, int H, const float *__restrict__ kern, int ksz)
+{
+    extern __shared__ float s_rows[]; // [(TH + 2r)][TW]
+    const int r = ksz >> 1;
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const int x0 = blockIdx.x * B3_TW, y0 = blockIdx.y * B3_TH;
+    const int rows = B3_TH + 2 * r;
+    for (int idx = threadIdx.x; idx < rows * B3_TW; idx += blockDim.x) {
+        int ry = idx / B3_TW, cx = idx % B3_TW;
+        int x = x0 + cx;
+        float acc = 0.f;
+        if (x < W) {
+            const uint8_t *s = src + (size_t)reflect101(y0 - r + ry, H) * W;
+            if (ksz == 3) {
+                acc = (float)s[x] * kern[1] + ((float)s[reflect101(x - 1, W)] + (float)s[reflect101(x + 1, W)]) * kern[2];
+            } else if (ksz == 5) {
+                acc = (float)s[x] * kern[2] +
+                      ((float)s[reflect101(x - 1, W)] + (float)s[reflect101(x + 1, W)]) * kern[3] +
+                      ((float)s[reflect101(x - 2, W)] + (float)s[reflect101(x + 2, W)]) * kern[4];
+            } else {
+                acc = kern[0] * (float)s[reflect101(x - r, W)];
+                for (int i = 1; i < ksz; i++)
+                    acc += kern[i] * (float)s[reflect101(x - r + i, W)];
+            }
+        }
+        s_rows[idx] = acc;
+    }
+    __syncthreads();
+    float *dst = img + (size_t)pi * W * H;
+    for (int idx = threadIdx.x; idx < B3_TH * B3_TW; idx += blockDim.x) {
+        int ty = idx / B3_TW, cx = idx % B3_TW;
+        int x = x0 + cx, y = y0 + ty;
+        if (x >= W || y >= H)
+            continue;
+        // LDS slot (ty + r +- i) holds image row reflect101(y +- i): the reflection was applied
+        // when the slot was filled
+        float acc = kern[r] * s_rows[(ty + r) * B3_TW + cx];
+        for (int i = 1; i <= r; i++) {
+            float a = s_rows[(ty + r + i) * B3_TW + cx];
+            float b = s_rows[(ty + r - i) * B3_TW + cx];
+            acc += kern[r + i] * (a + b);
+        }
+        dst[(size_t)y * W + x] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// A1, levels >= 1: row pass of the full-resolution blur, evaluated only at the two
+// source columns (sx, sx+1) each output column interpolates between.
+//   tmp [pairimg][H][Wk][2]
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float row_conv(const uint8_t *__restrict__ s, int col, int W, const float *__restrict__ kern,
+                                          int ksz)
+{
+    const int r = ksz >> 1;
+    if (ksz == 3)
+        return (float)s[col] * kern[1] + ((float)s[reflect101(col - 1, W)] + (float)s[reflect101(col + 1, W)]) * kern[2];
+    if (ksz == 5)
+        return (float)s[col] * kern[2] + ((float)s[reflect101(col - 1, W)] + (float)s[reflect101(col + 1, W)]) * kern[3] +
+               ((float)s[reflect101(col - 2, W)] + (float)s[reflect101(col + 2, W)]) * kern[4];
+    float acc;
+    if (col - r >= 0 && col + r < W) {
+        const uint8_t *p = s + col - r;
+        acc = kern[0] * (float)p[0];
+        for (int i = 1; i < ksz; i++)
+            acc += kern[i] * (float)p[i];
+    } else {
+        acc = kern[0] * (float)s[reflect101(col - r, W)];
+        for (int i = 1; i < ksz; i++)
+            acc += kern[i] * (float)s[reflect101(col - r + i, W)];
+    }
+    return acc;
+}
+
+__global__ void k_blur_rows(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs,
+                            float2 *__restrict__ tmp, int W, int H, int Wk, const int *__restrict__ xofs,
+                            const float *__restrict__ kern, int ksz)
+{
+    int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (dx >= Wk)
+        return;
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *s = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H + (size_t)y * W;
+    int sx = xofs[dx];
+    int sx1 = sx + 1 < W ? sx + 1 : sx;
+    float2 v;
+    v.x = row_conv(s, sx, W, kern, ksz);
+    v.y = sx1 != sx ? row_conv(s, sx1, W, kern, ksz) : v.x;
+    tmp[((size_t)pi * H + y) * Wk + dx] = v;
+}
+
+// Column pass at the two source rows (sy, sy+1) + horizontal lerp + vertical lerp.
+__device__ __forceinline__ float2 col_conv(const float2 *__restrict__ t, int row, int H, int Wk, int dx,
+                                           const float *__restrict__ kern, int ksz)
+{
+    const int r = ksz >> 1;
+    float2 c = t[(size_t)row * Wk + dx];
+    float2 acc = make_float2(kern[r] * c.x, kern[r] * c.y);
+    for (int i = 1; i <= r; i++) {
+        float2 a = t[(size_t)reflect101(row + i, H) * Wk + dx];
+        float2 b = t[(size_t)reflect101(row - i, H) * Wk + dx];
+        acc.x += kern[r + i] * (a.x + b.x);
+        acc.y += kern[r + i] * (a.y + b.y);
+    }
+    return acc;
+}
+
+__global__ void k_blur_cols_resize(const float2 *__restrict__ tmp, float *__restrict__ img, int W, int H, int Wk, int Hk,
+                                   const int *__restrict__ xofs, const float *__restrict__ xfrac,
+                                   const int *__restrict__ yofs, const float *__restrict__ yfrac,
+                                   const float *__restrict__ kern, int ksz)
+{
+    int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    int dy = blockIdx.y;
+    if (dx >= Wk)
+        return;
+    const int pi = blockIdx.z;
+    const float2 *t = tmp + (size_t)pi * H * Wk;
+    int sy = yofs[dy];
+    int sy0 = clampi(sy, 0, H - 1), sy1 = clampi(sy + 1, 0, H - 1);
+    float2 v0 = col_conv(t, sy0, H, Wk, dx, kern, ksz);
+    float2 v1 = sy1 != sy0 ? col_conv(t, sy1, H, Wk, dx, kern, ksz) : v0;
+    float fx = xfrac[dx], fy = yfrac[dy];
+    float h0, h1;
+    if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+        h0 = v0.x;
+        h1 = v1.x;
+    } else {
+        h0 = v0.x * (1.f - fx) + v0.y * fx;
+        h1 = v1.x * (1.f - fx) + v1.y * fx;
+    }
+    img[(size_t)pi * Wk * Hk + (size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
+}
+
+// ---------------------------------------------------------------------------------
+// A2: FarnebackPolyExp.  Tile 64x16 outputs; LDS holds the image tile with an
+// n-pixel halo, then the three vertical-pass planes; the horizontal pass runs in
+// double.  Clamped loads reproduce OpenCV's row clamping (vertical) and its
+// replication of the edge triple (horizontal).
+// ---------------------------------------------------------------------------------
+constexpr int PX_TW = 64, PX_TH = 16;
+
+__global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
+{
+    extern __shared__ float s_mem[];
+    const int n = pc.n;
+    const int LW = PX_TW + 2 * n;     // columns incl. halo
+    const int LH = PX_TH + 2 * n;     // rows incl. halo
+    float *sI = s_mem;                // [LH][LW]
+    float *sT = s_mem + LH * LW;      // [3][PX_TH][LW]
+    const int pi = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *src = img + (size_t)pi * Nk;
+    const int x0 = blockIdx.x * PX_TW, y0 = blockIdx.y * PX_TH;
+    for (int idx = threadIdx.x; idx < LH * LW; idx += blockDim.x) {
+        int ry = idx / LW, cx = idx % LW;
+        int y = clampi(y0 - n + ry, 0, Hk - 1), x = clampi(x0 - n + cx, 0, Wk - 1);
+        sI[idx] = src[(size_t)y * Wk + x];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < PX_TH * LW; idx += blockDim.x) {
+        int ty = idx / LW, cx = idx % LW;
+        int y = y0 + ty;
+        // rows y-k / y+k are clamped to the image: compute their LDS row from the clamped index
+        const float c = sI[(ty + n) * LW + cx];
+        float t0 = c * pc.g[0], t1 = 0.f, t2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            int ya = max(y - k, 0), yb = min(y + k, Hk - 1);
+            // LDS row of image row yy is (yy - (y0 - n)); clamped loads make out-of-image halo
+            // rows equal to the edge row, so indexing by ty works when y itself is in range
+            float a = sI[(ya - y0 + n) * LW + cx];
+            float b = sI[(yb - y0 + n) * LW + cx];
+            float p = a + b;
+            t0 = t0 + pc.g[k] * p;
+            t1 = t1 + pc.xg[k] * (b - a);
+            t2 = t2 + pc.xxg[k] * p;
+        }
+        if (y >= Hk) {
+            t0 = t1 = t2 = 0.f;
+        }
+        sT[(0 * PX_TH + ty) * LW + cx] = t0;
+        sT[(1 * PX_TH + ty) * LW + cx] = t1;
+        sT[(2 * PX_TH + ty) * LW + cx] = t2;
+    }
+    __syncthreads();
+    float *dst = R + (size_t)pi * 5 * Nk;
+    for (int idx = threadIdx.x; idx < PX_TH * PX_TW; idx += blockDim.x) {
+        int ty = idx / PX_TW, cx = idx % PX_TW;
+        int x = x0 + cx, y = y0 + ty;
+        if (x >= Wk || y >= Hk)
+            continue;
+        const float *T0 = sT + (0 * PX_TH + ty) * LW + cx + n;
+        const float *T1 = sT + (1 * PX_TH + ty) * LW + cx + n;
+        const float *T2 = sT + (2 * PX_TH + ty) * LW + cx + n;
+        float g0 = pc.g[0];
+        double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            double tg = T0[k] + T0[-k];
+            g0 = pc.g[k];
+            b1 += tg * g0;
+            b4 += tg * pc.xxg[k];
+            b2 += (T0[k] - T0[-k]) * pc.xg[k];
+            b3 += (T1[k] + T1[-k]) * g0;
+            b6 += (T1[k] - T1[-k]) * pc.xg[k];
+            b5 += (T2[k] + T2[-k]) * g0;
+        }
+        size_t o = (size_t)y * Wk + x;
+        dst[0 * Nk + o] = (float)(b3 * pc.ig11);
+        dst[1 * Nk + o] = (float)(b2 * pc.ig11);
+        dst[2 * Nk + o] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+        dst[3 * Nk + o] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+        dst[4 * Nk + o] = (float)(b6 * pc.ig55);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// A3: one pixel of FarnebackUpdateMatrices.  R0/R1 planar; out[5] = M.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, const float *__restrict__ R1, size_t Nk,
+                                                 int Wk, int Hk, int x, int y, float dx, float dy, float out[5])
+{
+    const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+    const size_t o = (size_t)y * Wk + x;
+    float fx = x + dx, fy = y + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1;
+    fy -= y1;
+    if ((unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1)) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        size_t q = (size_t)y1 * Wk + x1;
+        const float *p0 = R1 + q, *p1 = R1 + Nk + q, *p2 = R1 + 2 * Nk + q, *p3 = R1 + 3 * Nk + q, *p4 = R1 + 4 * Nk + q;
+        r2 = a00 * p0[0] + a01 * p0[1] + a10 * p0[Wk] + a11 * p0[Wk + 1];
+        r3 = a00 * p1[0] + a01 * p1[1] + a10 * p1[Wk] + a11 * p1[Wk + 1];
+        r4 = a00 * p2[0] + a01 * p2[1] + a10 * p2[Wk] + a11 * p2[Wk + 1];
+        r5 = a00 * p3[0] + a01 * p3[1] + a10 * p3[Wk] + a11 * p3[Wk + 1];
+        r6 = a00 * p4[0] + a01 * p4[1] + a10 * p4[Wk] + a11 * p4[Wk + 1];
+        r4 = (R0[2 * Nk + o] + r4) * 0.5f;
+        r5 = (R0[3 * Nk + o] + r5) * 0.5f;
+        r6 = (R0[4 * Nk + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * Nk + o];
+        r5 = R0[3 * Nk + o];
+        r6 = R0[4 * Nk + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[Nk + o] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(Wk - 10) || (unsigned)(y - 5) >= (unsigned)(Hk - 10)) {
+        float scale = (x < 5 ? border[x] : 1.f) * (x >= Wk - 5 ? border[Wk - x - 1] : 1.f) *
+                      (y < 5 ? border[y] : 1.f) * (y >= Hk - 5 ? border[Hk - y - 1] : 1.f);
+        r2 *= scale;
+        r3 *= scale;
+        r4 *= scale;
+        r5 *= scale;
+        r6 *= scale;
+    }
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}
+
+// Flow source of the first update-matrices of a level.
+//   mode 0: zero flow (coarsest scale, flags == 0)
+//   mode 1: bilinear upsample of the coarser level's flow, times 1/pyr_scale (A5)
+//   mode 2: explicit flow array at this level (stage tests)
+struct FlowInit {
+    int mode;
+    const float2 *src; // coarse flow [pair][Hc*Wc] (mode 1) or level flow (mode 2)
+    int Wc, Hc;
+    const int *xofs, *yofs;
+    const float *xfrac, *yfrac;
+    float mul;
+};
+
+__global__ void k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, int Hk, FlowInit fi)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= Wk)
+        return;
+    const int pair = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    float dx = 0.f, dy = 0.f;
+    if (fi.mode == 1) {
+        const float2 *c = fi.src + (size_t)pair * fi.Wc * fi.Hc;
+        int sx = fi.xofs[x], sy = fi.yofs[y];
+        float fx = fi.xfrac[x], fy = fi.yfrac[y];
+        int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
+        float2 h0, h1;
+        if (sx >= fi.Wc - 1) {
+            h0 = c[(size_t)sy0 * fi.Wc + sx];
+            h1 = c[(size_t)sy1 * fi.Wc + sx];
+        } else {
+            float2 a = c[(size_t)sy0 * fi.Wc + sx], b = c[(size_t)sy0 * fi.Wc + sx + 1];
+            float2 d = c[(size_t)sy1 * fi.Wc + sx], e = c[(size_t)sy1 * fi.Wc + sx + 1];
+            float a0 = 1.f - fx;
+            h0 = make_float2(a.x * a0 + b.x * fx, a.y * a0 + b.y * fx);
+            h1 = make_float2(d.x * a0 + e.x * fx, d.y * a0 + e.y * fx);
+        }
+        float b0 = 1.f - fy;
+        dx = (h0.x * b0 + h1.x * fy) * fi.mul;
+        dy = (h0.y * b0 + h1.y * fy) * fi.mul;
+    } else if (fi.mode == 2) {
+        float2 f = fi.src[(size_t)pair * Nk + (size_t)y * Wk + x];
+        dx = f.x;
+        dy = f.y;
+    }
+    const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
+    float m[5];
+    update_matrix_px(R0, R1, Nk, Wk, Hk, x, y, dx, dy, m);
+    float *Mo = M + (size_t)pair * 5 * Nk + (size_t)y * Wk + x;
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        Mo[c * Nk] = m[c];
+}
+
+// ---------------------------------------------------------------------------------
+// A4 (+A3 of the next iteration): box blur of M over (2m+1)^2 with replicated
+// borders, 2x2 solve, optional recomputation of M from the new flow.
+// One block marches a strip of 256 columns (256-2m outputs + halo) down `seg`
+// rows, holding the vertical window sums of its column in double registers.
+// ---------------------------------------------------------------------------------
+constexpr int BS_THREADS = 256;
+
+template <bool UPDATE>
+__global__ void __launch_bounds__(BS_THREADS)
+k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__restrict__ flow_out,
+             const float *__restrict__ R, int Wk, int Hk, int m, double scale, int seg)
+{
+    __shared__ double s_v[2][5][BS_THREADS];
+    const int tid = threadIdx.x;
+    const int out_cols = BS_THREADS - 2 * m;
+    const int col = blockIdx.x * out_cols - m + tid;
+    const int colc = clampi(col, 0, Wk - 1);
+    const int pair = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *Mi = Min + (size_t)pair * 5 * Nk + colc;
+    const int r0 = blockIdx.y * seg, r1 = min(r0 + seg, Hk);
+    double vs[5] = {0, 0, 0, 0, 0};
+    for (int j = -m; j <= m; j++) {
+        size_t ro = (size_t)clampi(r0 + j, 0, Hk - 1) * Wk;
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            vs[c] += (double)Mi[c * Nk + ro];
+    }
+    const bool is_out = tid >= m && tid < BS_THREADS - m && col < Wk;
+    const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
+    int buf = 0;
+    for (int y = r0; y < r1; y++) {
+        if (y > r0) {
+            size_t ra = (size_t)min(y + m, Hk - 1) * Wk, rb = (size_t)max(y - m - 1, 0) * Wk;
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                vs[c] += (double)Mi[c * Nk + ra] - (double)Mi[c * Nk + rb];
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            s_v[buf][c][tid] = vs[c];
+        __syncthreads();
+        if (is_out) {
+            double g[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                double a = 0;
+                for (int j = -m; j <= m; j++)
+                    a += s_v[buf][c][tid + j];
+                g[c] = a * scale;
+            }
+            double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+            float fx = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
+            float fy = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
+            if (flow_out)
+                flow_out[(size_t)pair * Nk + (size_t)y * Wk + col] = make_float2(fx, fy);
+            if (UPDATE) {
+                float mm[5];
+                update_matrix_px(R0, R1, Nk, Wk, Hk, col, y, fx, fy, mm);
+                float *Mo = Mout + (size_t)pair * 5 * Nk + (size_t)y * Wk + col;
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    Mo[c * Nk] = mm[c];
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// B1: FlowSource.post_process (source.py:337-363)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float2 clip_to_frame(float2 f, int i, int j, int W, int H)
+{
+    f.x = fminf(fmaxf(f.x, (float)(-j)), (float)(W - 1 - j));
+    f.y = fminf(fmaxf(f.y, (float)(-i)), (float)(H - 1 - i));
+    return f;
+}
+
+__global__ void k_pp_clip(float2 *flow, int W, int H)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * H)
+        return;
+    flow[t] = clip_to_frame(flow[t], t / W, t % W, W, H);
+}
+
+// source.py:350-358: every moving source p claims target p+d; numpy.put writes in
+// ascending p, so the largest p wins -> atomicMax on the source index.
+__global__ void k_pp_fwd_scatter(const float2 *__restrict__ flow, int *__restrict__ winner, int W, int H)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = W * H;
+    if (t >= N)
+        return;
+    float2 f = clip_to_frame(flow[t], t / W, t % W, W, H);
+    int ix = (int)rintf(f.x), iy = (int)rintf(f.y);
+    int d = iy * W + ix;
+    if (d == 0)
+        return;
+    int target = clampi(t + d, 0, N - 1); // mode="clip"
+    atomicMax(&winner[target], t);
+}
+
+__global__ void k_pp_fwd_resolve(float2 *__restrict__ flow, const int *__restrict__ winner, int W, int H)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * H)
+        return;
+    int w = winner[t];
+    int src = w >= 0 ? w : t;
+    int i = t / W, j = t % W;
+    float2 f = make_float2((float)(src % W - j), (float)(src / W - i)); // source.py:359-360
+    flow[t] = clip_to_frame(f, i, j, W, H);                            // :361-362
+}
+
+// host-side layout converters for the stage entry points
+__global__ void k_interleaved_to_planar5(const float *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    for (int c = 0; c < 5; c++)
+        dst[c * n + t] = src[t * 5 + c];
+}
+
+__global__ void k_planar5_to_interleaved(const float *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    for (int c = 0; c < 5; c++)
+        dst[t * 5 + c] = src[c * n + t];
+}
+
+// ---- host-side constant preparation ----------------------------------------------
+inline int cv_round(double v) { return (int)lrint(v); }
+
+std::vector<float> gaussian_kernel(int n, double sigma)
+{
+    std::vector<float> k((size_t)n);
+    if (sigma <= 0 && (n == 1 || n == 3 || n == 5 || n == 7)) {
+        static const float t1[] = {1.f};
+        static const float t3[] = {0.25f, 0.5f, 0.25f};
+        static const float t5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+        static const float t7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+        const float *t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : t7;
+        for (int i = 0; i < n; i++)
+            k[i] = t[i];
+        return k;
+    }
+    double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2x = -0.5 / (sx * sx);
+    std::vector<double> v((size_t)n);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        v[i] = std::exp(scale2x * x * x);
+        sum += v[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++)
+        k[i] = (float)(v[i] * sum);
+    return k;
+}
+
+// Symmetric 6x6 solve for the four entries of G^-1 the expansion needs.
+void invert6(const double G[36], double inv[36])
+{
+    double L[36] = {0};
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = G[i * 6 + j];
+            for (int k = 0; k < j; k++)
+                s -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = (i == j) ? std::sqrt(s) : s / L[j * 6 + j];
+        }
+    for (int c = 0; c < 6; c++) {
+        double y[6], x[6];
+        for (int i = 0; i < 6; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++)
+                s -= L[i * 6 + k] * y[k];
+            y[i] = s / L[i * 6 + i];
+        }
+        for (int i = 5; i >= 0; i--) {
+            double s = y[i];
+            for (int k = i + 1; k < 6; k++)
+                s -= L[k * 6 + i] * x[k];
+            x[i] = s / L[i * 6 + i];
+        }
+        for (int i = 0; i < 6; i++)
+            inv[i * 6 + c] = x[i];
+    }
+}
+
+PolyConst make_poly_const(int n, double sigma)
+{
+    PolyConst pc;
+    memset(&pc, 0, sizeof(pc));
+    pc.n = n;
+    if (sigma < FLT_EPSILON)
+        sigma = n * 0.3;
+    std::vector<float> gb(2 * n + 1), xgb(2 * n + 1), xxgb(2 * n + 1);
+    float *g = gb.data() + n, *xg = xgb.data() + n, *xxg = xxgb.data() + n;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G[36] = {0};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            float gg = g[y] * g[x];
+            G[0] += gg;
+            G[7] += gg * x * x;
+            G[21] += gg * x * x * x * x;
+            G[35] += gg * x * x * y * y;
+        }
+    G[14] = G[3] = G[4] = G[18] = G[24] = G[7];
+    G[28] = G[21];
+    G[22] = G[27] = G[35];
+    double inv[36];
+    invert6(G, inv);
+    pc.ig11 = inv[7];
+    pc.ig03 = inv[3];
+    pc.ig33 = inv[21];
+    pc.ig55 = inv[35];
+    for (int k = 0; k <= n; k++) {
+        pc.g[k] = g[k];
+        pc.xg[k] = xg[k];
+        pc.xxg[k] = xxg[k];
+    }
+    return pc;
+}
+
+// resize.cpp's INTER_LINEAR coefficient tables for one axis
+void make_lerp(int src, int dst, bool zero_at_edges, std::vector<int> &ofs, std::vector<float> &frac)
+{
+    ofs.resize((size_t)dst);
+    frac.resize((size_t)dst);
+    double inv_scale = (double)dst / src;
+    double scale = 1. / inv_scale;
+    for (int d = 0; d < dst; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (zero_at_edges) {
+            if (s < 0) {
+                f = 0;
+                s = 0;
+            }
+            if (s >= src - 1) {
+                f = 0;
+                s = src - 1;
+            }
+        }
+        ofs[d] = s;
+        frac[d] = f;
+    }
+}
+
+struct LerpDev {
+    DevBuf xofs, xfrac, yofs, yfrac;
+    int upload_tabs(int sw, int sh, int dw, int dh)
+    {
+        std::vector<int> o;
+        std::vector<float> f;
+        make_lerp(sw, dw, true, o, f);
+        TF_TRY(xofs.alloc(o.size() * 4));
+        TF_TRY(xfrac.alloc(f.size() * 4));
+        TF_HIP(hipMemcpy(xofs.p, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+        TF_HIP(hipMemcpy(xfrac.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+        make_lerp(sh, dh, false, o, f);
+        TF_TRY(yofs.alloc(o.size() * 4));
+        TF_TRY(yfrac.alloc(f.size() * 4));
+        TF_HIP(hipMemcpy(yofs.p, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+        TF_HIP(hipMemcpy(yfrac.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+        return TF_OK;
+    }
+};
+
+struct Level {
+    int W, H, ksz;
+    double sigma;
+    DevBuf kern;
+    LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
+    LerpDev flow_lerp; // level k+1 -> this level
+};
+
+} // namespace
+
+struct tf_fb {
+    int W = 0, H = 0;
+    tf_fb_params prm;
+    int K = 0; // scales K..0
+    int slots = 0, max_pairs = 0;
+    PolyConst pc;
+    std::vector<Level *> lv;
+    DevBuf frames, img, tmp, R, M[2], lflow[2], pairs, winner, scratch;
+    int last_pairs = 0;
+    int final_buf = 0; // which lflow buffer holds the level-0 result
+    ~tf_fb()
+    {
+        for (auto *l : lv)
+            delete l;
+    }
+};
+
+static int fb_level_image(tf_fb *fb, int k, int n_pairs)
+{
+    Level &L = *fb->lv[k];
+    const int W = fb->W, H = fb->H;
+    const int2 *pairs = fb->pairs.as<int2>();
+    const uint8_t *frames = fb->frames.as<uint8_t>();
+    if (L.W == W && L.H == H) { // resize of equal sizes is a copy
+        dim3 grid(cdiv(W, B3_TW), cdiv(H, B3_TH), n_pairs * 2);
+        size_t smem = (size_t)(B3_TH + 2 * (L.ksz / 2)) * B3_TW * sizeof(float);
+        return launch("fb_blur_small", k_blur_small_u8, grid, dim3(256), smem, frames, pairs, fb->img.as<float>(), W, H,
+                      (const float *)L.kern.as<float>(), L.ksz);
+    }
+    dim3 g1(cdiv(L.W, 128), H, n_pairs * 2);
+    TF_TRY(launch("fb_blur_rows", k_blur_rows, g1, dim3(128), 0, frames, pairs, fb->tmp.as<float2>(), W, H, L.W,
+                  (const int *)L.img_lerp.xofs.as<int>(), (const float *)L.kern.as<float>(), L.ksz));
+    dim3 g2(cdiv(L.W, 128), L.H, n_pairs * 2);
+    return launch("fb_blur_cols_resize", k_blur_cols_resize, g2, dim3(128), 0, (const float2 *)fb->tmp.as<float2>(),
+                  fb->img.as<float>(), W, H, L.W, L.H, (const int *)L.img_lerp.xofs.as<int>(),
+                  (const float *)L.img_lerp.xfrac.as<float>(), (const int *)L.img_lerp.yofs.as<int>(),
+                  (const float *)L.img_lerp.yfrac.as<float>(), (const float *)L.kern.as<float>(), L.ksz);
+}
+
+static int fb_polyexp(tf_fb *fb, int w, int h, int n_images)
+{
+    const int n = fb->pc.n;
+    dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
+    size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
+    return launch("fb_polyexp", k_polyexp, grid, dim3(256), smem, (const float *)fb->img.as<float>(),
+                  fb->R.as<float>(), w, h, fb->pc);
+}
+
+static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf)
+{
+    dim3 grid(cdiv(w, 128), h, n_pairs);
+    return launch("fb_update_matrices", k_update_matrices, grid, dim3(128), 0, (const float *)fb->R.as<float>(),
+                  fb->M[mbuf].as<float>(), w, h, fi);
+}
+
+static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, bool update, float2 *flow_out)
+{
+    const int m = fb->prm.winsize / 2;
+    const int out_cols = BS_THREADS - 2 * m;
+    const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
+    const unsigned strips = cdiv(w, out_cols);
+    // enough row segments to fill the chip (~4 blocks per CU); each segment re-sums its first
+    // window (2m+1 rows), so keep segments well above the window height
+    long segs_wanted = std::max(1l, 1024 / std::max(1l, (long)strips * n_pairs));
+    int seg = (int)std::min<long>(128, std::max<long>(16, (h + segs_wanted - 1) / segs_wanted));
+    dim3 grid(strips, cdiv(h, seg), n_pairs);
+    if (update)
+        return launch("fb_blur_solve_update", k_blur_solve<true>, grid, dim3(BS_THREADS), 0,
+                      (const float *)fb->M[mbuf_in].as<float>(), fb->M[mbuf_in ^ 1].as<float>(), flow_out,
+                      (const float *)fb->R.as<float>(), w, h, m, scale, seg);
+    return launch("fb_blur_solve", k_blur_solve<false>, grid, dim3(BS_THREADS), 0,
+                  (const float *)fb->M[mbuf_in].as<float>(), (float *)nullptr, flow_out,
+                  (const float *)fb->R.as<float>(), w, h, m, scale, seg);
+}
+
+static int fb_validate_params(const tf_fb_params *p, int width, int height)
+{
+    TF_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 30), "tf_fb_create: bad size %dx%d", width,
+               height);
+    TF_REQUIRE(p->pyr_scale > 0 && p->pyr_scale < 1, "tf_fb_create: pyr_scale must be in (0,1), got %g", p->pyr_scale);
+    TF_REQUIRE(p->levels >= 0 && p->levels <= 30, "tf_fb_create: bad levels %d", p->levels);
+    TF_REQUIRE(p->winsize >= 1 && p->winsize / 2 <= 100, "tf_fb_create: bad winsize %d", p->winsize);
+    TF_REQUIRE(p->iterations >= 1, "tf_fb_create: iterations must be >= 1, got %d", p->iterations);
+    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= MAX_POLY_N, "tf_fb_create: poly_n must be in [1,%d], got %d", MAX_POLY_N,
+               p->poly_n);
+    if (p->flags != 0)
+        return set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: flags=%d not supported (only 0: box window, no initial flow)",
+                         p->flags);
+    return TF_OK;
+}
+
+TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params, int frame_slots, int max_pairs)
+{
+    TF_REQUIRE(out && params, "tf_fb_create: null pointer");
+    TF_TRY(fb_validate_params(params, width, height));
+    TF_REQUIRE(frame_slots >= 2 && max_pairs >= 1, "tf_fb_create: need >= 2 frame slots and >= 1 pair");
+    TF_TRY(ensure_init());
+    tf_fb *fb = new tf_fb;
+    auto fail = [&](int rc) {
+        delete fb;
+        return rc;
+    };
+    fb->W = width;
+    fb->H = height;
+    fb->prm = *params;
+    fb->slots = frame_slots;
+    fb->max_pairs = max_pairs;
+    fb->pc = make_poly_const(params->poly_n, params->poly_sigma);
+    // A.1 driver: number of usable coarse scales
+    {
+        int k;
+        double scale = 1;
+        for (k = 0; k < params->levels; k++) {
+            scale *= params->pyr_scale;
+            if (width * scale < 32 || height * scale < 32)
+                break;
+        }
+        fb->K = k;
+    }
+    int rc;
+    size_t max_tmp = 0;
+    for (int k = 0; k <= fb->K; k++) {
+        Level *L = new Level;
+        fb->lv.push_back(L);
+        double scale = 1;
+        for (int i = 0; i < k; i++)
+            scale *= params->pyr_scale;
+        L->sigma = (1. / scale - 1) * 0.5;
+        int sm = cv_round(L->sigma * 5) | 1;
+        L->ksz = std::max(sm, 3);
+        L->W = cv_round(width * scale);
+        L->H = cv_round(height * scale);
+        if (L->W < 1 || L->H < 1)
+            return fail(set_error(TF_ERR_ARG, "tf_fb_create: level %d is empty", k));
+        std::vector<float> kern = gaussian_kernel(L->ksz, L->sigma);
+        if ((rc = L->kern.alloc(kern.size() * 4)))
+            return fail(rc);
+        if (hipMemcpy(L->kern.p, kern.data(), kern.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(set_error(TF_ERR_HIP, "hipMemcpy failed"));
+        if (!(L->W == width && L->H == height)) {
+            if ((rc = L->img_lerp.upload_tabs(width, height, L->W, L->H)))
+                return fail(rc);
+            max_tmp = std::max(max_tmp, (size_t)height * L->W);
+        }
+    }
+    for (int k = 0; k < fb->K; k++) {
+        Level &L = *fb->lv[k], &C = *fb->lv[k + 1];
+        if ((rc = L.flow_lerp.upload_tabs(C.W, C.H, L.W, L.H)))
+            return fail(rc);
+    }
+    const size_t N0 = (size_t)width * height, P = (size_t)max_pairs;
+    if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
+        (rc = fb->tmp.alloc(std::max<size_t>(1, P * 2 * max_tmp * 8))) || (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
+        (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
+        (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
+        (rc = fb->pairs.alloc(P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
+        return fail(rc);
+    *out = fb;
+    return TF_OK;
+}
+
+TF_API void tf_fb_destroy(tf_fb *fb) { delete fb; }
+
+TF_API int tf_fb_level_count(tf_fb *fb, int *n_scales)
+{
+    TF_REQUIRE(fb && n_scales, "tf_fb_level_count: null pointer");
+    *n_scales = fb->K + 1;
+    return TF_OK;
+}
+
+TF_API int tf_fb_level_size(tf_fb *fb, int level, int *w, int *h)
+{
+    TF_REQUIRE(fb && w && h, "tf_fb_level_size: null pointer");
+    TF_REQUIRE(level >= 0 && level <= fb->K, "tf_fb_level_size: level %d out of range", level);
+    *w = fb->lv[level]->W;
+    *h = fb->lv[level]->H;
+    return TF_OK;
+}
+
+TF_API int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t stride)
+{
+    TF_REQUIRE(fb && grey, "tf_fb_set_frame: null pointer");
+    TF_REQUIRE(slot >= 0 && slot < fb->slots, "tf_fb_set_frame: slot %d out of range (%d slots)", slot, fb->slots);
+    TF_REQUIRE(stride >= fb->W, "tf_fb_set_frame: stride %td smaller than width %d", stride, fb->W);
+    TF_TRY(ensure_init());
+    uint8_t *dst = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
+    TF_HIP(hipMemcpy2DAsync(dst, fb->W, grey, (size_t)stride, fb->W, fb->H, hipMemcpyHostToDevice, stream()));
+    TF_HIP(hipStreamSynchronize(stream())); // the host frame is borrowed for this call only
+    return TF_OK;
+}
+
+TF_API int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev)
+{
+    TF_REQUIRE(fb && dev, "tf_fb_frame_ptr: null pointer");
+    TF_REQUIRE(slot >= 0 && slot < fb->slots, "tf_fb_frame_ptr: slot %d out of range", slot);
+    *dev = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
+    return TF_OK;
+}
+
+TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const int *next_slots)
+{
+    TF_REQUIRE(fb && prev_slots && next_slots, "tf_fb_calc_slots: null pointer");
+    TF_REQUIRE(n_pairs >= 1 && n_pairs <= fb->max_pairs, "tf_fb_calc_slots: n_pairs %d not in [1,%d]", n_pairs,
+               fb->max_pairs);
+    TF_TRY(ensure_init());
+    std::vector<int2> pr((size_t)n_pairs);
+    for (int i = 0; i < n_pairs; i++) {
+        TF_REQUIRE(prev_slots[i] >= 0 && prev_slots[i] < fb->slots && next_slots[i] >= 0 && next_slots[i] < fb->slots,
+                   "tf_fb_calc_slots: pair %d uses a slot outside [0,%d)", i, fb->slots);
+        pr[i] = make_int2(prev_slots[i], next_slots[i]);
+    }
+    TF_HIP(hipMemcpyAsync(fb->pairs.p, pr.data(), pr.size() * 8, hipMemcpyHostToDevice, stream()));
+    TF_HIP(hipStreamSynchronize(stream())); // pr is a stack-lifetime staging buffer
+    int cur = 0; // lflow buffer the current level writes
+    for (int k = fb->K; k >= 0; k--) {
+        Level &L = *fb->lv[k];
+        TF_TRY(fb_level_image(fb, k, n_pairs));
+        TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2));
+        FlowInit fi;
+        memset(&fi, 0, sizeof(fi));
+        if (k < fb->K) {
+            Level &C = *fb->lv[k + 1];
+            fi.mode = 1;
+            fi.src = fb->lflow[cur ^ 1].as<float2>();
+            fi.Wc = C.W;
+            fi.Hc = C.H;
+            fi.xofs = L.flow_lerp.xofs.as<int>();
+            fi.yofs = L.flow_lerp.yofs.as<int>();
+            fi.xfrac = L.flow_lerp.xfrac.as<float>();
+            fi.yfrac = L.flow_lerp.yfrac.as<float>();
+            fi.mul = (float)(1. / fb->prm.pyr_scale);
+        }
+        int mb = 0;
+        TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, mb));
+        for (int i = 0; i < fb->prm.iterations; i++) {
+            bool last = i == fb->prm.iterations - 1;
+            TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, mb, !last, last ? fb->lflow[cur].as<float2>() : nullptr));
+            mb ^= 1;
+        }
+        fb->final_buf = cur;
+        cur ^= 1;
+    }
+    fb->last_pairs = n_pairs;
+    return TF_OK;
+}
+
+TF_API int tf_fb_flow_ptr(tf_fb *fb, int pair, void **dev)
+{
+    TF_REQUIRE(fb && dev, "tf_fb_flow_ptr: null pointer");
+    TF_REQUIRE(pair >= 0 && pair < fb->max_pairs, "tf_fb_flow_ptr: pair %d out of range", pair);
+    *dev = fb->lflow[fb->final_buf].as<float2>() + (size_t)pair * fb->W * fb->H;
+    return TF_OK;
+}
+
+TF_API int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out)
+{
+    TF_REQUIRE(fb && flow_out, "tf_fb_get_flow: null pointer");
+    TF_REQUIRE(pair >= 0 && pair < fb->last_pairs, "tf_fb_get_flow: pair %d was not computed by the last call", pair);
+    TF_TRY(ensure_init());
+    void *src;
+    TF_TRY(tf_fb_flow_ptr(fb, pair, &src));
+    TF_HIP(hipMemcpyAsync(flow_out, src, (size_t)fb->W * fb->H * 8, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint8_t *next, ptrdiff_t next_stride,
+                      float *flow_out)
+{
+    TF_REQUIRE(fb && prev && next && flow_out, "tf_fb_calc: null pointer");
+    TF_TRY(tf_fb_set_frame(fb, 0, prev, prev_stride));
+    TF_TRY(tf_fb_set_frame(fb, 1, next, next_stride));
+    int a = 0, b = 1;
+    TF_TRY(tf_fb_calc_slots(fb, 1, &a, &b));
+    return tf_fb_get_flow(fb, 0, flow_out);
+}
+
+static int pp_run(tf_fb *fb, float2 *flow, int direction)
+{
+    TF_REQUIRE(direction == 0 || direction == 1, "post_process: direction must be 0 (FORWARD) or 1 (BACKWARD), got %d",
+               direction);
+    const int N = fb->W * fb->H;
+    dim3 grid(cdiv((size_t)N, 256)), block(256);
+    if (direction == 0) {
+        TF_HIP(hipMemsetAsync(fb->winner.p, 0xFF, (size_t)N * 4, stream()));
+        TF_TRY(launch("pp_fwd_scatter", k_pp_fwd_scatter, grid, block, 0, (const float2 *)flow, fb->winner.as<int>(),
+                      fb->W, fb->H));
+        return launch("pp_fwd_resolve", k_pp_fwd_resolve, grid, block, 0, flow, (const int *)fb->winner.as<int>(), fb->W,
+                      fb->H);
+    }
+    return launch("pp_clip", k_pp_clip, grid, block, 0, flow, fb->W, fb->H);
+}
+
+TF_API int tf_fb_post_process(tf_fb *fb, int pair, int direction)
+{
+    TF_REQUIRE(fb, "tf_fb_post_process: null handle");
+    TF_REQUIRE(pair >= 0 && pair < fb->max_pairs, "tf_fb_post_process: pair %d out of range", pair);
+    TF_TRY(ensure_init());
+    void *p;
+    TF_TRY(tf_fb_flow_ptr(fb, pair, &p));
+    return pp_run(fb, (float2 *)p, direction);
+}
+
+TF_API int tf_fb_post_process_host(tf_fb *fb, float *flow_inout, int direction)
+{
+    TF_REQUIRE(fb && flow_inout, "tf_fb_post_process_host: null pointer");
+    TF_TRY(ensure_init());
+    size_t bytes = (size_t)fb->W * fb->H * 8;
+    TF_HIP(hipMemcpyAsync(fb->scratch.p, flow_inout, bytes, hipMemcpyHostToDevice, stream()));
+    TF_TRY(pp_run(fb, fb->scratch.as<float2>(), direction));
+    TF_HIP(hipMemcpyAsync(flow_inout, fb->scratch.p, bytes, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+// ---- stage entry points (parity tests drive single kernels through these) ---------
+TF_API int tf_fb_stage_level_image(tf_fb *fb, const uint8_t *grey, ptrdiff_t stride, int level, float *out)
+{
+    TF_REQUIRE(fb && grey && out, "tf_fb_stage_level_image: null pointer");
+    TF_REQUIRE(level >= 0 && level <= fb->K, "tf_fb_stage_level_image: level %d out of range", level);
+    TF_TRY(tf_fb_set_frame(fb, 0, grey, stride));
+    int2 pr = make_int2(0, 0);
+    TF_HIP(hipMemcpy(fb->pairs.p, &pr, 8, hipMemcpyHostToDevice));
+    TF_TRY(fb_level_image(fb, level, 1));
+    Level &L = *fb->lv[level];
+    TF_HIP(hipMemcpyAsync(out, fb->img.p, (size_t)L.W * L.H * 4, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+static int check_stage_size(tf_fb *fb, int w, int h)
+{
+    TF_REQUIRE(w >= 1 && h >= 1 && (size_t)w * h <= (size_t)fb->W * fb->H, "stage: %dx%d exceeds the handle's %dx%d", w,
+               h, fb->W, fb->H);
+    return TF_OK;
+}
+
+static int upload_planar5(float *dst_planar, const float *host_interleaved, size_t n, DevBuf &staging)
+{
+    TF_HIP(hipMemcpyAsync(staging.p, host_interleaved, n * 20, hipMemcpyHostToDevice, stream()));
+    return launch("stage_to_planar", k_interleaved_to_planar5, dim3(cdiv(n, 256)), dim3(256), 0,
+                  (const float *)staging.as<float>(), dst_planar, n);
+}
+
+static int download_planar5(float *host_interleaved, const float *src_planar, size_t n, DevBuf &staging)
+{
+    TF_TRY(launch("stage_to_interleaved", k_planar5_to_interleaved, dim3(cdiv(n, 256)), dim3(256), 0, src_planar,
+                  staging.as<float>(), n));
+    TF_HIP(hipMemcpyAsync(host_interleaved, staging.p, n * 20, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out)
+{
+    TF_REQUIRE(fb && img && r_out, "tf_fb_stage_polyexp: null pointer");
+    TF_TRY(check_stage_size(fb, w, h));
+    TF_TRY(ensure_init());
+    size_t n = (size_t)w * h;
+    TF_HIP(hipMemcpyAsync(fb->img.p, img, n * 4, hipMemcpyHostToDevice, stream()));
+    TF_TRY(fb_polyexp(fb, w, h, 1));
+    return download_planar5(r_out, fb->R.as<float>(), n, fb->scratch);
+}
+
+TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, const float *flow, int w, int h,
+                                       float *m_out)
+{
+    TF_REQUIRE(fb && r0 && r1 && flow && m_out, "tf_fb_stage_update_matrices: null pointer");
+    TF_TRY(check_stage_size(fb, w, h));
+    TF_TRY(ensure_init());
+    size_t n = (size_t)w * h;
+    TF_TRY(upload_planar5(fb->R.as<float>(), r0, n, fb->scratch));
+    TF_HIP(hipStreamSynchronize(stream()));
+    TF_TRY(upload_planar5(fb->R.as<float>() + 5 * n, r1, n, fb->scratch));
+    TF_HIP(hipMemcpyAsync(fb->lflow[0].p, flow, n * 8, hipMemcpyHostToDevice, stream()));
+    FlowInit fi;
+    memset(&fi, 0, sizeof(fi));
+    fi.mode = 2;
+    fi.src = fb->lflow[0].as<float2>();
+    TF_TRY(fb_update_matrices(fb, w, h, 1, fi, 0));
+    return download_planar5(m_out, fb->M[0].as<float>(), n, fb->scratch);
+}
+
+TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out)
+{
+    TF_REQUIRE(fb && m && flow_out, "tf_fb_stage_blur_solve: null pointer");
+    TF_TRY(check_stage_size(fb, w, h));
+    TF_TRY(ensure_init());
+    size_t n = (size_t)w * h;
+    TF_TRY(upload_planar5(fb->M[0].as<float>(), m, n, fb->scratch));
+    TF_TRY(fb_blur_solve(fb, w, h, 1, 0, false, fb->lflow[0].as<float2>()));
+    TF_HIP(hipMemcpyAsync(flow_out, fb->lflow[0].p, n * 8, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}

@@ -1,0 +1,275 @@
+// Runtime of libtfhip.so: device selection, the library stream, errors, events,
+// the per-kernel profiler and raw device buffers.
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "common.h"
+
+namespace tf {
+
+static thread_local std::string g_last_error;
+static std::mutex g_mu;
+static bool g_inited = false;
+static int g_device = 0;
+static hipStream_t g_stream = nullptr;
+
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+hipStream_t stream() { return g_stream; }
+
+static int init_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited) {
+        if (device != g_device)
+            return set_error(TF_ERR_STATE, "tf_init(%d): library already bound to device %d", device, g_device);
+        TF_HIP(hipSetDevice(g_device));
+        return TF_OK;
+    }
+    int n = 0;
+    TF_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n)
+        return set_error(TF_ERR_ARG, "tf_init: device %d out of range (%d visible)", device, n);
+    TF_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TF_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(TF_ERR_UNSUPPORTED, "tf_init: device %d is %s; this library is built for gfx950 only",
+                         device, prop.gcnArchName);
+    TF_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    g_inited = true;
+    return TF_OK;
+}
+
+int ensure_init()
+{
+    if (g_inited)
+        return hipSetDevice(g_device) == hipSuccess ? TF_OK : set_error(TF_ERR_HIP, "hipSetDevice failed");
+    return init_device(0);
+}
+
+int DevBuf::alloc(size_t n)
+{
+    release();
+    if (n == 0)
+        return TF_OK;
+    TF_HIP(hipMalloc(&p, n));
+    bytes = n;
+    return TF_OK;
+}
+
+void DevBuf::release()
+{
+    if (p)
+        (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+// ---- profiler ---------------------------------------------------------------------
+struct ProfRec {
+    const char *name;
+    hipEvent_t a, b;
+};
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_free_events;
+static std::map<std::string, std::pair<long, double>> g_acc;
+
+bool prof_enabled() { return g_prof; }
+
+static hipEvent_t get_event()
+{
+    if (!g_free_events.empty()) {
+        hipEvent_t e = g_free_events.back();
+        g_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static void prof_drain()
+{
+    if (g_recs.empty())
+        return;
+    (void)hipStreamSynchronize(g_stream);
+    for (auto &r : g_recs) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        auto &acc = g_acc[r.name];
+        acc.first += 1;
+        acc.second += ms;
+        g_free_events.push_back(r.a);
+        g_free_events.push_back(r.b);
+    }
+    g_recs.clear();
+}
+
+ProfScope::ProfScope(const char *name) : slot(-1)
+{
+    if (!g_prof)
+        return;
+    if (g_recs.size() >= 4096)
+        prof_drain();
+    ProfRec r{name, get_event(), get_event()};
+    (void)hipEventRecord(r.a, g_stream);
+    slot = (int)g_recs.size();
+    g_recs.push_back(r);
+}
+
+ProfScope::~ProfScope()
+{
+    if (slot >= 0)
+        (void)hipEventRecord(g_recs[slot].b, g_stream);
+}
+
+} // namespace tf
+
+using namespace tf;
+
+struct tf_event {
+    hipEvent_t ev;
+};
+
+TF_API int tf_abi_version(void) { return TFHIP_ABI_VERSION; }
+
+TF_API int tf_init(int device) { return init_device(device); }
+
+TF_API int tf_device_count(int *count)
+{
+    TF_REQUIRE(count, "tf_device_count: null pointer");
+    TF_HIP(hipGetDeviceCount(count));
+    return TF_OK;
+}
+
+TF_API const char *tf_last_error(void) { return g_last_error.c_str(); }
+
+TF_API int tf_sync(void)
+{
+    TF_TRY(ensure_init());
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_stream(void **hip_stream)
+{
+    TF_REQUIRE(hip_stream, "tf_stream: null pointer");
+    TF_TRY(ensure_init());
+    *hip_stream = (void *)stream();
+    return TF_OK;
+}
+
+TF_API int tf_event_create(tf_event **ev)
+{
+    TF_REQUIRE(ev, "tf_event_create: null pointer");
+    TF_TRY(ensure_init());
+    tf_event *e = new tf_event;
+    hipError_t rc = hipEventCreate(&e->ev);
+    if (rc != hipSuccess) {
+        delete e;
+        return set_error(TF_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(rc));
+    }
+    *ev = e;
+    return TF_OK;
+}
+
+TF_API int tf_event_record(tf_event *ev)
+{
+    TF_REQUIRE(ev, "tf_event_record: null event");
+    TF_HIP(hipEventRecord(ev->ev, stream()));
+    return TF_OK;
+}
+
+TF_API int tf_event_elapsed_ms(tf_event *start, tf_event *stop, float *ms)
+{
+    TF_REQUIRE(start && stop && ms, "tf_event_elapsed_ms: null argument");
+    TF_HIP(hipEventSynchronize(stop->ev));
+    TF_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return TF_OK;
+}
+
+TF_API void tf_event_destroy(tf_event *ev)
+{
+    if (!ev)
+        return;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+}
+
+TF_API int tf_prof_enable(int on)
+{
+    TF_TRY(ensure_init());
+    if (!on)
+        prof_drain();
+    g_prof = on != 0;
+    return TF_OK;
+}
+
+TF_API int tf_prof_reset(void)
+{
+    prof_drain();
+    g_acc.clear();
+    return TF_OK;
+}
+
+TF_API int tf_prof_report(char *buf, size_t buf_size)
+{
+    TF_REQUIRE(buf && buf_size > 0, "tf_prof_report: null buffer");
+    prof_drain();
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto &kv : g_acc) {
+        int n = snprintf(buf + off, buf_size - off, "%s %ld %.6f\n", kv.first.c_str(), kv.second.first,
+                         kv.second.second);
+        if (n < 0 || (size_t)n >= buf_size - off)
+            return set_error(TF_ERR_ARG, "tf_prof_report: buffer too small");
+        off += (size_t)n;
+    }
+    return TF_OK;
+}
+
+TF_API int tf_dev_alloc(void **dev, size_t bytes)
+{
+    TF_REQUIRE(dev, "tf_dev_alloc: null pointer");
+    TF_TRY(ensure_init());
+    TF_HIP(hipMalloc(dev, bytes ? bytes : 1));
+    return TF_OK;
+}
+
+TF_API int tf_dev_free(void *dev)
+{
+    if (dev)
+        TF_HIP(hipFree(dev));
+    return TF_OK;
+}
+
+TF_API int tf_dev_upload(void *dev, const void *host, size_t bytes)
+{
+    TF_REQUIRE(dev && host, "tf_dev_upload: null pointer");
+    TF_TRY(ensure_init());
+    TF_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_dev_download(void *host, const void *dev, size_t bytes)
+{
+    TF_REQUIRE(dev && host, "tf_dev_download: null pointer");
+    TF_TRY(ensure_init());
+    TF_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}

@@ -1,0 +1,143 @@
+"""Farnebäck handle: thin object over the tf_fb_* entry points of libtfhip.so.
+
+`Farneback.calc(prev, next)` has the argument meaning of
+cv2.calcOpticalFlowFarneback as the reference calls it
+(transflow/flow/sources/cv.py:479-490).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TfFbParams, check
+
+FORWARD = 0   # FlowSource.Direction.FORWARD  (flow/sources/source.py:21)
+BACKWARD = 1  # FlowSource.Direction.BACKWARD (flow/sources/source.py:22)
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class Farneback:
+    def __init__(self, width: int, height: int, pyr_scale: float = 0.5, levels: int = 3, winsize: int = 15,
+                 iterations: int = 3, poly_n: int = 5, poly_sigma: float = 1.2, flags: int = 0,
+                 frame_slots: int = 2, max_pairs: int = 1, device: int | None = None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if device is not None:
+            check(self._lib.tf_init(int(device)))
+        self.width, self.height = int(width), int(height)
+        self.frame_slots, self.max_pairs = int(frame_slots), int(max_pairs)
+        prm = TfFbParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
+                         float(poly_sigma), int(flags))
+        check(self._lib.tf_fb_create(C.byref(self._h), self.width, self.height, C.byref(prm),
+                                     self.frame_slots, self.max_pairs))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tf_fb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _grey(self, frame) -> np.ndarray:
+        a = np.asarray(frame)
+        if a.dtype != np.uint8 or a.shape != (self.height, self.width):
+            raise ValueError(f"expected uint8 grey frame {(self.height, self.width)}, got {a.dtype} {a.shape}")
+        if a.strides[1] != 1:
+            a = np.ascontiguousarray(a)
+        return a
+
+    # -- one pair, host in / host out -------------------------------------------------
+    def calc(self, prev, nxt) -> np.ndarray:
+        p, n = self._grey(prev), self._grey(nxt)
+        flow = np.empty((self.height, self.width, 2), np.float32)
+        check(self._lib.tf_fb_calc(self._h, _ptr(p), p.strides[0], _ptr(n), n.strides[0], _ptr(flow)))
+        return flow
+
+    # -- resident path ----------------------------------------------------------------
+    def set_frame(self, slot: int, frame) -> None:
+        a = self._grey(frame)
+        check(self._lib.tf_fb_set_frame(self._h, int(slot), _ptr(a), a.strides[0]))
+
+    def frame_ptr(self, slot: int) -> int:
+        p = C.c_void_p()
+        check(self._lib.tf_fb_frame_ptr(self._h, int(slot), C.byref(p)))
+        return p.value
+
+    def calc_slots(self, prev_slots, next_slots) -> None:
+        n = len(prev_slots)
+        if n != len(next_slots):
+            raise ValueError("prev_slots and next_slots differ in length")
+        a = (C.c_int * n)(*[int(v) for v in prev_slots])
+        b = (C.c_int * n)(*[int(v) for v in next_slots])
+        check(self._lib.tf_fb_calc_slots(self._h, n, a, b))
+
+    def get_flow(self, pair: int = 0) -> np.ndarray:
+        flow = np.empty((self.height, self.width, 2), np.float32)
+        check(self._lib.tf_fb_get_flow(self._h, int(pair), _ptr(flow)))
+        return flow
+
+    def flow_ptr(self, pair: int = 0) -> int:
+        p = C.c_void_p()
+        check(self._lib.tf_fb_flow_ptr(self._h, int(pair), C.byref(p)))
+        return p.value
+
+    def post_process(self, pair: int, direction: int) -> None:
+        check(self._lib.tf_fb_post_process(self._h, int(pair), int(direction)))
+
+    def post_process_host(self, flow: np.ndarray, direction: int) -> np.ndarray:
+        """In place on a float32 C-contiguous [H,W,2] array, like the reference."""
+        if (not isinstance(flow, np.ndarray) or flow.dtype != np.float32 or not flow.flags.c_contiguous
+                or flow.shape != (self.height, self.width, 2)):
+            raise ValueError("post_process needs a C-contiguous float32 array of shape (H, W, 2)")
+        check(self._lib.tf_fb_post_process_host(self._h, _ptr(flow), int(direction)))
+        return flow
+
+    # -- geometry / stage entry points (parity tests) -----------------------------------
+    def level_sizes(self):
+        n = C.c_int()
+        check(self._lib.tf_fb_level_count(self._h, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            w, h = C.c_int(), C.c_int()
+            check(self._lib.tf_fb_level_size(self._h, k, C.byref(w), C.byref(h)))
+            out.append((w.value, h.value))
+        return out
+
+    def stage_level_image(self, frame, level: int) -> np.ndarray:
+        a = self._grey(frame)
+        w, h = self.level_sizes()[level]
+        out = np.empty((h, w), np.float32)
+        check(self._lib.tf_fb_stage_level_image(self._h, _ptr(a), a.strides[0], int(level), _ptr(out)))
+        return out
+
+    def stage_polyexp(self, img) -> np.ndarray:
+        img = np.ascontiguousarray(img, np.float32)
+        h, w = img.shape
+        out = np.empty((h, w, 5), np.float32)
+        check(self._lib.tf_fb_stage_polyexp(self._h, _ptr(img), w, h, _ptr(out)))
+        return out
+
+    def stage_update_matrices(self, r0, r1, flow) -> np.ndarray:
+        r0 = np.ascontiguousarray(r0, np.float32)
+        r1 = np.ascontiguousarray(r1, np.float32)
+        flow = np.ascontiguousarray(flow, np.float32)
+        h, w, _ = flow.shape
+        out = np.empty((h, w, 5), np.float32)
+        check(self._lib.tf_fb_stage_update_matrices(self._h, _ptr(r0), _ptr(r1), _ptr(flow), w, h, _ptr(out)))
+        return out
+
+    def stage_blur_solve(self, m) -> np.ndarray:
+        m = np.ascontiguousarray(m, np.float32)
+        h, w, _ = m.shape
+        out = np.empty((h, w, 2), np.float32)
+        check(self._lib.tf_fb_stage_blur_solve(self._h, _ptr(m), w, h, _ptr(out)))
+        return out

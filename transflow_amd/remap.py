@@ -1,0 +1,150 @@
+"""Remap handles: thin objects over tf_remap_* / tf_comp_* of libtfhip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TfLayerCfg, check
+
+RESET_MODES = {"off": 0, "random": 1, "constant": 2, "linear": 3}  # reference.py:16-21
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class CompImage:
+    """Background + output frame of Compositor (compositor/compositor.py:17-40)."""
+
+    def __init__(self, height: int, width: int, background_rgb=(255, 255, 255)):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.height, self.width = int(height), int(width)
+        bg = (C.c_uint8 * 3)(*[int(v) & 255 for v in background_rgb])
+        check(self._lib.tf_comp_create(C.byref(self._h), self.height, self.width, bg))
+
+    def begin(self):
+        check(self._lib.tf_comp_begin(self._h))
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        check(self._lib.tf_comp_download(self._h, _ptr(out)))
+        return out
+
+    def image_ptr(self) -> int:
+        p = C.c_void_p()
+        check(self._lib.tf_comp_image_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tf_comp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RemapLayer:
+    """Device state and kernels of one moveref layer."""
+
+    def __init__(self, height: int, width: int, *, transparent_pixels_can_move=False,
+                 pixels_can_move_to_empty_spot=True, pixels_can_move_to_filled_spot=True,
+                 moving_pixels_leave_empty_spot=False, reset_mode="off", reset_random_factor=1.0,
+                 reset_constant_step=1.0, reset_linear_factor=0.1, reset_source=False,
+                 mask_src=None, mask_dst=None, mask_alpha=None, reset_mask=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.height, self.width = int(height), int(width)
+        if reset_mode not in RESET_MODES:
+            raise ValueError(f"Unknown reset mode {reset_mode}")  # reference.py:35
+        cfg = TfLayerCfg(int(bool(transparent_pixels_can_move)), int(bool(pixels_can_move_to_empty_spot)),
+                         int(bool(pixels_can_move_to_filled_spot)), int(bool(moving_pixels_leave_empty_spot)),
+                         RESET_MODES[reset_mode], float(reset_random_factor), float(reset_constant_step),
+                         float(reset_linear_factor), int(bool(reset_source)))
+        shape = (self.height, self.width)
+
+        def mask(a, dtype):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dtype)
+            if a.shape != shape:
+                raise ValueError(f"mask shape {a.shape} != {shape}")
+            return a
+
+        ms, md = mask(mask_src, np.uint8), mask(mask_dst, np.uint8)
+        ma, rm = mask(mask_alpha, np.float32), mask(reset_mask, np.float32)
+        check(self._lib.tf_remap_create(C.byref(self._h), self.height, self.width, C.byref(cfg), _ptr(ms), _ptr(md),
+                                        _ptr(ma), _ptr(rm)))
+
+    def set_sources(self, introduction_masks) -> None:
+        masks = [np.ascontiguousarray(m, dtype=np.uint8) for m in introduction_masks]
+        for m in masks:
+            if m.shape != (self.height, self.width):
+                raise ValueError("introduction mask has the wrong shape")
+        arr = (C.c_void_p * max(1, len(masks)))(*[m.ctypes.data for m in masks])
+        check(self._lib.tf_remap_set_sources(self._h, len(masks), arr))
+
+    def update(self, flow: np.ndarray, uniform: np.ndarray | None = None, seed: int = 0) -> None:
+        flow = np.ascontiguousarray(flow, dtype=np.float32)
+        if flow.shape != (self.height, self.width, 2):
+            raise ValueError(f"flow shape {flow.shape} != {(self.height, self.width, 2)}")
+        u = None
+        if uniform is not None:
+            u = np.ascontiguousarray(uniform, dtype=np.float64)
+            if u.shape != (self.height, self.width):
+                raise ValueError("uniform field has the wrong shape")
+        check(self._lib.tf_remap_update(self._h, _ptr(flow), _ptr(u), C.c_uint64(seed & (2**64 - 1))))
+
+    def update_dev(self, flow_dev: int, uniform_dev: int | None = None, seed: int = 0) -> None:
+        check(self._lib.tf_remap_update_dev(self._h, C.c_void_p(flow_dev),
+                                            C.c_void_p(uniform_dev) if uniform_dev else None,
+                                            C.c_uint64(seed & (2**64 - 1))))
+
+    def out_of_frame(self) -> bool:
+        v = C.c_int()
+        check(self._lib.tf_remap_check(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def gather(self, source_index: int, pixmap: np.ndarray) -> None:
+        pm = np.ascontiguousarray(pixmap, dtype=np.uint8)
+        if pm.ndim != 3 or pm.shape[:2] != (self.height, self.width):
+            raise ValueError(f"pixmap shape {pm.shape} does not match the layer")
+        check(self._lib.tf_remap_gather(self._h, int(source_index), _ptr(pm), int(pm.shape[2])))
+
+    def gather_dev(self, source_index: int, pixmap_dev: int, channels: int) -> None:
+        check(self._lib.tf_remap_gather_dev(self._h, int(source_index), C.c_void_p(pixmap_dev), int(channels)))
+
+    def render(self, comp: CompImage) -> None:
+        check(self._lib.tf_remap_render(self._h, comp._h))
+
+    def get_state(self):
+        data = np.empty((self.height, self.width, 4), np.int32)
+        rgba = np.empty((self.height, self.width, 4), np.uint8)
+        check(self._lib.tf_remap_get_state(self._h, _ptr(data), _ptr(rgba)))
+        return data, rgba
+
+    def set_state(self, data=None, rgba=None) -> None:
+        d = None if data is None else np.ascontiguousarray(data, dtype=np.int32)
+        r = None if rgba is None else np.ascontiguousarray(rgba, dtype=np.uint8)
+        if d is not None and d.shape != (self.height, self.width, 4):
+            raise ValueError("data has the wrong shape")
+        if r is not None and r.shape != (self.height, self.width, 4):
+            raise ValueError("rgba has the wrong shape")
+        check(self._lib.tf_remap_set_state(self._h, _ptr(d), _ptr(r)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tf_remap_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
