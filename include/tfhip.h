@@ -57,6 +57,8 @@ void tf_event_destroy(tf_event *ev);
 /* Per-kernel timing: when enabled every launch is bracketed by HIP events on the
    library stream.  tf_prof_report writes lines "name count total_ms" into buf. */
 int tf_prof_enable(int on);
+/* Only time kernels whose name contains `substring` (NULL or "" = all). */
+int tf_prof_set_filter(const char *substring);
 int tf_prof_reset(void);
 int tf_prof_report(char *buf, size_t buf_size);
 
@@ -65,6 +67,7 @@ int tf_dev_alloc(void **dev, size_t bytes);
 int tf_dev_free(void *dev);
 int tf_dev_upload(void *dev, const void *host, size_t bytes);
 int tf_dev_download(void *host, const void *dev, size_t bytes);
+int tf_dev_copy(void *dst_dev, const void *src_dev, size_t bytes); /* device to device, on the library stream */
 
 /* ---- Farnebäck dense optical flow ----------------------------------------------
  * Replaces cv2.calcOpticalFlowFarneback as called at
@@ -172,6 +175,16 @@ int tf_remap_gather_dev(tf_remap *layer, int source_index, const void *pixmap_de
    (compositor.py:36-39): alpha := uint8(mask_alpha*alpha) in place, then paint the
    opaque pixels onto the compositor image. */
 int tf_remap_render(tf_remap *layer, tf_comp *comp);
+
+/* The resident path's one call per frame, same result as
+     [clip of post_process BACKWARD on the flow, if clip_flow]; tf_remap_update_dev;
+     tf_remap_gather_dev(source 0); tf_comp_begin; tf_remap_render
+   for a compositor with this single layer and a single source.  Runs as ONE kernel when
+   the layer needs no second pass (moving_pixels_leave_empty_spot off, reset off/random),
+   otherwise as those separate kernels.  With clip_flow the clipped flow is written back
+   only in the unfused form; the fused form clips in registers. */
+int tf_remap_step_dev(tf_remap *layer, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev,
+                      uint64_t seed, const void *pixmap_dev, int channels);
 
 /* State exchange for checkpoints (pipeline.py:225-242 pickles the compositor) and
    for extra/control.py:146-162 which reads layer.data.  data int32 [H][W][4]

@@ -209,3 +209,52 @@ def test_argument_errors(tf):
     empty = remap.RemapLayer(0, 0)
     empty.update(np.zeros((0, 0, 2), np.float32))
     assert empty.get_state()[0].shape == (0, 0, 4)
+
+
+@pytest.mark.parametrize("path", layer_case_files(), ids=lambda p: os.path.basename(p)[12:-4])
+def test_fused_step_matches_golden(tf, path):
+    """tf_remap_step_dev (one kernel when the layer allows it, the separate kernels otherwise)
+    on the reference's vectors: single-source cases, flow/pixmap/u resident in HBM."""
+    from transflow_amd.device import DevBuffer
+    _, remap = tf
+    z = np.load(path)
+    if int(z["nsources"]) != 1:
+        pytest.skip("the fused step serves one source")
+    h, w = int(z["h"]), int(z["w"])
+    layer = _make_layer(remap, h, w, case_cfg(z), z)
+    layer.set_sources([z["intro_0"]])
+    comp = remap.CompImage(h, w, tuple(int(v) for v in z["background"]))
+    for t in range(int(z["nframes"])):
+        flow = DevBuffer.from_array(z[f"flow_{t}"])
+        u = DevBuffer.from_array(z[f"u_{t}"])
+        pm = DevBuffer.from_array(z["pixmap_0"][t])
+        layer.step_dev(comp, flow.ptr, pm.ptr, channels=z["pixmap_0"].shape[-1], clip_flow=True,
+                       uniform_dev=u.ptr)
+        data, rgba = layer.get_state()
+        np.testing.assert_array_equal(data, z[f"data_{t}"], err_msg=f"data t={t}")
+        np.testing.assert_array_equal(rgba, z[f"rgba_after_render_{t}"], err_msg=f"rgba t={t}")
+        np.testing.assert_array_equal(comp.download(), z[f"frame_{t}"], err_msg=f"frame t={t}")
+    assert not layer.out_of_frame()
+
+
+def test_fused_step_clips_like_post_process(tf):
+    """clip_flow=True on a raw flow == BACKWARD post_process then the separate calls."""
+    from transflow_amd.device import DevBuffer
+    _, remap = tf
+    h, w = 203, 317
+    rng = np.random.default_rng(12)
+    raw = rng.normal(0, 30, (h, w, 2)).astype(np.float32)
+    pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ora = R.MoveRefLayer(h, w, introduction_masks=[np.ones((h, w), bool)])
+    ora.update(R.post_process(raw.copy(), R.BACKWARD), [pm])
+    layer = remap.RemapLayer(h, w)
+    layer.set_sources([np.ones((h, w), np.uint8)])
+    comp = remap.CompImage(h, w, (1, 2, 3))
+    raw_dev, pm_dev = DevBuffer.from_array(raw), DevBuffer.from_array(pm)  # keep the buffers alive
+    layer.step_dev(comp, raw_dev.ptr, pm_dev.ptr, 3, clip_flow=True)
+    np.testing.assert_array_equal(layer.get_state()[0], ora.data)
+    exp = R.composite(np.broadcast_to(np.uint8([1, 2, 3]), (h, w, 3)), [ora.render()])
+    np.testing.assert_array_equal(comp.download(), exp)
+    # without the clip the same flow leaves the frame: flagged, offending pixels stay put
+    layer.step_dev(comp, raw_dev.ptr, pm_dev.ptr, 3, clip_flow=False)
+    assert layer.out_of_frame()

@@ -53,12 +53,14 @@ PROTOTYPES = {
     "tf_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
     "tf_event_destroy": (None, [_P]),
     "tf_prof_enable": (_I, [_I]),
+    "tf_prof_set_filter": (_I, [C.c_char_p]),
     "tf_prof_reset": (_I, []),
     "tf_prof_report": (_I, [C.c_char_p, C.c_size_t]),
     "tf_dev_alloc": (_I, [_PP, C.c_size_t]),
     "tf_dev_free": (_I, [_P]),
     "tf_dev_upload": (_I, [_P, _P, C.c_size_t]),
     "tf_dev_download": (_I, [_P, _P, C.c_size_t]),
+    "tf_dev_copy": (_I, [_P, _P, C.c_size_t]),
     "tf_fb_create": (_I, [_PP, _I, _I, C.POINTER(TfFbParams), _I, _I]),
     "tf_fb_destroy": (None, [_P]),
     "tf_fb_calc": (_I, [_P, _P, C.c_ssize_t, _P, C.c_ssize_t, _P]),
@@ -84,6 +86,7 @@ PROTOTYPES = {
     "tf_remap_gather": (_I, [_P, _I, _P, _I]),
     "tf_remap_gather_dev": (_I, [_P, _I, _P, _I]),
     "tf_remap_render": (_I, [_P, _P]),
+    "tf_remap_step_dev": (_I, [_P, _P, _P, _I, _P, C.c_uint64, _P, _I]),
     "tf_remap_get_state": (_I, [_P, _P, _P]),
     "tf_remap_set_state": (_I, [_P, _P, _P]),
     "tf_comp_create": (_I, [_PP, _I, _I, C.POINTER(C.c_uint8)]),

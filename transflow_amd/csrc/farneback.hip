@@ -17,7 +17,7 @@
 //
 // HBM layout (per handle, sized for `max_pairs` frame pairs):
 //   frames  u8  [slot][H][W]
-//   img     f32 [pair][2][Hk*Wk]          level image of both frames
+//   img     f32 [pair][2][Hk*Wk]          level image of both frames (A1 output)
 //   R       f32 [pair][2][5][Hk*Wk]       polynomial coefficients, planar (SoA)
 //   M[2]    f32 [pair][5][Hk*Wk]          2x2 systems, planar, ping-pong
 //   lflow   f32 [2][pair][Hk*Wk][2]       per-level flow, ping-pong between levels
@@ -52,148 +52,123 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---------------------------------------------------------------------------------
-// A1, level 0 (and any level whose size equals the frame's): kszxksz blur with a
-// small kernel, fused row+column pass through LDS.  Tile 64x16, 256 threads.
+// A1: level image = resize(GaussianBlur(float(frame)), level size), one kernel per level.
+// A block produces a tile of TWo x THo level pixels.  It stages the uint8 source region
+// those pixels depend on (with the blur's halo, REFLECT_101 applied while loading) in
+// LDS, runs the row pass only at the two source columns each output column interpolates
+// between, then the column pass at the two source rows of each output row, then the two
+// lerps.  Tap order and float rounding are those of the CPU filters (row pass: paired
+// taps for ksz <= 5, left-to-right otherwise; column pass: centre, then pairs outwards).
+// In the row pass lanes walk source ROWS, so the byte reads of one instruction hit
+// different LDS banks (pitch/4 is odd).
 // ---------------------------------------------------------------------------------
-constexpr int B3_TW = 64, B3_TH = 16;
+struct ImgTile {
+    int TWo, THo;   // output tile
+    int LW, LH;     // source columns / rows staged per tile (upper bounds)
+    int pitch;      // bytes per staged source row, multiple of 4 with pitch/4 odd
+    int same_size;  // level size == frame size: resize is a copy
+};
 
-__global__ void k_blur_small_u8(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs,
-                                float *__restrict__ img, int W, int H, const float *__restrict__ kern, int ksz)
+__global__ void __launch_bounds__(256)
+k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W,
+              int H, int Wk, int Hk, const int *__restrict__ xofs, const float *__restrict__ xfrac,
+              const int *__restrict__ yofs, const float *__restrict__ yfrac, const float *__restrict__ kern, int ksz,
+              ImgTile tl)
 {
-    extern __shared__ float s_rows[]; // [(TH + 2r)][TW]
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    uint8_t *sS = s_raw;                                                // [LH][pitch] source bytes
+    float *sR = reinterpret_cast<float *>(s_raw + (size_t)tl.LH * tl.pitch); // [LH][2*TWo] row-pass values
     const int r = ksz >> 1;
     const int pi = blockIdx.z;
     const int2 pr = pairs[pi >> 1];
     const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
-    const int x0 = blockIdx.x * B3_TW, y0 = blockIdx.y * B3_TH;
-    const int rows = B3_TH + 2 * r;
-    for (int idx = threadIdx.x; idx < rows * B3_TW; idx += blockDim.x) {
-        int ry = idx / B3_TW, cx = idx % B3_TW;
-        int x = x0 + cx;
-        float acc = 0.f;
-        if (x < W) {
-            const uint8_t *s = src + (size_t)reflect101(y0 - r + ry, H) * W;
-            if (ksz == 3) {
-                acc = (float)s[x] * kern[1] + ((float)s[reflect101(x - 1, W)] + (float)s[reflect101(x + 1, W)]) * kern[2];
-            } else if (ksz == 5) {
-                acc = (float)s[x] * kern[2] +
-                      ((float)s[reflect101(x - 1, W)] + (float)s[reflect101(x + 1, W)]) * kern[3] +
-                      ((float)s[reflect101(x - 2, W)] + (float)s[reflect101(x + 2, W)]) * kern[4];
-            } else {
-                acc = kern[0] * (float)s[reflect101(x - r, W)];
-                for (int i = 1; i < ksz; i++)
-                    acc += kern[i] * (float)s[reflect101(x - r + i, W)];
-            }
-        }
-        s_rows[idx] = acc;
+    const int dx0 = blockIdx.x * tl.TWo, dy0 = blockIdx.y * tl.THo;
+    const int ndx = min(tl.TWo, Wk - dx0), ndy = min(tl.THo, Hk - dy0);
+    const int x_lo = xofs[dx0] - r, x_hi = min(xofs[dx0 + ndx - 1] + 1, W - 1) + r;
+    const int y_lo = clampi(yofs[dy0], 0, H - 1) - r, y_hi = clampi(yofs[dy0 + ndy - 1] + 1, 0, H - 1) + r;
+    const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // phase 1: stage the source region; a wave copies one row at a time, lanes along x
+    for (int ry = wave; ry < nrows; ry += 4) {
+        const uint8_t *srow = src + (size_t)reflect101(y_lo + ry, H) * W;
+        uint8_t *drow = sS + ry * tl.pitch;
+        for (int cx = lane; cx < ncols; cx += 64)
+            drow[cx] = srow[reflect101(x_lo + cx, W)];
     }
     __syncthreads();
-    float *dst = img + (size_t)pi * W * H;
-    for (int idx = threadIdx.x; idx < B3_TH * B3_TW; idx += blockDim.x) {
-        int ty = idx / B3_TW, cx = idx % B3_TW;
-        int x = x0 + cx, y = y0 + ty;
-        if (x >= W || y >= H)
-            continue;
-        // LDS slot (ty + r +- i) holds image row reflect101(y +- i): the reflection was applied
-        // when the slot was filled
-        float acc = kern[r] * s_rows[(ty + r) * B3_TW + cx];
-        for (int i = 1; i <= r; i++) {
-            float a = s_rows[(ty + r + i) * B3_TW + cx];
-            float b = s_rows[(ty + r - i) * B3_TW + cx];
-            acc += kern[r + i] * (a + b);
+    // phase 2: row pass at the needed columns.  With many staged rows the lanes walk rows
+    // (conflict-free byte reads); with few (small kernels) they walk output columns.
+    const int no = 2 * ndx;
+    const int ostep = tl.same_size ? 2 : 1; // a copy-sized level only needs column sx
+    const bool lanes_on_rows = nrows >= 48;
+    const int n_a = lanes_on_rows ? nrows : no, n_b = lanes_on_rows ? no : nrows;
+    for (int b_ = wave; b_ < n_b; b_ += 4) {
+        for (int a_ = lane; a_ < n_a; a_ += 64) {
+            const int ry = lanes_on_rows ? a_ : b_, o = lanes_on_rows ? b_ : a_;
+            if (ostep == 2 && (o & 1))
+                continue;
+            int sx = xofs[dx0 + (o >> 1)];
+            int col = (o & 1) ? min(sx + 1, W - 1) : sx;
+            const uint8_t *p = sS + ry * tl.pitch + (col - x_lo); // tap i sits at p[i - r]
+            float acc;
+            if (ksz == 3) {
+                acc = (float)p[0] * kern[1] + ((float)p[-1] + (float)p[1]) * kern[2];
+            } else if (ksz == 5) {
+                acc = (float)p[0] * kern[2] + ((float)p[-1] + (float)p[1]) * kern[3] +
+                      ((float)p[-2] + (float)p[2]) * kern[4];
+            } else {
+                acc = kern[0] * (float)p[-r];
+                for (int i = 1; i < ksz; i++)
+                    acc += kern[i] * (float)p[i - r];
+            }
+            sR[ry * (2 * tl.TWo) + o] = acc;
         }
-        dst[(size_t)y * W + x] = acc;
     }
-}
-
-// ---------------------------------------------------------------------------------
-// A1, levels >= 1: row pass of the full-resolution blur, evaluated only at the two
-// source columns (sx, sx+1) each output column interpolates between.
-//   tmp [pairimg][H][Wk][2]
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ float row_conv(const uint8_t *__restrict__ s, int col, int W, const float *__restrict__ kern,
-                                          int ksz)
-{
-    const int r = ksz >> 1;
-    if (ksz == 3)
-        return (float)s[col] * kern[1] + ((float)s[reflect101(col - 1, W)] + (float)s[reflect101(col + 1, W)]) * kern[2];
-    if (ksz == 5)
-        return (float)s[col] * kern[2] + ((float)s[reflect101(col - 1, W)] + (float)s[reflect101(col + 1, W)]) * kern[3] +
-               ((float)s[reflect101(col - 2, W)] + (float)s[reflect101(col + 2, W)]) * kern[4];
-    float acc;
-    if (col - r >= 0 && col + r < W) {
-        const uint8_t *p = s + col - r;
-        acc = kern[0] * (float)p[0];
-        for (int i = 1; i < ksz; i++)
-            acc += kern[i] * (float)p[i];
-    } else {
-        acc = kern[0] * (float)s[reflect101(col - r, W)];
-        for (int i = 1; i < ksz; i++)
-            acc += kern[i] * (float)s[reflect101(col - r + i, W)];
+    __syncthreads();
+    // phase 3: column pass at the needed rows, then the lerps
+    float *dst = img + (size_t)pi * Wk * Hk;
+    for (int idx = threadIdx.x; idx < ndy * tl.TWo; idx += blockDim.x) {
+        int ty = idx / tl.TWo, tx = idx - ty * tl.TWo; // TWo is a power of two
+        if (tx >= ndx)
+            continue;
+        int dx = dx0 + tx, dy = dy0 + ty;
+        int sy = yofs[dy];
+        int row0 = clampi(sy, 0, H - 1) - y_lo, row1 = clampi(sy + 1, 0, H - 1) - y_lo;
+        const float *c0 = sR + row0 * (2 * tl.TWo) + 2 * tx;
+        const float *c1 = sR + row1 * (2 * tl.TWo) + 2 * tx;
+        const int st = 2 * tl.TWo;
+        float v00 = kern[r] * c0[0];
+        for (int i = 1; i <= r; i++)
+            v00 += kern[r + i] * (c0[i * st] + c0[-i * st]);
+        float out;
+        if (tl.same_size) {
+            out = v00;
+        } else {
+            float v01 = kern[r] * c0[1];
+            for (int i = 1; i <= r; i++)
+                v01 += kern[r + i] * (c0[i * st + 1] + c0[-i * st + 1]);
+            float v10 = v00, v11 = v01;
+            if (row1 != row0) {
+                v10 = kern[r] * c1[0];
+                v11 = kern[r] * c1[1];
+                for (int i = 1; i <= r; i++) {
+                    v10 += kern[r + i] * (c1[i * st] + c1[-i * st]);
+                    v11 += kern[r + i] * (c1[i * st + 1] + c1[-i * st + 1]);
+                }
+            }
+            float fx = xfrac[dx], fy = yfrac[dy];
+            float h0, h1;
+            if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+                h0 = v00;
+                h1 = v10;
+            } else {
+                h0 = v00 * (1.f - fx) + v01 * fx;
+                h1 = v10 * (1.f - fx) + v11 * fx;
+            }
+            out = h0 * (1.f - fy) + h1 * fy;
+        }
+        dst[(size_t)dy * Wk + dx] = out;
     }
-    return acc;
-}
-
-__global__ void k_blur_rows(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs,
-                            float2 *__restrict__ tmp, int W, int H, int Wk, const int *__restrict__ xofs,
-                            const float *__restrict__ kern, int ksz)
-{
-    int dx = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y;
-    if (dx >= Wk)
-        return;
-    const int pi = blockIdx.z;
-    const int2 pr = pairs[pi >> 1];
-    const uint8_t *s = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H + (size_t)y * W;
-    int sx = xofs[dx];
-    int sx1 = sx + 1 < W ? sx + 1 : sx;
-    float2 v;
-    v.x = row_conv(s, sx, W, kern, ksz);
-    v.y = sx1 != sx ? row_conv(s, sx1, W, kern, ksz) : v.x;
-    tmp[((size_t)pi * H + y) * Wk + dx] = v;
-}
-
-// Column pass at the two source rows (sy, sy+1) + horizontal lerp + vertical lerp.
-__device__ __forceinline__ float2 col_conv(const float2 *__restrict__ t, int row, int H, int Wk, int dx,
-                                           const float *__restrict__ kern, int ksz)
-{
-    const int r = ksz >> 1;
-    float2 c = t[(size_t)row * Wk + dx];
-    float2 acc = make_float2(kern[r] * c.x, kern[r] * c.y);
-    for (int i = 1; i <= r; i++) {
-        float2 a = t[(size_t)reflect101(row + i, H) * Wk + dx];
-        float2 b = t[(size_t)reflect101(row - i, H) * Wk + dx];
-        acc.x += kern[r + i] * (a.x + b.x);
-        acc.y += kern[r + i] * (a.y + b.y);
-    }
-    return acc;
-}
-
-__global__ void k_blur_cols_resize(const float2 *__restrict__ tmp, float *__restrict__ img, int W, int H, int Wk, int Hk,
-                                   const int *__restrict__ xofs, const float *__restrict__ xfrac,
-                                   const int *__restrict__ yofs, const float *__restrict__ yfrac,
-                                   const float *__restrict__ kern, int ksz)
-{
-    int dx = blockIdx.x * blockDim.x + threadIdx.x;
-    int dy = blockIdx.y;
-    if (dx >= Wk)
-        return;
-    const int pi = blockIdx.z;
-    const float2 *t = tmp + (size_t)pi * H * Wk;
-    int sy = yofs[dy];
-    int sy0 = clampi(sy, 0, H - 1), sy1 = clampi(sy + 1, 0, H - 1);
-    float2 v0 = col_conv(t, sy0, H, Wk, dx, kern, ksz);
-    float2 v1 = sy1 != sy0 ? col_conv(t, sy1, H, Wk, dx, kern, ksz) : v0;
-    float fx = xfrac[dx], fy = yfrac[dy];
-    float h0, h1;
-    if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
-        h0 = v0.x;
-        h1 = v1.x;
-    } else {
-        h0 = v0.x * (1.f - fx) + v0.y * fx;
-        h1 = v1.x * (1.f - fx) + v1.y * fx;
-    }
-    img[(size_t)pi * Wk * Hk + (size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
 }
 
 // ---------------------------------------------------------------------------------
@@ -454,6 +429,141 @@ k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__
 }
 
 // ---------------------------------------------------------------------------------
+// A4, fast path: one WAVE marches a strip of 128 columns (two per lane) down `seg`
+// rows; no block barrier, so waves run decoupled and hide each other's latency.
+// Per row: the lane updates the vertical window sums of its two columns (double
+// registers, float2 loads, next row prefetched), publishes them to the wave's LDS
+// row, and reads back the 2M+2 neighbours it needs for its two outputs with
+// 16-byte LDS reads.  HALO = M rounded up to even keeps column pairs aligned.
+// ---------------------------------------------------------------------------------
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int M, bool VEC>
+__device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ Min, float2 *__restrict__ flow_out,
+                                                     int Wk, int Hk, double scale, int seg, double (*s_v)[128])
+{
+    constexpr int HALO = (M + 1) & ~1;
+    constexpr int OUTC = 128 - 2 * HALO;
+    constexpr int NE = 2 * HALO + 2; // LDS elements a lane reads per channel
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * OUTC - HALO + 2 * lane;
+    const int pair = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *Mi = Min + (size_t)pair * 5 * Nk;
+    const int r0 = blockIdx.y * seg, r1 = min(r0 + seg, Hk);
+    // VEC: the whole strip lies inside the image (wave-uniform), so every lane loads its two
+    // columns with one 8-byte load; otherwise two clamped scalar loads (replicated border)
+    const int ca = clampi(c0, 0, Wk - 1), cb = clampi(c0 + 1, 0, Wk - 1);
+
+    auto load_row = [&](int row, float2 out[5]) {
+        const size_t ro = (size_t)row * Wk;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float *p = Mi + c * Nk + ro;
+            if (VEC) {
+                float2u v = *reinterpret_cast<const float2u *>(p + c0);
+                out[c] = make_float2(v.x, v.y);
+            } else {
+                out[c] = make_float2(p[ca], p[cb]);
+            }
+        }
+    };
+
+    double vs[5][2];
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        vs[c][0] = vs[c][1] = 0.0;
+#pragma unroll 3
+    for (int j = -M; j <= M; j++) {
+        float2 v[5];
+        load_row(clampi(r0 + j, 0, Hk - 1), v);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            vs[c][0] += (double)v[c].x;
+            vs[c][1] += (double)v[c].y;
+        }
+    }
+    float2 nin[5], nout[5]; // rows entering / leaving the window at the NEXT step
+    if (r0 + 1 < r1) {
+        load_row(min(r0 + 1 + M, Hk - 1), nin);
+        load_row(max(r0 - M, 0), nout);
+    }
+    const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
+    for (int y = r0; y < r1; y++) {
+        if (y > r0) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c][0] += (double)nin[c].x - (double)nout[c].x;
+                vs[c][1] += (double)nin[c].y - (double)nout[c].y;
+            }
+            if (y + 1 < r1) {
+                load_row(min(y + 1 + M, Hk - 1), nin);
+                load_row(max(y - M, 0), nout);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            *reinterpret_cast<double2 *>(&s_v[c][2 * lane]) = make_double2(vs[c][0], vs[c][1]);
+        __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
+        if (is_out) {
+            double g0[5], g1[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                // element i of the lane's view is s_v[c][2*lane - HALO + i], i in [0, NE): output 0 sums
+                // i in [HALO-M, HALO+M], output 1 sums i in [HALO-M+1, HALO+M+1]; the 2M shared terms
+                // are added once
+                double first = 0, last = 0, common = 0;
+#pragma unroll
+                for (int q = 0; q < NE / 2; q++) {
+                    if (2 * q + 1 < HALO - M || 2 * q > HALO + M + 1)
+                        continue;
+                    double2 d = *reinterpret_cast<const double2 *>(&s_v[c][2 * lane - HALO + 2 * q]);
+                    if (2 * q == HALO - M)
+                        first = d.x;
+                    else if (2 * q > HALO - M && 2 * q <= HALO + M)
+                        common += d.x;
+                    else if (2 * q == HALO + M + 1)
+                        last = d.x;
+                    if (2 * q + 1 == HALO - M)
+                        first = d.y;
+                    else if (2 * q + 1 > HALO - M && 2 * q + 1 <= HALO + M)
+                        common += d.y;
+                    else if (2 * q + 1 == HALO + M + 1)
+                        last = d.y;
+                }
+                g0[c] = (first + common) * scale;
+                g1[c] = (common + last) * scale;
+            }
+            double idet0 = 1. / (g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
+            double idet1 = 1. / (g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
+            float2 f0 = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
+                                    (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
+            float2 f1 = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
+                                    (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+            float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
+            o[0] = f0;
+            if (c0 + 1 < Wk)
+                o[1] = f1;
+        }
+        __syncthreads(); // the next row's writes must not overtake this row's reads
+    }
+}
+
+template <int M>
+__global__ void __launch_bounds__(64, 4)
+k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, double scale, int seg)
+{
+    constexpr int HALO = (M + 1) & ~1;
+    constexpr int OUTC = 128 - 2 * HALO;
+    __shared__ __attribute__((aligned(16))) double s_v[5][128];
+    const int first = (int)blockIdx.x * OUTC - HALO;
+    if (first >= 0 && first + 127 < Wk)
+        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_v);
+    else
+        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_v);
+}
+
+// ---------------------------------------------------------------------------------
 // B1: FlowSource.post_process (source.py:337-363)
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float2 clip_to_frame(float2 f, int i, int j, int W, int H)
@@ -675,6 +785,7 @@ struct LerpDev {
 struct Level {
     int W, H, ksz;
     double sigma;
+    ImgTile tile;
     DevBuf kern;
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
     LerpDev flow_lerp; // level k+1 -> this level
@@ -689,7 +800,7 @@ struct tf_fb {
     int slots = 0, max_pairs = 0;
     PolyConst pc;
     std::vector<Level *> lv;
-    DevBuf frames, img, tmp, R, M[2], lflow[2], pairs, winner, scratch;
+    DevBuf frames, img, R, M[2], lflow[2], pairs, winner, scratch;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
     ~tf_fb()
@@ -702,23 +813,53 @@ struct tf_fb {
 static int fb_level_image(tf_fb *fb, int k, int n_pairs)
 {
     Level &L = *fb->lv[k];
-    const int W = fb->W, H = fb->H;
-    const int2 *pairs = fb->pairs.as<int2>();
-    const uint8_t *frames = fb->frames.as<uint8_t>();
-    if (L.W == W && L.H == H) { // resize of equal sizes is a copy
-        dim3 grid(cdiv(W, B3_TW), cdiv(H, B3_TH), n_pairs * 2);
-        size_t smem = (size_t)(B3_TH + 2 * (L.ksz / 2)) * B3_TW * sizeof(float);
-        return launch("fb_blur_small", k_blur_small_u8, grid, dim3(256), smem, frames, pairs, fb->img.as<float>(), W, H,
-                      (const float *)L.kern.as<float>(), L.ksz);
+    const ImgTile &t = L.tile;
+    dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
+    size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float);
+    return launch("fb_level_image", k_level_image, grid, dim3(256), smem, (const uint8_t *)fb->frames.as<uint8_t>(),
+                  (const int2 *)fb->pairs.as<int2>(), fb->img.as<float>(), fb->W, fb->H, L.W, L.H,
+                  (const int *)L.img_lerp.xofs.as<int>(), (const float *)L.img_lerp.xfrac.as<float>(),
+                  (const int *)L.img_lerp.yofs.as<int>(), (const float *)L.img_lerp.yfrac.as<float>(),
+                  (const float *)L.kern.as<float>(), L.ksz, t);
+}
+
+// Output tile of a level: as large as fits ~60 KB of LDS, given the source extent a tile needs.
+static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
+{
+    std::vector<int> xo, yo;
+    std::vector<float> fr;
+    make_lerp(W, Wk, true, xo, fr);
+    make_lerp(H, Hk, false, yo, fr);
+    const int r = ksz / 2;
+    auto extent = [&](const std::vector<int> &ofs, int n, int len, int tile) {
+        int worst = 0;
+        for (int d0 = 0; d0 < n; d0 += tile) {
+            int d1 = std::min(n, d0 + tile) - 1;
+            int lo = std::max(0, std::min(ofs[d0], len - 1)), hi = std::max(0, std::min(ofs[d1] + 1, len - 1));
+            worst = std::max(worst, hi - lo + 1 + 2 * r);
+        }
+        return worst;
+    };
+    int s = std::max(1, (W + Wk - 1) / Wk);
+    ImgTile t;
+    t.same_size = (W == Wk && H == Hk);
+    t.TWo = std::max(8, std::min(64, 256 / s));
+    t.THo = std::max(2, std::min(16, 128 / s));
+    for (;;) {
+        t.LW = extent(xo, Wk, W, t.TWo);
+        t.LH = extent(yo, Hk, H, t.THo);
+        t.pitch = (t.LW + 3) & ~3;
+        if (((t.pitch / 4) & 1) == 0)
+            t.pitch += 4;
+        size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float);
+        if (smem <= 60 * 1024 || (t.TWo <= 2 && t.THo <= 1))
+            break;
+        if (t.THo > 1 && (t.THo >= t.TWo / 4 || t.TWo <= 2))
+            t.THo = std::max(1, t.THo / 2);
+        else
+            t.TWo = std::max(2, t.TWo / 2);
     }
-    dim3 g1(cdiv(L.W, 128), H, n_pairs * 2);
-    TF_TRY(launch("fb_blur_rows", k_blur_rows, g1, dim3(128), 0, frames, pairs, fb->tmp.as<float2>(), W, H, L.W,
-                  (const int *)L.img_lerp.xofs.as<int>(), (const float *)L.kern.as<float>(), L.ksz));
-    dim3 g2(cdiv(L.W, 128), L.H, n_pairs * 2);
-    return launch("fb_blur_cols_resize", k_blur_cols_resize, g2, dim3(128), 0, (const float2 *)fb->tmp.as<float2>(),
-                  fb->img.as<float>(), W, H, L.W, L.H, (const int *)L.img_lerp.xofs.as<int>(),
-                  (const float *)L.img_lerp.xfrac.as<float>(), (const int *)L.img_lerp.yofs.as<int>(),
-                  (const float *)L.img_lerp.yfrac.as<float>(), (const float *)L.kern.as<float>(), L.ksz);
+    return t;
 }
 
 static int fb_polyexp(tf_fb *fb, int w, int h, int n_images)
@@ -737,22 +878,43 @@ static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowIn
                   fb->M[mbuf].as<float>(), w, h, fi);
 }
 
-static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, bool update, float2 *flow_out)
+template <int M>
+static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out, double scale)
+{
+    constexpr int HALO = (M + 1) & ~1;
+    constexpr int OUTC = 128 - 2 * HALO;
+    const unsigned strips = cdiv(w, OUTC);
+    // ~16 waves per CU in flight; each segment re-sums its first window (2M+1 rows)
+    long segs_wanted = std::max(1l, 4096 / std::max(1l, (long)strips * n_pairs));
+    int seg = (int)std::min<long>(256, std::max<long>(32, (h + segs_wanted - 1) / segs_wanted));
+    dim3 grid(strips, cdiv(h, seg), n_pairs);
+    return launch("fb_blur_solve", k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M[mbuf_in].as<float>(),
+                  flow_out, w, h, scale, seg);
+}
+
+static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out)
 {
     const int m = fb->prm.winsize / 2;
-    const int out_cols = BS_THREADS - 2 * m;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
+    switch (m) {
+    case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 3: return launch_blur_solve_wave<3>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 4: return launch_blur_solve_wave<4>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 5: return launch_blur_solve_wave<5>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 6: return launch_blur_solve_wave<6>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 7: return launch_blur_solve_wave<7>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 8: return launch_blur_solve_wave<8>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 10: return launch_blur_solve_wave<10>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    default: break;
+    }
+    // any other window: the generic block-per-strip kernel
+    const int out_cols = BS_THREADS - 2 * m;
     const unsigned strips = cdiv(w, out_cols);
-    // enough row segments to fill the chip (~4 blocks per CU); each segment re-sums its first
-    // window (2m+1 rows), so keep segments well above the window height
     long segs_wanted = std::max(1l, 1024 / std::max(1l, (long)strips * n_pairs));
     int seg = (int)std::min<long>(128, std::max<long>(16, (h + segs_wanted - 1) / segs_wanted));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
-    if (update)
-        return launch("fb_blur_solve_update", k_blur_solve<true>, grid, dim3(BS_THREADS), 0,
-                      (const float *)fb->M[mbuf_in].as<float>(), fb->M[mbuf_in ^ 1].as<float>(), flow_out,
-                      (const float *)fb->R.as<float>(), w, h, m, scale, seg);
-    return launch("fb_blur_solve", k_blur_solve<false>, grid, dim3(BS_THREADS), 0,
+    return launch("fb_blur_solve_generic", k_blur_solve<false>, grid, dim3(BS_THREADS), 0,
                   (const float *)fb->M[mbuf_in].as<float>(), (float *)nullptr, flow_out,
                   (const float *)fb->R.as<float>(), w, h, m, scale, seg);
 }
@@ -802,7 +964,6 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         fb->K = k;
     }
     int rc;
-    size_t max_tmp = 0;
     for (int k = 0; k <= fb->K; k++) {
         Level *L = new Level;
         fb->lv.push_back(L);
@@ -821,10 +982,14 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             return fail(rc);
         if (hipMemcpy(L->kern.p, kern.data(), kern.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             return fail(set_error(TF_ERR_HIP, "hipMemcpy failed"));
-        if (!(L->W == width && L->H == height)) {
-            if ((rc = L->img_lerp.upload_tabs(width, height, L->W, L->H)))
-                return fail(rc);
-            max_tmp = std::max(max_tmp, (size_t)height * L->W);
+        if ((rc = L->img_lerp.upload_tabs(width, height, L->W, L->H)))
+            return fail(rc);
+        L->tile = choose_tile(width, height, L->W, L->H, L->ksz);
+        {
+            size_t smem = (size_t)L->tile.LH * L->tile.pitch + (size_t)L->tile.LH * 2 * L->tile.TWo * sizeof(float);
+            if (smem > 64 * 1024)
+                return fail(set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: level %d needs %zu bytes of LDS per tile "
+                                                          "(blur kernel %d taps)", k, smem, L->ksz));
         }
     }
     for (int k = 0; k < fb->K; k++) {
@@ -834,7 +999,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
     }
     const size_t N0 = (size_t)width * height, P = (size_t)max_pairs;
     if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
-        (rc = fb->tmp.alloc(std::max<size_t>(1, P * 2 * max_tmp * 8))) || (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
+        (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
         (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->pairs.alloc(P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
@@ -914,12 +1079,15 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             fi.yfrac = L.flow_lerp.yfrac.as<float>();
             fi.mul = (float)(1. / fb->prm.pyr_scale);
         }
-        int mb = 0;
-        TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, mb));
+        TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0));
+        FlowInit fl;
+        memset(&fl, 0, sizeof(fl));
+        fl.mode = 2;
+        fl.src = fb->lflow[cur].as<float2>();
         for (int i = 0; i < fb->prm.iterations; i++) {
-            bool last = i == fb->prm.iterations - 1;
-            TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, mb, !last, last ? fb->lflow[cur].as<float2>() : nullptr));
-            mb ^= 1;
+            TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, 0, fb->lflow[cur].as<float2>()));
+            if (i < fb->prm.iterations - 1) // M is a pure function of (R0, R1, flow): rebuild it in place
+                TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0));
         }
         fb->final_buf = cur;
         cur ^= 1;
@@ -1072,7 +1240,7 @@ TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float
     TF_TRY(ensure_init());
     size_t n = (size_t)w * h;
     TF_TRY(upload_planar5(fb->M[0].as<float>(), m, n, fb->scratch));
-    TF_TRY(fb_blur_solve(fb, w, h, 1, 0, false, fb->lflow[0].as<float2>()));
+    TF_TRY(fb_blur_solve(fb, w, h, 1, 0, fb->lflow[0].as<float2>()));
     TF_HIP(hipMemcpyAsync(flow_out, fb->lflow[0].p, n * 8, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
     return TF_OK;

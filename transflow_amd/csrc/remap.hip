@@ -267,6 +267,131 @@ __global__ void k_remap_render(uchar4 *__restrict__ rgba, const float *__restric
     }
 }
 
+// The resident path's single launch per frame: [clip of post_process] + move + random reset +
+// gather of source 0 + Layer.render + Compositor.render for a one-layer compositor.  Same
+// statements as the separate kernels above, applied per pixel in the reference's order; valid
+// when nothing needs a second pass over `neu` (no leave-empty scatter).  RGB output is staged
+// through LDS so the 3-byte pixels leave as whole dwords.
+struct StepParams {
+    MoveFlags fl;
+    int clip_flow;     // apply source.py:361-362 to the flow in registers (BACKWARD post_process)
+    int reset_random;  // reset_mode == random
+    float factor;
+    int reset_source;
+    int n_sources;
+    uint64_t seed, frame;
+    uchar4 bg;
+};
+
+template <int C>
+__global__ void __launch_bounds__(BLOCK)
+k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4 *__restrict__ neu,
+             const uint8_t *__restrict__ msrc, const uint8_t *__restrict__ mdst, const double *__restrict__ u,
+             const float *__restrict__ reset_mask, const uint8_t *__restrict__ intro, uchar4 *__restrict__ rgba,
+             const uint8_t *__restrict__ pixmap, const float *__restrict__ mask_alpha, uint8_t *__restrict__ image,
+             int N, int H, int W, StepParams sp, int *err)
+{
+    __shared__ uint32_t s_rgb[BLOCK * 3 / 4];
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    uint8_t *s8 = reinterpret_cast<uint8_t *>(s_rgb);
+    if (t < N) {
+        const int i = t / W, j = t % W;
+        float2 f = flow[t];
+        if (sp.clip_flow) {
+            f.x = fminf(fmaxf(f.x, (float)(-j)), (float)(W - 1 - j));
+            f.y = fminf(fmaxf(f.y, (float)(-i)), (float)(H - 1 - i));
+        }
+        // --- move (movement.py:20-60)
+        int4 me = old[t];
+        int4 d = me;
+        long long off = flow_offset(f, W);
+        if (off != 0) {
+            long long s = t + off;
+            if (s < 0 || s >= N) {
+                atomicOr(err, 1);
+            } else {
+                int4 so = old[s];
+                bool src_filled = so.z != 0;
+                bool ms = (msrc ? msrc[s] != 0 : true) && (sp.fl.transparent_can_move || src_filled);
+                bool md = (mdst ? mdst[t] != 0 : true) && (sp.fl.to_empty || me.z != 0) && (sp.fl.to_filled || me.z == 0);
+                if (ms && md) {
+                    d = so;
+                    if (!sp.fl.transparent_can_move || src_filled)
+                        d.z = 1;
+                }
+            }
+        }
+        // --- random reset (reference.py:58-67)
+        if (sp.reset_random) {
+            float thr = reset_mask ? sp.factor * reset_mask[t] : sp.factor;
+            double uu = u ? u[t] : philox_uniform((uint32_t)t, sp.frame, sp.seed);
+            if (uu < (double)thr) {
+                d.x = i;
+                d.y = j;
+                d.z = 1;
+                if (sp.reset_source)
+                    for (int s = 0; s < sp.n_sources; s++)
+                        if (intro[(size_t)s * N + t])
+                            d.w = s;
+            }
+        }
+        neu[t] = d;
+        // --- gather of source 0 (reference.py:94-105)
+        bool sel = d.w == 0 && d.z != 0;
+        uchar4 px;
+        if (C == 4) {
+            if (sel) {
+                int gi = min(max(d.x, 0), H - 1), gj = min(max(d.y, 0), W - 1);
+                px = reinterpret_cast<const uchar4 *>(pixmap)[(size_t)gi * W + gj];
+            } else {
+                px = rgba[t];
+            }
+        } else {
+            if (sel) {
+                int gi = min(max(d.x, 0), H - 1), gj = min(max(d.y, 0), W - 1);
+                const uint8_t *p = pixmap + ((size_t)gi * W + gj) * 3;
+                px = make_uchar4(p[0], p[1], p[2], 1);
+            } else {
+                px = rgba[t];
+                px.w = 0;
+            }
+        }
+        // --- Layer.render (layer.py:32-34)
+        if (mask_alpha)
+            px.w = (unsigned char)(int)(mask_alpha[t] * (float)px.w);
+        rgba[t] = px;
+        // --- Compositor.render over the background (compositor.py:35-39)
+        uchar4 o = px.w != 0 ? px : sp.bg;
+        s8[threadIdx.x * 3 + 0] = o.x;
+        s8[threadIdx.x * 3 + 1] = o.y;
+        s8[threadIdx.x * 3 + 2] = o.z;
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * BLOCK * 3; // multiple of 4
+    const size_t total = (size_t)N * 3;
+    if (threadIdx.x < BLOCK * 3 / 4) {
+        size_t b = base + (size_t)threadIdx.x * 4;
+        if (b + 4 <= total) {
+            *reinterpret_cast<uint32_t *>(image + b) = s_rgb[threadIdx.x];
+        } else {
+            for (size_t q = b; q < total; q++)
+                image[q] = s8[q - base];
+        }
+    }
+}
+
+__global__ void k_remap_clip_flow(float2 *flow, int W, int H)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= W * H)
+        return;
+    int i = t / W, j = t % W;
+    float2 f = flow[t];
+    f.x = fminf(fmaxf(f.x, (float)(-j)), (float)(W - 1 - j));
+    f.y = fminf(fmaxf(f.y, (float)(-i)), (float)(H - 1 - i));
+    flow[t] = f;
+}
+
 __global__ void k_comp_fill(uint8_t *image, int N, uchar4 bg)
 {
     int t = blockIdx.x * BLOCK + threadIdx.x;
@@ -571,5 +696,57 @@ TF_API int tf_remap_set_state(tf_remap *L, const int32_t *data, const uint8_t *r
     if (rgba && n)
         TF_HIP(hipMemcpyAsync(L->rgba.p, rgba, n * 4, hipMemcpyHostToDevice, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev,
+                             uint64_t seed, const void *pixmap_dev, int channels)
+{
+    TF_REQUIRE(L && comp && (flow_dev || L->N == 0) && (pixmap_dev || L->N == 0), "tf_remap_step_dev: null pointer");
+    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_step_dev: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_REQUIRE(L->H == comp->H && L->W == comp->W, "tf_remap_step_dev: layer is %dx%d, compositor %dx%d", L->W, L->H,
+               comp->W, comp->H);
+    TF_TRY(ensure_init());
+    if (L->N == 0)
+        return TF_OK;
+    const bool fusable = !L->fl.leave_empty && (L->cfg.reset_mode == 0 || L->cfg.reset_mode == 1);
+    if (!fusable) { // same statements, one launch each
+        if (clip_flow)
+            TF_TRY(launch("remap_clip_flow", k_remap_clip_flow, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
+                          (float2 *)const_cast<void *>(flow_dev), L->W, L->H));
+        TF_TRY(tf_remap_update_dev(L, flow_dev, uniform_dev, seed));
+        TF_TRY(tf_remap_gather_dev(L, 0, pixmap_dev, channels));
+        TF_TRY(tf_comp_begin(comp));
+        return tf_remap_render(L, comp);
+    }
+    StepParams sp;
+    sp.fl = L->fl;
+    sp.clip_flow = clip_flow != 0;
+    sp.reset_random = L->cfg.reset_mode == 1;
+    sp.factor = (float)L->cfg.reset_random_factor;
+    sp.reset_source = L->cfg.reset_source;
+    sp.n_sources = L->n_sources;
+    sp.seed = seed;
+    sp.frame = L->frame;
+    sp.bg = comp->bg;
+    dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
+    const int4 *old = L->data[L->cur].as<int4>();
+    int4 *neu = L->data[L->cur ^ 1].as<int4>();
+    if (channels == 4)
+        TF_TRY(launch("remap_step_rgba", k_remap_step<4>, grid, block, 0, (const float2 *)flow_dev, old, neu,
+                      (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
+                      (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
+                      (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
+                      (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
+                      L->err.as<int>()));
+    else
+        TF_TRY(launch("remap_step_rgb", k_remap_step<3>, grid, block, 0, (const float2 *)flow_dev, old, neu,
+                      (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
+                      (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
+                      (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
+                      (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
+                      L->err.as<int>()));
+    L->cur ^= 1;
+    L->frame++;
     return TF_OK;
 }

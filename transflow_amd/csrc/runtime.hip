@@ -83,6 +83,7 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 static bool g_prof = false;
+static std::string g_prof_filter;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free_events;
 static std::map<std::string, std::pair<long, double>> g_acc;
@@ -121,6 +122,8 @@ static void prof_drain()
 ProfScope::ProfScope(const char *name) : slot(-1)
 {
     if (!g_prof)
+        return;
+    if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str()))
         return;
     if (g_recs.size() >= 4096)
         prof_drain();
@@ -218,6 +221,12 @@ TF_API int tf_prof_enable(int on)
     return TF_OK;
 }
 
+TF_API int tf_prof_set_filter(const char *substring)
+{
+    g_prof_filter = substring ? substring : "";
+    return TF_OK;
+}
+
 TF_API int tf_prof_reset(void)
 {
     prof_drain();
@@ -271,5 +280,13 @@ TF_API int tf_dev_download(void *host, const void *dev, size_t bytes)
     TF_TRY(ensure_init());
     TF_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_dev_copy(void *dst_dev, const void *src_dev, size_t bytes)
+{
+    TF_REQUIRE(dst_dev && src_dev, "tf_dev_copy: null pointer");
+    TF_TRY(ensure_init());
+    TF_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, stream()));
     return TF_OK;
 }

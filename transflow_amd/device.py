@@ -1,0 +1,55 @@
+"""Raw device buffers (tf_dev_*): for harnesses that keep inputs resident in HBM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class DevBuffer:
+    def __init__(self, nbytes: int):
+        self._lib = _lib.load()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(self._lib.tf_dev_alloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, a: np.ndarray) -> "DevBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        buf.upload(a)
+        return buf
+
+    def upload(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a)
+        if a.nbytes > self.nbytes:
+            raise ValueError("array larger than the device buffer")
+        if a.nbytes:
+            check(self._lib.tf_dev_upload(C.c_void_p(self.ptr), C.c_void_p(a.ctypes.data), a.nbytes))
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("requested more bytes than the device buffer holds")
+        if out.nbytes:
+            check(self._lib.tf_dev_download(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self._lib.tf_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sync() -> None:
+    check(_lib.load().tf_sync())
