@@ -1,0 +1,184 @@
+"""GPU parity through the reference-shaped surface: HipFlowSource / HipCompositor used
+the way transflow/pipeline.py uses FlowSource / Compositor (pipeline.py:562-567:
+flow = next(flow_source); compositor.update(flow); compositor.render())."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import farneback as OF
+from oracle import remap_ref as R
+from tests.helpers import GOLDEN, PRM_KEYS, case_cfg, layer_case_files, oracle_params, synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeSource:
+    """PixmapSourceInterface stand-in (pixmap_source_interface.py:12-37)."""
+
+    def __init__(self, frames, introduction_mask):
+        self.frames, self.introduction_mask, self.counter = list(frames), introduction_mask, -1
+
+    def next(self, timeout=1):
+        self.counter += 1
+        return self.frames[self.counter % len(self.frames)]
+
+
+def _frames(h, w, n, seed=5):
+    out = []
+    for i in range(n):
+        a, b = synth_pair(h, w, seed=seed, shift=(0.8 * i, 0.5 * i))
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize("direction", ["forward", "backward"])
+def test_flow_source_matches_oracle(direction):
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 120, 160
+    frames = _frames(h, w, 4)
+    builder = HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction=direction)
+    with builder as source:
+        # what reference tests/test_flow_source.py:22-33 checks
+        assert (source.width, source.height, source.framerate, source.length) == (w, h, 25.0, 3)
+        flows = list(source)
+    assert len(flows) == 3
+    for t, flow in enumerate(flows):
+        assert isinstance(flow, np.ndarray) and flow.shape == (h, w, 2) and flow.dtype == np.float32
+        prev, nxt = (frames[t], frames[t + 1]) if direction == "forward" else (frames[t + 1], frames[t])
+        raw = OF.calc(prev, nxt)
+        d = R.FORWARD if direction == "forward" else R.BACKWARD
+        if d == R.BACKWARD:
+            # the clip only touches vectors that leave the frame; compare within tolerance
+            exp = R.post_process(raw.copy(), d)
+            assert np.abs(flow - exp).max() <= 1e-4 * max(1.0, float(np.abs(exp).max()))
+        else:
+            # FORWARD output is an integer gather map of the GPU's own flow: it must be exactly
+            # post_process(oracle) wherever rounding the two raw flows agrees
+            exp = R.post_process(raw.copy(), d)
+            assert (flow == np.rint(flow)).all()
+            assert (flow != exp).any(axis=2).mean() < 0.01
+        pickle.loads(pickle.dumps(flow))   # what pipeline.py:86 puts on the queue
+
+
+def test_flow_source_repeat_and_seek():
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 64, 96
+    frames = _frames(h, w, 6, seed=9)
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 10.0), direction="backward", seek_time=0.2,
+                                 repeat=2) as source:
+        assert source.length == 2 * 3
+        flows = [f.copy() for f in source]
+    assert len(flows) == 6
+    for t in range(3):                      # second pass replays the first after the rewind
+        np.testing.assert_array_equal(flows[t], flows[t + 3])
+    single = OF.calc(frames[3], frames[2])
+    assert np.abs(flows[0] - R.post_process(single, R.BACKWARD)).max() <= 1e-4 * max(1, np.abs(single).max())
+
+
+@pytest.mark.parametrize("path", [p for p in layer_case_files()
+                                  if any(k in p for k in ("flags05", "holes13", "masks_bool", "reset_random_p05",
+                                                          "two_sources_rgb", "rgba_pixmap", "reset_linear"))],
+                         ids=lambda p: os.path.basename(p)[12:-4])
+def test_compositor_matches_reference_vectors(path):
+    """The reference's own vectors through HipCompositor; the random-reset field is drawn
+    from numpy's global generator on the host exactly like reference.py:59."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    z = np.load(path)
+    h, w = int(z["h"]), int(z["w"])
+    cfg = case_cfg(z)
+    ns = int(z["nsources"])
+    comp = HipCompositor.from_args(h, w, [LayerConfig(0, **cfg)],
+                                   background_color="#%02x%02x%02x" % tuple(int(v) for v in z["background"]))
+    layer = comp.layers[0]
+    # the capture script installed arbitrary mask arrays on the reference layer: do the same here
+    layer.mask_src, layer.mask_dst = z["mask_src"], z["mask_dst"]
+    layer.mask_alpha, layer.reset_mask = z["mask_alpha"], z["reset_mask"]
+    comp.set_sources({0: [FakeSource(z[f"pixmap_{s}"], z[f"intro_{s}"]) for s in range(ns)]})
+    orig = np.random.random
+    for t in range(int(z["nframes"])):
+        np.random.random = lambda size=None, _u=z[f"u_{t}"]: _u.copy()
+        try:
+            comp.update(z[f"flow_{t}"])
+        finally:
+            np.random.random = orig
+        np.testing.assert_array_equal(layer.data, z[f"data_{t}"], err_msg=f"data t={t}")
+        frame = comp.render()
+        assert frame.dtype == np.uint8 and frame.shape == (h, w, 3)
+        np.testing.assert_array_equal(frame, z[f"frame_{t}"], err_msg=f"frame t={t}")
+
+
+def test_numpy_seed_reproduces_reference_stream():
+    """Same numpy seed => same reset decisions as the reference would take (it draws
+    numpy.random.random((H, W)) once per update, reference.py:59)."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    h, w = 33, 47
+    rng = np.random.default_rng(1)
+    flows = [R.post_process(rng.normal(0, 2, (h, w, 2)).astype(np.float32), R.BACKWARD) for _ in range(3)]
+    comp = HipCompositor.from_args(h, w, [LayerConfig(0, reset_mode="random", reset_random_factor=0.3)])
+    ora = R.MoveRefLayer(h, w, R.LayerParams(reset_mode="random", reset_random_factor=0.3))
+    np.random.seed(1234)
+    for f in flows:
+        comp.update(f)
+    state = np.random.RandomState(1234)
+    for f in flows:
+        ora.update(f, u=state.random_sample((h, w)))
+    np.testing.assert_array_equal(comp.layers[0].data, ora.data)
+
+
+def test_checkpoint_pickle_roundtrip_is_bit_identical():
+    """reference tests/test_pipeline.py:90-119: resuming from a pickled compositor
+    reproduces the following frames bit for bit."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    h, w = 40, 56
+    rng = np.random.default_rng(2)
+    flows = [R.post_process(rng.normal(0, 3, (h, w, 2)).astype(np.float32), R.BACKWARD) for _ in range(6)]
+    pix = rng.integers(0, 256, (6, h, w, 3), dtype=np.uint8)
+    cfgs = [LayerConfig(0, moving_pixels_leave_empty_spot=True, reset_mode="linear", reset_linear_factor=0.2)]
+
+    def run(comp, lo, hi, frames_seen):
+        out = []
+        comp.set_sources({0: [FakeSource(pix[frames_seen:], np.ones((h, w), bool))]})
+        for t in range(lo, hi):
+            comp.update(flows[t])
+            out.append(comp.render())
+        return out
+
+    full = HipCompositor.from_args(h, w, cfgs, "#336699")
+    ref_frames = run(full, 0, 6, 0)
+    part = HipCompositor.from_args(h, w, cfgs, "#336699")
+    first = run(part, 0, 3, 0)
+    for layer in part.layers:           # pipeline.py:236-238 strips the sources before pickling
+        layer.sources = []
+    resumed = pickle.loads(pickle.dumps(part))
+    assert resumed.layers[0]._dev is None
+    np.testing.assert_array_equal(resumed.layers[0].data, part.layers[0].data)   # extra/control.py:155-162
+    rest = run(resumed, 3, 6, 3)
+    for a, b in zip(first + rest, ref_frames):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_pipeline_loop_matches_oracle_sequence():
+    """configs[0] plumbing stand-in: 854x480 frames, defaults, BACKWARD,
+    moveref with reset off -- the per-frame sequence of pipeline.py:562-567."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 480, 854
+    frames = _frames(h, w, 4, seed=21)
+    pixmap = np.random.default_rng(3).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    comp = HipCompositor.from_args(h, w, [LayerConfig(0)], "#ffffff")
+    comp.set_sources({0: [FakeSource([pixmap], np.ones((h, w), bool))]})
+    ora = R.MoveRefLayer(h, w, introduction_masks=[np.ones((h, w), bool)])
+    white = np.full((h, w, 3), 255, np.uint8)
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 50.0), direction="backward") as source:
+        for flow in source:
+            comp.update(flow)
+            frame = comp.render()
+            ora.update(flow, [pixmap])          # oracle remap driven by the SAME flow: bit-exact
+            np.testing.assert_array_equal(comp.layers[0].data, ora.data)
+            np.testing.assert_array_equal(frame, R.composite(white, [ora.render()]))

@@ -1,0 +1,209 @@
+"""Host-side mirror of the reference interface (no GPU): argument parsing, the Builder's
+timing arithmetic, lock logic, masks, config round trips, pickling of a never-used
+compositor.  Expected values for masks/colours come from the reference itself
+(tests/golden/masks.npz, tools/capture_golden.py)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN
+from transflow_amd import masks
+from transflow_amd.compositor import HipCompositor, HipMoveReferenceLayer
+from transflow_amd.config import FlowConfig, LayerConfig, parse_bool_arg
+from transflow_amd.flow import ArrayFrameProvider, FlowSource, HipFlowSource, to_grey
+
+
+def test_masks_and_colors_match_reference():
+    z = np.load(os.path.join(GOLDEN, "masks.npz"))
+    for shape in [(37, 53), (60, 80)]:
+        for i, spec in enumerate(z["specs"]):
+            f = masks.load_float_mask(str(spec), shape, 1)
+            b = masks.load_bool_mask(str(spec), shape, True)
+            np.testing.assert_array_equal(f, z[f"f_{shape[0]}_{i}"], err_msg=str(spec))
+            assert f.dtype == z[f"f_{shape[0]}_{i}"].dtype, spec
+            np.testing.assert_array_equal(b, z[f"b_{shape[0]}_{i}"], err_msg=str(spec))
+    np.testing.assert_array_equal(masks.load_float_mask(None, (4, 5), 1), z["none_float"])
+    np.testing.assert_array_equal(masks.load_bool_mask(None, (4, 5), True), z["none_bool"])
+    for c, v in zip(z["colors"], z["color_values"]):
+        assert masks.parse_color(str(c)) == tuple(int(x) for x in v), c
+    with pytest.raises(ValueError):
+        masks.load_float_mask("border:1:2:3", (8, 8))
+
+
+def test_layer_config_defaults_and_roundtrip():
+    c = LayerConfig(0)
+    assert c.classname == "moveref" and c.reset_mode == "off"
+    assert (c.transparent_pixels_can_move, c.pixels_can_move_to_empty_spot, c.pixels_can_move_to_filled_spot,
+            c.moving_pixels_leave_empty_spot) == (False, True, True, False)
+    assert c.reset_random_factor == 1 and c.reset_constant_step == 1 and c.reset_linear_factor == 0.1
+    c = LayerConfig(2, transparent_pixels_can_move="yes", pixels_can_move_to_empty_spot="off", reset_mode="random",
+                    reset_random_factor=0.25, mask_src="border:2")
+    assert c.transparent_pixels_can_move is True and c.pixels_can_move_to_empty_spot is False
+    d = c.todict()
+    c2 = LayerConfig.fromdict(d)
+    assert c2.todict() == d
+    assert LayerConfig.fromdict({"index": 1}).classname == "reference"   # reference config.py:110
+    assert parse_bool_arg("OUI", False) and not parse_bool_arg("no", True) and parse_bool_arg(None, True)
+
+
+def test_flow_config(tmp_path):
+    c = FlowConfig()
+    assert c.fb_kwargs() == dict(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0)
+    c = FlowConfig(fb_levels=5, hs_alpha=2.0)
+    p = tmp_path / "cfg.json"
+    c.to_file(str(p))
+    c2 = FlowConfig.from_file(str(p))
+    assert c2.fb_levels == 5 and c2.extra["hs_alpha"] == 2.0
+    with pytest.raises(ValueError):
+        FlowConfig(method="horn-schunck")
+
+
+def _builder(n_frames=51, fps=25.0, **kw):
+    frames = [np.zeros((4, 6), np.uint8)] * n_frames
+    return HipFlowSource.Builder(ArrayFrameProvider(frames, fps), None, **kw)
+
+
+def test_builder_timing_arithmetic():
+    """FlowSource.Builder.build, reference source.py:151-197."""
+    b = _builder()
+    b.build()
+    assert (b.width, b.height, b.framerate, b.base_length) == (6, 4, 25.0, 50)
+    assert (b.start_frame, b.end_frame, b.length, b.ckpt_start_frame) == (0, 50, 50, 0)
+    b = _builder(seek_time=1.0, duration_time=0.5, repeat=3)
+    b.build()
+    assert (b.start_frame, b.end_frame, b.length) == (25, 37, 36)
+    b = _builder(duration_time=10.0)
+    b.build()
+    assert b.end_frame == 50 and b.length == 50                      # clipped to the base length
+    b = _builder(repeat=0)
+    b.build()
+    assert b.length is None
+    b = _builder(seek_time=0.4, seek_ckpt=47)
+    b.build()
+    assert b.start_frame == 10 and b.ckpt_start_frame == 10 + 47 % 40
+    b = _builder(lock_expr="(0.2,0.4),(1,0.2)", lock_mode="stay")
+    b.build()
+    assert b.lock_expr_stay == ((0.2, 0.4), (1, 0.2)) and b.length == 50 + 10 + 5
+    b = _builder(lock_expr="t > 1", lock_mode="skip")
+    b.build()
+    assert b.lock_expr_skip(1.5) and not b.lock_expr_skip(0.5)
+    with pytest.raises(NotImplementedError):
+        _builder(mask_path="ones").build()
+
+
+def test_direction_and_lockmode_parsing():
+    D, L = FlowSource.Direction, FlowSource.LockMode
+    assert D.from_arg(None) is D.FORWARD and D.from_arg("backward") is D.BACKWARD and D.from_arg(1) is D.BACKWARD
+    assert L.from_arg(None) is L.STAY and L.from_arg("skip") is L.SKIP and L.from_arg(0) is L.STAY
+    with pytest.raises(ValueError):
+        D.from_arg("sideways")
+    assert FlowSource.Builder().direction is D.BACKWARD              # Builder default, source.py:61
+
+
+class _Scripted(FlowSource):
+    """Counts next() calls; flows are tagged with their index."""
+
+    def __init__(self, *a, **k):
+        self.calls = 0
+        super().__init__(*a, **k)
+
+    def next(self):
+        self.calls += 1
+        return np.full((2, 3, 2), float(self.calls), np.float32)
+
+    def post_process(self, raw):   # keep this test on the CPU
+        return raw
+
+
+def test_iteration_lock_stay_and_skip_and_rewind():
+    D, L = FlowSource.Direction, FlowSource.LockMode
+    s = _Scripted(D.BACKWARD, 3, 2, 10.0, 6, 0, 0, 4)
+    vals = [float(f[0, 0, 0]) for f in s]
+    assert vals == [1, 2, 3, 4, 5, 6] and s.calls == 6               # rewinds at end_frame, keeps counting
+    # STAY: from t=0.2 hold the flow for 0.2 s (frames 2,3 repeat frame 1's flow)
+    s = _Scripted(D.BACKWARD, 3, 2, 10.0, 6, 0, 0, 100, lock_mode=L.STAY, lock_expr_stay=((0.2, 0.2),))
+    vals = [float(next(s)[0, 0, 0]) for _ in range(4)]
+    assert vals == [1, 2, 2, 2]
+    with pytest.raises(IndexError):
+        next(s)   # the reference indexes past its last (start, duration) pair here too (source.py:304-307)
+    # SKIP: while locked the previous flow is reused AND one input flow is consumed
+    s = _Scripted(D.BACKWARD, 3, 2, 10.0, None, 0, 0, 100, lock_mode=L.SKIP, lock_expr_skip=lambda t: 0.15 < t < 0.35)
+    vals = [float(next(s)[0, 0, 0]) for _ in range(5)]
+    assert vals == [1, 2, 2, 2, 5] and s.calls == 5
+    s = _Scripted(D.BACKWARD, 3, 2, 10.0, 2, 0, 0, 100, lock_mode=L.STAY, lock_expr_stay=((0.0, 1.0),))
+    with pytest.raises(RuntimeError):
+        next(s)                                                      # locked before any flow exists
+
+
+def test_hip_flow_source_plumbing_without_gpu():
+    frames = [np.full((4, 6), i, np.uint8) for i in range(5)]
+    with pytest.raises(StopIteration):
+        # provider exhausted inside next(): StopIteration like cv.py:462-463
+        b = HipFlowSource.Builder(ArrayFrameProvider(frames[:1], 10.0), None, direction="forward")
+        b.build()
+        src = HipFlowSource(*b.args(), **b.kwargs())
+        src.next()
+    b = HipFlowSource.Builder(ArrayFrameProvider(frames, 10.0), None, seek_time=0.2)
+    b.build()
+    src = HipFlowSource(*b.args(), **b.kwargs())
+    src.validate()
+    assert src.prev_gray[0, 0] == 2 and src.length == 2              # rewind decoded up to the start frame
+    bgr = np.zeros((2, 2, 3), np.uint8)
+    bgr[..., 2] = 255
+    assert to_grey(bgr)[0, 0] == 76                                   # 0.299 * 255 in cv2's fixed point
+
+
+def test_compositor_surface_and_pickle_without_gpu():
+    comp = HipCompositor.from_args(4, 6, [LayerConfig(0, reset_mode="random", mask_src="border:1")], "#102030")
+    assert comp.background_color == (16, 32, 48) and comp.background.shape == (4, 6, 3)
+    layer = comp.layers[0]
+    assert isinstance(layer, HipMoveReferenceLayer)
+    assert (layer.INDEX_I, layer.INDEX_J, layer.INDEX_ALPHA, layer.INDEX_SOURCE, layer.DEPTH) == (0, 1, 2, 3, 4)
+    assert layer.mask_src.dtype == bool and layer.mask_src.sum() == 4 * 6 - 2 * 4
+
+    class Src:
+        introduction_mask = np.ones((4, 6), bool)
+    comp.set_sources({0: [Src()]})
+    assert len(layer.sources) == 1
+    blob = pickle.dumps(comp)                                         # never touched the GPU
+    back = pickle.loads(blob)
+    assert back.layers[0].sources == [] and back.layers[0].config.reset_mode == "random"
+    with pytest.raises(NotImplementedError):
+        HipCompositor.from_args(4, 6, [LayerConfig(0, classname="sum")])
+    with pytest.raises(ValueError):
+        HipCompositor.from_args(4, 6, [LayerConfig(0, reset_mode="never")])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/transflow"), reason="reference tree not present")
+def test_dropin_install_patches_reference_factories():
+    """transflow_amd.dropin against the importable half of the real reference package."""
+    import sys
+    sys.path.insert(0, "/root/reference")
+    try:
+        from transflow.compositor import Compositor
+        from transflow.compositor.layers.move_reference import MoveReferenceLayer
+        from transflow.config import LayerConfig as RefLayerConfig
+        from transflow.flow.sources.source import FlowSource as RefFlowSource
+
+        from transflow_amd import dropin
+        dropin.install()
+        try:
+            comp = Compositor.from_args(4, 6, [RefLayerConfig(0, reset_mode="random", reset_random_factor=0.5)],
+                                        background_color="#ff8000")
+            assert isinstance(comp, HipCompositor) and comp.layers[0].config.reset_random_factor == 0.5
+            assert comp.background_color == (255, 128, 0)
+            other = Compositor.from_args(4, 6, [RefLayerConfig(0, classname="sum")])
+            assert isinstance(other, Compositor)                     # not ours: the reference's own layers
+            b = RefFlowSource.from_args("clip.mp4", direction=RefFlowSource.Direction.BACKWARD)
+            assert isinstance(b, HipFlowSource.Builder) and b.direction is FlowSource.Direction.BACKWARD
+            with pytest.raises(Exception):
+                RefFlowSource.from_args("clip.flow.zip").build()     # falls through to the reference's archive source
+        finally:
+            dropin.uninstall()
+        assert isinstance(Compositor.from_args(2, 3, [RefLayerConfig(0)]).layers[0], MoveReferenceLayer)
+    finally:
+        sys.path.remove("/root/reference")
+        for m in [m for m in sys.modules if m == "transflow" or m.startswith("transflow.")]:
+            del sys.modules[m]

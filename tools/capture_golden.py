@@ -267,7 +267,31 @@ def capture_multilayer():
     np.savez_compressed(os.path.join(OUT, "remap_multilayer.npz"), **d)
 
 
+MASK_SPECS = ["zeros", "ones", "border:2", "border:3:5", "border:1:2:3:4", "border:10%", "border-left:1",
+              "border-top:25%", "border-right:4", "border-bottom:2", "hline:5", "vline:30%", "circle:40%", "circle:7",
+              "rect:60%", "rect:20:10", "rect:50%:inv", "grid:2:3:4", "border:2:inv", "circle:40%:inv"]
+COLORS = ["#ff8000", "white", "black", "cornflowerblue", "Tomato", "rgb(1, 2, 3)", "(10,20,30)", "0x123456", "abcdef",
+          "rebeccapurple", "grey", "gray", "lime"]
+
+
+def capture_masks():
+    """utils.load_float_mask / load_bool_mask / parse_color outputs for the argument grammar."""
+    from transflow.utils import load_bool_mask, load_float_mask, parse_color
+    d = {"specs": np.array(MASK_SPECS), "colors": np.array(COLORS)}
+    for shape in [(37, 53), (60, 80)]:
+        for i, spec in enumerate(MASK_SPECS):
+            d[f"f_{shape[0]}_{i}"] = np.asarray(load_float_mask(spec, shape, 1))
+            d[f"b_{shape[0]}_{i}"] = np.asarray(load_bool_mask(spec, shape, True))
+    d["none_float"] = load_float_mask(None, (4, 5), 1)
+    d["none_bool"] = load_bool_mask(None, (4, 5), True)
+    d["color_values"] = np.array([parse_color(c) for c in COLORS], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **d)
+
+
 if __name__ == "__main__":
+    capture_masks()
+    if "--masks-only" in sys.argv:
+        sys.exit(0)
     capture_post_process()
     capture_layers()
     capture_known_answers()

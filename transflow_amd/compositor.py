@@ -1,0 +1,196 @@
+"""Compositor backed by libtfhip.so, behind the reference's Compositor surface.
+
+  HipCompositor            <- transflow/compositor/compositor.py:17-53
+  HipMoveReferenceLayer    <- transflow/compositor/layers/move_reference.py:6-14 and its bases
+                              (layer.py:11-55, data.py:6-17, movement.py:10-64, reference.py:31-109)
+
+`pipeline.py` only needs: Compositor.from_args(height, width, layer_configs,
+background_color), set_sources({layer: [PixmapSourceInterface]}), update(flow),
+render() -> uint8 (H, W, 3), `.layers[i].sources`, and a picklable object
+(pipeline.py:225-242, 290-306, 440-455, 518, 565).  `extra/control.py:146-162`
+reads `layer.data` and `layer.INDEX_I/J/ALPHA`.
+
+Device state is created lazily on the first update/render and never pickled:
+__getstate__ downloads `data`/`rgba` into numpy arrays.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .config import LayerConfig
+from .masks import load_bool_mask, load_float_mask, parse_color
+
+
+class HipMoveReferenceLayer:
+    """The default `moveref` layer.  State lives in HBM; `data` / `rgba` are downloaded on
+    access (int32 [H,W,4] = (i, j, alpha, source); uint8 [H,W,4])."""
+
+    DEPTH = 4
+    INDEX_I, INDEX_J, INDEX_ALPHA, INDEX_SOURCE = 0, 1, 2, 3   # data.py:8-12
+
+    def __init__(self, config, height: int, width: int, sources, rng: str = "numpy"):
+        self.config = LayerConfig.from_reference(config)
+        self.height, self.width = int(height), int(width)
+        self.sources = list(sources)
+        shape = (self.height, self.width)
+        self.mask_alpha = load_float_mask(self.config.mask_alpha, shape, 1)            # layer.py:24
+        self.mask_src = load_bool_mask(self.config.mask_src, shape, True)              # movement.py:14
+        self.mask_dst = load_bool_mask(self.config.mask_dst, shape, True)              # movement.py:15
+        self.reset_mask = load_float_mask(self.config.reset_mask, shape, 1)            # reference.py:44
+        if self.config.reset_mode not in ("off", "random", "constant", "linear"):
+            raise ValueError(f"Unknown reset mode {self.config.reset_mode}")           # reference.py:35
+        # "numpy": draw the reset field with numpy.random.random on the host, exactly like
+        # reference.py:59 (same global stream => same frames for the same numpy seed);
+        # "device": counter-based generator on the GPU (no 8 B/px upload)
+        self.rng = rng
+        self.seed = 0
+        self._dev = None
+        self._pending_state = None  # (data, rgba) to upload when the device layer is created
+        self._sources_dirty = False
+
+    # ---- device side -------------------------------------------------------------------
+    def _layer(self):
+        if self._dev is None:
+            from .remap import RemapLayer
+            c = self.config
+            default = lambda a, v: None if np.all(a == v) else a  # noqa: E731  (absent mask == default)
+            self._dev = RemapLayer(
+                self.height, self.width,
+                transparent_pixels_can_move=c.transparent_pixels_can_move,
+                pixels_can_move_to_empty_spot=c.pixels_can_move_to_empty_spot,
+                pixels_can_move_to_filled_spot=c.pixels_can_move_to_filled_spot,
+                moving_pixels_leave_empty_spot=c.moving_pixels_leave_empty_spot,
+                reset_mode=c.reset_mode, reset_random_factor=c.reset_random_factor,
+                reset_constant_step=c.reset_constant_step, reset_linear_factor=c.reset_linear_factor,
+                reset_source=c.reset_source,
+                mask_src=default(self.mask_src, True), mask_dst=default(self.mask_dst, True),
+                mask_alpha=default(self.mask_alpha, 1), reset_mask=default(self.reset_mask, 1))
+            if self._pending_state is not None:          # restored from a checkpoint
+                self._dev.set_state(*self._pending_state)
+                self._pending_state = None
+            elif self.sources:                           # constructor-time sources (reference.py:42)
+                self._sources_dirty = True
+        if self._sources_dirty:
+            self._dev.set_sources([np.asarray(s.introduction_mask, dtype=bool) for s in self.sources])
+            self._sources_dirty = False
+        return self._dev
+
+    def set_sources(self, sources):
+        """reference.py:54-56: remember the sources and write their index where their
+        introduction mask is set (also after a checkpoint restore, as the reference does:
+        pipeline.py:450-455).  Applied to the device state at its next use."""
+        self.sources = list(sources)
+        self._sources_dirty = True
+
+    def update(self, flow):
+        """move_reference.py:12-14: MovementLayer.update, then ReferenceLayer.update."""
+        layer = self._layer()
+        u = None
+        if self.config.reset_mode == "random" and self.rng == "numpy":
+            u = np.random.random(size=(self.height, self.width))                       # reference.py:59
+        layer.update(flow, u, self.seed)
+        for i, source in enumerate(self.sources):                                      # reference.py:94-105
+            layer.gather(i, source.next())
+
+    def render_into(self, comp):
+        self._layer().render(comp)
+
+    @property
+    def data(self) -> np.ndarray:
+        if self._dev is None:
+            if self._pending_state is not None and self._pending_state[0] is not None:
+                return self._pending_state[0]
+            self._layer()
+        return self._dev.get_state()[0]
+
+    @property
+    def rgba(self) -> np.ndarray:
+        if self._dev is None:
+            if self._pending_state is not None and self._pending_state[1] is not None:
+                return self._pending_state[1]
+            self._layer()
+        return self._dev.get_state()[1]
+
+    # ---- pickling (checkpoints, pipeline.py:225-242) --------------------------------------
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in ("_dev", "_pending_state", "sources")}
+        state["sources"] = []   # the pipeline strips sources before pickling (pipeline.py:236-238)
+        if self._dev is not None:
+            state["_saved_state"] = self._dev.get_state()
+        elif self._pending_state is not None:
+            state["_saved_state"] = self._pending_state
+        return state
+
+    def __setstate__(self, state):
+        saved = state.pop("_saved_state", None)
+        self.__dict__.update(state)
+        self._dev = None
+        self._pending_state = saved
+        self._sources_dirty = False
+
+    def close(self):
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
+
+
+LAYER_CLASSES = {"moveref": HipMoveReferenceLayer}
+
+
+class HipCompositor:
+    """Same constructor, methods and attributes as transflow.compositor.Compositor."""
+
+    def __init__(self, height: int, width: int, layers, background_color: str = "#ffffff"):
+        self.height, self.width = int(height), int(width)
+        self.background_color = parse_color(background_color)
+        self.background = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+        self.background[:, :] = self.background_color
+        self.layers = list(layers)
+        self._comp = None
+
+    def _image(self):
+        if self._comp is None:
+            from .remap import CompImage
+            self._comp = CompImage(self.height, self.width, self.background_color)
+        return self._comp
+
+    def update(self, flow):
+        for layer in self.layers:
+            layer.update(flow)
+
+    def render(self) -> np.ndarray:
+        """compositor.py:31-40: background, then every layer's opaque pixels in order."""
+        comp = self._image()
+        comp.begin()
+        for layer in self.layers:
+            layer.render_into(comp)
+        return comp.download()
+
+    @classmethod
+    def from_args(cls, height: int, width: int, layer_configs, background_color: str = "#ffffff", rng: str = "numpy"):
+        layers = []
+        for config in layer_configs:
+            classname = getattr(config, "classname", "moveref")
+            if classname not in LAYER_CLASSES:
+                # static / sum / introduction layers: SURVEY.md §8(f) N2, not built yet
+                raise NotImplementedError(f"layer class {classname!r} is not implemented by transflow_amd yet")
+            layers.append(LAYER_CLASSES[classname](config, height, width, [], rng=rng))
+        return cls(height, width, layers, background_color=background_color)
+
+    def set_sources(self, pixmap_interfaces: dict):
+        for i, layer in enumerate(self.layers):
+            layer.set_sources(pixmap_interfaces.get(i, []))
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k != "_comp"}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._comp = None
+
+    def close(self):
+        for layer in self.layers:
+            layer.close()
+        if self._comp is not None:
+            self._comp.close()
+            self._comp = None

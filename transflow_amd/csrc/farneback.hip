@@ -24,7 +24,10 @@
 // All stages are HBM-bound (<= ~60 flop/B); MFMA is not applicable.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
 
 #include "common.h"
 
@@ -78,7 +81,10 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     uint8_t *sS = s_raw;                                                // [LH][pitch] source bytes
     float *sR = reinterpret_cast<float *>(s_raw + (size_t)tl.LH * tl.pitch); // [LH][2*TWo] row-pass values
+    float *sK = sR + (size_t)tl.LH * 2 * tl.TWo;                        // [ksz] blur taps (LDS broadcast reads)
     const int r = ksz >> 1;
+    for (int i = threadIdx.x; i < ksz; i += blockDim.x)
+        sK[i] = kern[i];
     const int pi = blockIdx.z;
     const int2 pr = pairs[pi >> 1];
     const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
@@ -98,28 +104,37 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     __syncthreads();
     // phase 2: row pass at the needed columns.  With many staged rows the lanes walk rows
     // (conflict-free byte reads); with few (small kernels) they walk output columns.
-    const int no = 2 * ndx;
-    const int ostep = tl.same_size ? 2 : 1; // a copy-sized level only needs column sx
+    // A copy-sized level only needs column sx of each output (even slots).
+    const int ostep = tl.same_size ? 2 : 1;
+    const int no = 2 * ndx / ostep;
     const bool lanes_on_rows = nrows >= 48;
     const int n_a = lanes_on_rows ? nrows : no, n_b = lanes_on_rows ? no : nrows;
+    const float k0 = sK[0], kc = sK[r], kc1 = ksz >= 3 ? sK[r + 1] : 0.f, kc2 = ksz >= 5 ? sK[r + 2] : 0.f;
     for (int b_ = wave; b_ < n_b; b_ += 4) {
         for (int a_ = lane; a_ < n_a; a_ += 64) {
-            const int ry = lanes_on_rows ? a_ : b_, o = lanes_on_rows ? b_ : a_;
-            if (ostep == 2 && (o & 1))
-                continue;
+            const int ry = lanes_on_rows ? a_ : b_, o = (lanes_on_rows ? b_ : a_) * ostep;
             int sx = xofs[dx0 + (o >> 1)];
             int col = (o & 1) ? min(sx + 1, W - 1) : sx;
             const uint8_t *p = sS + ry * tl.pitch + (col - x_lo); // tap i sits at p[i - r]
             float acc;
             if (ksz == 3) {
-                acc = (float)p[0] * kern[1] + ((float)p[-1] + (float)p[1]) * kern[2];
+                acc = (float)p[0] * kc + ((float)p[-1] + (float)p[1]) * kc1;
             } else if (ksz == 5) {
-                acc = (float)p[0] * kern[2] + ((float)p[-1] + (float)p[1]) * kern[3] +
-                      ((float)p[-2] + (float)p[2]) * kern[4];
+                acc = (float)p[0] * kc + ((float)p[-1] + (float)p[1]) * kc1 + ((float)p[-2] + (float)p[2]) * kc2;
             } else {
-                acc = kern[0] * (float)p[-r];
-                for (int i = 1; i < ksz; i++)
-                    acc += kern[i] * (float)p[i - r];
+                const uint8_t *q = p - r;
+                acc = k0 * (float)q[0];
+                int i = 1;
+                for (; i + 3 < ksz; i += 4) { // same left-to-right order, four taps per trip
+                    float t0 = sK[i] * (float)q[i], t1 = sK[i + 1] * (float)q[i + 1];
+                    float t2 = sK[i + 2] * (float)q[i + 2], t3 = sK[i + 3] * (float)q[i + 3];
+                    acc += t0;
+                    acc += t1;
+                    acc += t2;
+                    acc += t3;
+                }
+                for (; i < ksz; i++)
+                    acc += sK[i] * (float)q[i];
             }
             sR[ry * (2 * tl.TWo) + o] = acc;
         }
@@ -137,23 +152,23 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
         const float *c0 = sR + row0 * (2 * tl.TWo) + 2 * tx;
         const float *c1 = sR + row1 * (2 * tl.TWo) + 2 * tx;
         const int st = 2 * tl.TWo;
-        float v00 = kern[r] * c0[0];
+        float v00 = kc * c0[0];
         for (int i = 1; i <= r; i++)
-            v00 += kern[r + i] * (c0[i * st] + c0[-i * st]);
+            v00 += sK[r + i] * (c0[i * st] + c0[-i * st]);
         float out;
         if (tl.same_size) {
             out = v00;
         } else {
-            float v01 = kern[r] * c0[1];
+            float v01 = kc * c0[1];
             for (int i = 1; i <= r; i++)
-                v01 += kern[r + i] * (c0[i * st + 1] + c0[-i * st + 1]);
+                v01 += sK[r + i] * (c0[i * st + 1] + c0[-i * st + 1]);
             float v10 = v00, v11 = v01;
             if (row1 != row0) {
-                v10 = kern[r] * c1[0];
-                v11 = kern[r] * c1[1];
+                v10 = kc * c1[0];
+                v11 = kc * c1[1];
                 for (int i = 1; i <= r; i++) {
-                    v10 += kern[r + i] * (c1[i * st] + c1[-i * st]);
-                    v11 += kern[r + i] * (c1[i * st + 1] + c1[-i * st + 1]);
+                    v10 += sK[r + i] * (c1[i * st] + c1[-i * st]);
+                    v11 += sK[r + i] * (c1[i * st + 1] + c1[-i * st + 1]);
                 }
             }
             float fx = xfrac[dx], fy = yfrac[dy];
@@ -810,13 +825,28 @@ struct tf_fb {
     }
 };
 
+// Profiler labels: with TF_PROF_LEVELS=1 in the environment every Farneback launch is
+// labelled with its pyramid level ("fb_polyexp.k2"), otherwise by kernel only.
+static const char *lvl_name(const char *base, int k)
+{
+    static const bool per_level = getenv("TF_PROF_LEVELS") && atoi(getenv("TF_PROF_LEVELS")) != 0;
+    if (!per_level || k < 0)
+        return base;
+    static std::map<std::string, std::string> names;
+    std::string key = std::string(base) + ".k" + std::to_string(k);
+    auto it = names.find(key);
+    if (it == names.end())
+        it = names.emplace(key, key).first;
+    return it->second.c_str();
+}
+
 static int fb_level_image(tf_fb *fb, int k, int n_pairs)
 {
     Level &L = *fb->lv[k];
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
-    size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float);
-    return launch("fb_level_image", k_level_image, grid, dim3(256), smem, (const uint8_t *)fb->frames.as<uint8_t>(),
+    size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float) + (size_t)L.ksz * sizeof(float);
+    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem, (const uint8_t *)fb->frames.as<uint8_t>(),
                   (const int2 *)fb->pairs.as<int2>(), fb->img.as<float>(), fb->W, fb->H, L.W, L.H,
                   (const int *)L.img_lerp.xofs.as<int>(), (const float *)L.img_lerp.xfrac.as<float>(),
                   (const int *)L.img_lerp.yofs.as<int>(), (const float *)L.img_lerp.yfrac.as<float>(),
@@ -851,7 +881,7 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
         t.pitch = (t.LW + 3) & ~3;
         if (((t.pitch / 4) & 1) == 0)
             t.pitch += 4;
-        size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float);
+        size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float) + (size_t)ksz * sizeof(float);
         if (smem <= 60 * 1024 || (t.TWo <= 2 && t.THo <= 1))
             break;
         if (t.THo > 1 && (t.THo >= t.TWo / 4 || t.TWo <= 2))
@@ -862,24 +892,24 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
     return t;
 }
 
-static int fb_polyexp(tf_fb *fb, int w, int h, int n_images)
+static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
 {
     const int n = fb->pc.n;
     dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
     size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
-    return launch("fb_polyexp", k_polyexp, grid, dim3(256), smem, (const float *)fb->img.as<float>(),
+    return launch(lvl_name("fb_polyexp", k), k_polyexp, grid, dim3(256), smem, (const float *)fb->img.as<float>(),
                   fb->R.as<float>(), w, h, fb->pc);
 }
 
-static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf)
+static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
     dim3 grid(cdiv(w, 128), h, n_pairs);
-    return launch("fb_update_matrices", k_update_matrices, grid, dim3(128), 0, (const float *)fb->R.as<float>(),
+    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(128), 0, (const float *)fb->R.as<float>(),
                   fb->M[mbuf].as<float>(), w, h, fi);
 }
 
 template <int M>
-static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out, double scale)
+static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out, double scale, int k)
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
@@ -888,24 +918,24 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf
     long segs_wanted = std::max(1l, 4096 / std::max(1l, (long)strips * n_pairs));
     int seg = (int)std::min<long>(256, std::max<long>(32, (h + segs_wanted - 1) / segs_wanted));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
-    return launch("fb_blur_solve", k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M[mbuf_in].as<float>(),
+    return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M[mbuf_in].as<float>(),
                   flow_out, w, h, scale, seg);
 }
 
-static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out)
+static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out, int k = -1)
 {
     const int m = fb->prm.winsize / 2;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     switch (m) {
-    case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 3: return launch_blur_solve_wave<3>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 4: return launch_blur_solve_wave<4>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 5: return launch_blur_solve_wave<5>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 6: return launch_blur_solve_wave<6>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 7: return launch_blur_solve_wave<7>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 8: return launch_blur_solve_wave<8>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 10: return launch_blur_solve_wave<10>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
-    case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, mbuf_in, flow_out, scale);
+    case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 3: return launch_blur_solve_wave<3>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 4: return launch_blur_solve_wave<4>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 5: return launch_blur_solve_wave<5>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 6: return launch_blur_solve_wave<6>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 7: return launch_blur_solve_wave<7>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 8: return launch_blur_solve_wave<8>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 10: return launch_blur_solve_wave<10>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
     default: break;
     }
     // any other window: the generic block-per-strip kernel
@@ -986,7 +1016,8 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             return fail(rc);
         L->tile = choose_tile(width, height, L->W, L->H, L->ksz);
         {
-            size_t smem = (size_t)L->tile.LH * L->tile.pitch + (size_t)L->tile.LH * 2 * L->tile.TWo * sizeof(float);
+            size_t smem = (size_t)L->tile.LH * L->tile.pitch + (size_t)L->tile.LH * 2 * L->tile.TWo * sizeof(float) +
+                          (size_t)L->ksz * sizeof(float);
             if (smem > 64 * 1024)
                 return fail(set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: level %d needs %zu bytes of LDS per tile "
                                                           "(blur kernel %d taps)", k, smem, L->ksz));
@@ -1064,7 +1095,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
         TF_TRY(fb_level_image(fb, k, n_pairs));
-        TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2));
+        TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
         FlowInit fi;
         memset(&fi, 0, sizeof(fi));
         if (k < fb->K) {
@@ -1079,15 +1110,15 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             fi.yfrac = L.flow_lerp.yfrac.as<float>();
             fi.mul = (float)(1. / fb->prm.pyr_scale);
         }
-        TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0));
+        TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0, k));
         FlowInit fl;
         memset(&fl, 0, sizeof(fl));
         fl.mode = 2;
         fl.src = fb->lflow[cur].as<float2>();
         for (int i = 0; i < fb->prm.iterations; i++) {
-            TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, 0, fb->lflow[cur].as<float2>()));
+            TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, 0, fb->lflow[cur].as<float2>(), k));
             if (i < fb->prm.iterations - 1) // M is a pure function of (R0, R1, flow): rebuild it in place
-                TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0));
+                TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0, k));
         }
         fb->final_buf = cur;
         cur ^= 1;

@@ -1,0 +1,439 @@
+"""Flow sources backed by libtfhip.so, behind the reference's FlowSource surface.
+
+`FlowSource` mirrors transflow/flow/sources/source.py:17-415 (Direction, LockMode,
+Builder with its seek/duration/repeat/lock arithmetic, the iterator protocol and
+post_process); `HipFlowSource` mirrors CvFlowSource's Farnebäck branch
+(transflow/flow/sources/cv.py:366-524): frames come from a frame provider, the
+flow from the GPU.  Items yielded are numpy float32 arrays of shape (H, W, 2),
+picklable, exactly what pipeline.py:85-86 puts on its queue.
+
+No HIP call happens before Builder.__enter__/build(): the reference forks the
+flow source into a child process (pipeline.py:56-64).
+"""
+from __future__ import annotations
+
+import enum
+import logging
+import os
+import warnings
+from typing import Callable
+
+import numpy as np
+
+from .config import FlowConfig
+
+logger = logging.getLogger(__name__)
+
+
+class FlowSource:
+    """Base class; same constructor, attributes and iteration protocol as the reference's."""
+
+    @enum.unique
+    class Direction(enum.Enum):
+        FORWARD = 0   # past to present
+        BACKWARD = 1  # present to past
+
+        @classmethod
+        def from_arg(cls, arg):
+            if arg is None:
+                return FlowSource.Direction.FORWARD          # source.py:26-28
+            if isinstance(arg, FlowSource.Direction):
+                return arg
+            if isinstance(arg, enum.Enum) and arg.name in ("FORWARD", "BACKWARD"):
+                return FlowSource.Direction[arg.name]        # the reference's own enum
+            if isinstance(arg, int):
+                return FlowSource.Direction(arg)
+            if arg in ("forward", "backward"):
+                return FlowSource.Direction[arg.upper()]
+            raise ValueError(f"Invalid Flow Direction: {arg}")
+
+    @enum.unique
+    class LockMode(enum.Enum):
+        STAY = 0
+        SKIP = 1
+
+        @classmethod
+        def from_arg(cls, arg):
+            if arg is None:
+                return FlowSource.LockMode.STAY
+            if isinstance(arg, FlowSource.LockMode):
+                return arg
+            if isinstance(arg, enum.Enum) and arg.name in ("STAY", "SKIP"):
+                return FlowSource.LockMode[arg.name]
+            if isinstance(arg, int):
+                return FlowSource.LockMode(arg)
+            if arg in ("stay", "skip"):
+                return FlowSource.LockMode[arg.upper()]
+            raise ValueError(f"Invalid Lock Mode: {arg}")
+
+    class Builder:
+        """Context manager that resolves timing and instantiates the source
+        (source.py:58-209)."""
+
+        def __init__(self, direction="backward", mask_path=None, kernel_path=None, flow_filters=None,
+                     seek_ckpt=None, seek_time=None, duration_time=None, repeat: int = 1, lock_expr=None,
+                     lock_mode="stay"):
+            self.direction = FlowSource.Direction.from_arg(direction)
+            self.width: int | None = None
+            self.height: int | None = None
+            self.framerate: float = 30
+            self.mask_path, self.mask = mask_path, None
+            self.kernel_path, self.kernel = kernel_path, None
+            self.flow_filters: list = []
+            self.flow_filters_string = flow_filters
+            self.seek_ckpt, self.seek_time, self.duration_time = seek_ckpt, seek_time, duration_time
+            self.is_stream = False
+            self.base_length: int | None = None
+            self.length: int | None = None
+            self.start_frame = self.ckpt_start_frame = self.end_frame = 0
+            self.repeat = repeat
+            self.lock_expr_string = lock_expr
+            self.lock_expr_stay = None
+            self.lock_expr_skip: Callable[[float], bool] | None = None
+            self.lock_mode = FlowSource.LockMode.from_arg(lock_mode)
+            self.source: FlowSource | None = None
+
+        @property
+        def cls(self):
+            return FlowSource
+
+        def args(self) -> list:
+            return [self.direction, self.width, self.height, self.framerate, self.length, self.start_frame,
+                    self.ckpt_start_frame, self.end_frame]
+
+        def kwargs(self) -> dict:
+            return {"mask": self.mask, "kernel": self.kernel, "flow_filters": self.flow_filters,
+                    "lock_mode": self.lock_mode, "lock_expr_stay": self.lock_expr_stay,
+                    "lock_expr_skip": self.lock_expr_skip}
+
+        def build(self):
+            if self.mask_path is not None or self.kernel_path is not None or self.flow_filters_string is not None:
+                # flow mask / convolution kernel / filters are not on the GPU yet;
+                # there is deliberately no host fallback
+                raise NotImplementedError("flow mask, kernel and filters are not implemented by transflow_amd yet")
+            if self.lock_expr_string is not None:                                       # source.py:133-139
+                if self.lock_mode == FlowSource.LockMode.STAY:
+                    text = self.lock_expr_string if "(" in self.lock_expr_string else f"({self.lock_expr_string})"
+                    self.lock_expr_stay = tuple(eval(f"[{text},]"))
+                else:
+                    self.lock_expr_skip = eval("lambda t: " + self.lock_expr_string)
+            if self.base_length is not None and self.base_length <= 0:                  # :151-152
+                self.base_length = None
+            self.is_stream = self.base_length is None
+            if self.is_stream and self.repeat > 1:
+                warnings.warn("Flow source is a stream, cannot repeat it!")
+                self.repeat = 1
+            if self.is_stream and self.seek_time is not None and self.seek_time > 0:
+                warnings.warn("Flow source is a stream, seek time is ignored!")
+                self.seek_time = None
+            start = int(self.seek_time * self.framerate) if (self.seek_time is not None and not self.is_stream) else 0
+            self.start_frame = start                                                    # :164-168
+            if self.duration_time is not None:                                          # :170-175
+                self.end_frame = start + int(round(self.duration_time * self.framerate, 3))
+                if self.base_length is not None:
+                    self.end_frame = min(self.end_frame, self.base_length)
+            elif self.base_length is not None:
+                self.end_frame = self.base_length
+            if self.repeat == 0:                                                        # :178-183
+                self.length = None
+            elif self.is_stream:
+                self.length = self.end_frame
+            else:
+                self.length = self.repeat * (self.end_frame - self.start_frame)
+            if (self.length is not None and self.lock_mode == FlowSource.LockMode.STAY
+                    and self.lock_expr_stay is not None):                                # :186-188
+                for _, lock_duration in self.lock_expr_stay:
+                    self.length += int(lock_duration * self.framerate)
+            self.ckpt_start_frame = start                                               # :190-197
+            if self.seek_ckpt is not None:
+                self.ckpt_start_frame += self.seek_ckpt % (self.end_frame - self.start_frame)
+
+        def __enter__(self):
+            self.build()
+            self.source = self.cls(*self.args(), **self.kwargs())
+            self.source.validate()
+            logger.debug("Built '%s'", self.source.__class__.__name__)
+            return self.source
+
+        def __exit__(self, exc_type, exc_value, exc_traceback):
+            if self.source is not None:
+                self.source.close()
+
+    def __init__(self, direction, width: int, height: int, framerate: float, length, start_frame: int,
+                 ckpt_start_frame: int, end_frame: int, mask=None, kernel=None, flow_filters=(),
+                 lock_mode=None, lock_expr_stay=None, lock_expr_skip=None):
+        self.direction = FlowSource.Direction.from_arg(direction)
+        self.width, self.height, self.framerate = width, height, framerate
+        self.length = length
+        self.end_frame = end_frame
+        self.mask, self.kernel, self.flow_filters = mask, kernel, list(flow_filters)
+        if self.mask is not None or self.kernel is not None or self.flow_filters:
+            raise NotImplementedError("flow mask, kernel and filters are not implemented by transflow_amd yet")
+        self.lock_mode = FlowSource.LockMode.from_arg(lock_mode)
+        self.lock_expr_stay, self.lock_expr_skip = lock_expr_stay, lock_expr_skip
+        self.input_frame_index = 0
+        self.output_frame_index = 0
+        self.prev_flow = None
+        self.lock_start: float | None = None
+        self.lock_expr_stay_index = 0
+        self._pp = None  # device handle used by post_process, created on first use
+        self.start_frame = ckpt_start_frame      # source.py:246-248: the first rewind honours a checkpoint seek
+        self.rewind()
+        self.start_frame = start_frame
+        # source.py:250-263 builds per-pixel clip tables on the host (a 1.2 s Python loop at
+        # 1080p); the kernels derive the bounds from the pixel index instead
+
+    def __len__(self):
+        return self.length
+
+    def validate(self):
+        checks = (("direction", (FlowSource.Direction,)), ("width", (int,)), ("height", (int,)),
+                  ("framerate", (float,)), ("length", (int, type(None))), ("start_frame", (int,)),
+                  ("end_frame", (int,)), ("flow_filters", (list,)), ("lock_mode", (FlowSource.LockMode,)),
+                  ("lock_expr_stay", (tuple, type(None))))
+        for attr, types in checks:                                                       # source.py:268-284
+            if not isinstance(getattr(self, attr), types):
+                raise ValueError(f"Attribute {attr} has incorrect type {type(getattr(self, attr))}")
+
+    @property
+    def t(self) -> float:
+        return 0 if self.framerate is None else self.output_frame_index / self.framerate
+
+    def read_next_flow(self):
+        if self.input_frame_index == self.end_frame:
+            self.rewind()
+        flow = self.next()
+        self.input_frame_index += 1
+        return flow
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        """source.py:293-321."""
+        if self.length is not None and self.output_frame_index >= self.length:
+            raise StopIteration
+        locked = False
+        if self.lock_mode == FlowSource.LockMode.STAY and self.lock_expr_stay is not None:
+            was_locked = self.lock_start is not None
+            if was_locked:
+                locked = (self.t - self.lock_start) < self.lock_expr_stay[self.lock_expr_stay_index][1]
+                if not locked:
+                    self.lock_expr_stay_index += 1
+                    self.lock_start = None
+            if (not was_locked) or (not locked):
+                locked = self.t >= self.lock_expr_stay[self.lock_expr_stay_index][0]
+                if locked:
+                    self.lock_start = self.t
+        elif self.lock_mode == FlowSource.LockMode.SKIP and self.lock_expr_skip is not None:
+            locked = self.lock_expr_skip(self.t)
+        if locked:
+            if self.prev_flow is None:
+                raise RuntimeError("Flow is locked but has not been initialized. Maybe lock the flow later?")
+            flow = self.prev_flow
+        else:
+            flow = self.read_next_flow()
+        self.prev_flow = flow
+        if locked and self.lock_mode == FlowSource.LockMode.SKIP:
+            self.read_next_flow()
+        self.output_frame_index += 1
+        return self.post_process(flow)
+
+    def next(self):
+        raise NotImplementedError()
+
+    def rewind(self):
+        self.input_frame_index = self.start_frame
+
+    def post_process(self, raw):
+        """source.py:337-363 on the GPU (tf_fb_post_process_host): FORWARD inverts the push
+        field with last-write-wins, both directions clip to the frame.  In place, like the
+        reference (so `prev_flow` sees the processed array, source.py:317)."""
+        flow = raw
+        if not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.flags.c_contiguous):
+            flow = np.ascontiguousarray(raw, dtype=np.float32)
+        if self._pp is None:
+            from .farneback import Farneback
+            self._pp = Farneback(self.width, self.height, levels=0)
+        self._pp.post_process_host(flow, self.direction.value)
+        return flow
+
+    def close(self):
+        if self._pp is not None:
+            self._pp.close()
+            self._pp = None
+
+
+class ArrayFrameProvider:
+    """Frames held in memory: a sequence of uint8 arrays, grey (H, W) or BGR (H, W, 3)."""
+
+    def __init__(self, frames, framerate: float = 30.0):
+        self.frames = frames
+        self.framerate = float(framerate)
+        first = np.asarray(frames[0])
+        self.height, self.width = first.shape[:2]
+        self.frame_count = len(frames)
+        self.pos = 0
+
+    def seek_start(self):
+        self.pos = 0
+
+    def read(self):
+        if self.pos >= self.frame_count:
+            return None
+        f = np.asarray(self.frames[self.pos])
+        self.pos += 1
+        return f
+
+    def release(self):
+        pass
+
+
+class Cv2FrameProvider:
+    """Video decode through cv2.VideoCapture, as CvFlowSource does (cv.py:416-429, 447-466).
+    Decode stays on the CPU and is out of this backend's scope; it needs opencv-python."""
+
+    def __init__(self, file: str, size=None):
+        import re
+
+        import cv2
+        self.cv2 = cv2
+        self.capture = cv2.VideoCapture(int(file)) if re.match(r"\d+", file) else cv2.VideoCapture(file)
+        if size is not None:
+            self.capture.set(cv2.CAP_PROP_FRAME_WIDTH, size[0])
+            self.capture.set(cv2.CAP_PROP_FRAME_HEIGHT, size[1])
+        self.width = int(self.capture.get(cv2.CAP_PROP_FRAME_WIDTH))
+        self.height = int(self.capture.get(cv2.CAP_PROP_FRAME_HEIGHT))
+        self.framerate = float(self.capture.get(cv2.CAP_PROP_FPS))
+        self.frame_count = int(self.capture.get(cv2.CAP_PROP_FRAME_COUNT))
+
+    def seek_start(self):
+        self.capture.set(self.cv2.CAP_PROP_POS_MSEC, 0)
+
+    def read(self):
+        ok, frame = self.capture.read()
+        if not ok or frame is None:
+            return None
+        return self.cv2.resize(frame, dsize=(self.width, self.height), interpolation=self.cv2.INTER_NEAREST)
+
+    def release(self):
+        self.capture.release()
+
+
+def to_grey(frame: np.ndarray) -> np.ndarray:
+    """Grey uint8 (H, W).  BGR input is converted with cv2's COLOR_BGR2GRAY fixed-point
+    weights ((B*1868 + G*9617 + R*4899 + 8192) >> 14) -- SURVEY §8(f) N4 keeps this step on
+    the host for now (cv.py:463)."""
+    a = np.asarray(frame)
+    if a.ndim == 2:
+        return a if a.dtype == np.uint8 else a.astype(np.uint8)
+    b, g, r = (a[:, :, i].astype(np.uint32) for i in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+class HipFlowSource(FlowSource):
+    """CvFlowSource's Farnebäck branch on the GPU (cv.py:434-521)."""
+
+    class Builder(FlowSource.Builder):
+
+        def __init__(self, provider, config=None, size=None, device: int | None = None, **kwargs):
+            super().__init__(**kwargs)
+            self.provider_arg, self.size, self.device = provider, size, device
+            self.config = FlowConfig.from_reference(config)
+            self.provider = None
+
+        @property
+        def cls(self):
+            return HipFlowSource
+
+        def build(self):
+            p = self.provider_arg
+            self.provider = Cv2FrameProvider(p, self.size) if isinstance(p, str) else p
+            self.width, self.height = int(self.provider.width), int(self.provider.height)
+            self.framerate = float(self.provider.framerate)
+            self.base_length = int(self.provider.frame_count) - 1                        # cv.py:428
+            super().build()
+
+        def args(self):
+            return [self.provider, self.config, *FlowSource.Builder.args(self)]
+
+        def kwargs(self):
+            kw = super().kwargs()
+            kw["device"] = self.device
+            return kw
+
+    def __init__(self, provider, config: FlowConfig, *args, device: int | None = None, **kwargs):
+        self.config = config
+        self.provider = provider
+        self.device = device
+        self.prev_gray = None
+        self._fb = None
+        FlowSource.__init__(self, *args, **kwargs)
+
+    def validate(self):
+        super().validate()
+        if not isinstance(self.config, FlowConfig):
+            raise ValueError("Attribute config has incorrect type")
+
+    def _handle(self):
+        if self._fb is None:
+            from .farneback import Farneback
+            self._fb = Farneback(self.width, self.height, device=self.device, **self.config.fb_kwargs())
+            self._pp = self._fb  # one handle serves both calls
+        return self._fb
+
+    def rewind(self):
+        """cv.py:447-458: decode from the start up to the start frame, keep it as `prev`."""
+        FlowSource.rewind(self)
+        self.provider.seek_start()
+        frame = None
+        for i in range(self.input_frame_index + 1):
+            frame = self.provider.read()
+            if frame is None:
+                raise RuntimeError(f"An error occurred while reading frame at index {i}")
+        self.prev_gray = to_grey(frame)
+        self.prev_flow = None
+
+    def next(self):
+        """cv.py:460-490: (prev, next) ordered by direction, one Farnebäck call."""
+        frame = self.provider.read()
+        if frame is None:
+            raise StopIteration
+        gray = to_grey(frame)
+        if self.direction == FlowSource.Direction.FORWARD:
+            left, right = self.prev_gray, gray
+        else:
+            left, right = gray, self.prev_gray
+        if left is None or right is None:
+            raise ValueError("Missing reference frames")
+        flow = self._handle().calc(left, right)
+        self.prev_gray = gray
+        return flow
+
+    def close(self):
+        if self._fb is not None:
+            self._fb.close()
+            self._fb = None
+            self._pp = None
+        else:
+            FlowSource.close(self)
+        self.provider.release()
+
+    @classmethod
+    def from_args(cls, flow_path, use_mvs: bool = False, mask_path=None, kernel_path=None, cv_config=None,
+                  flow_filters=None, size=None, direction=None, seek_ckpt=None, seek_time=None,
+                  duration_time=None, repeat: int = 1, lock_expr=None, lock_mode="stay"):
+        """Same signature as FlowSource.from_args (source.py:365-411); `flow_path` may also be
+        a frame provider object.  Archive and motion-vector sources are not this backend's."""
+        if use_mvs or (isinstance(flow_path, str) and flow_path.endswith(".flow.zip")):
+            raise NotImplementedError("transflow_amd replaces the cv2 Farneback source only")
+        if isinstance(cv_config, str):
+            config = FlowConfig.from_file(cv_config) if os.path.isfile(cv_config) else FlowConfig()
+        else:
+            config = FlowConfig.from_reference(cv_config)
+        if isinstance(flow_path, str) and "::" in flow_path:
+            flow_path = flow_path.split("::")[1]
+        return cls.Builder(flow_path, config, size, direction=direction, mask_path=mask_path,
+                           kernel_path=kernel_path, flow_filters=flow_filters, seek_ckpt=seek_ckpt,
+                           seek_time=seek_time, duration_time=duration_time, repeat=repeat, lock_expr=lock_expr,
+                           lock_mode=lock_mode)
