@@ -66,23 +66,46 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // different LDS banks (pitch/4 is odd).
 // ---------------------------------------------------------------------------------
 struct ImgTile {
-    int TWo, THo;   // output tile
-    int LW, LH;     // source columns / rows staged per tile (upper bounds)
-    int pitch;      // bytes per staged source row, multiple of 4 with pitch/4 odd
-    int same_size;  // level size == frame size: resize is a copy
+    int TWo, THo;           // output tile (TWo a power of two)
+    int LW, LH;             // source columns / rows staged per tile (upper bounds)
+    int pitch;              // bytes per staged source row, multiple of 4 with pitch/4 odd
+    int same_size;          // level size == frame size: resize is a copy
+    double scale_x, scale_y; // resize.cpp's 1/(dst/src) per axis
 };
+
+// resize.cpp's INTER_LINEAR source coordinate for destination index d (the statement order
+// of the host's make_lerp: double product and difference, one rounding each, then float).
+__device__ __forceinline__ int lerp_coord(int d, double scale, int src, bool zero_at_edges, float &frac)
+{
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (zero_at_edges) {
+        if (s < 0) {
+            f = 0.f;
+            s = 0;
+        }
+        if (s >= src - 1) {
+            f = 0.f;
+            s = src - 1;
+        }
+    }
+    frac = f;
+    return s;
+}
 
 __global__ void __launch_bounds__(256)
 k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W,
-              int H, int Wk, int Hk, const int *__restrict__ xofs, const float *__restrict__ xfrac,
-              const int *__restrict__ yofs, const float *__restrict__ yfrac, const float *__restrict__ kern, int ksz,
-              ImgTile tl)
+              int H, int Wk, int Hk, const float *__restrict__ kern, int ksz, ImgTile tl)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
-    uint8_t *sS = s_raw;                                                // [LH][pitch] source bytes
+    uint8_t *sS = s_raw;                                                     // [LH][pitch] source bytes
     float *sR = reinterpret_cast<float *>(s_raw + (size_t)tl.LH * tl.pitch); // [LH][2*TWo] row-pass values
-    float *sK = sR + (size_t)tl.LH * 2 * tl.TWo;                        // [ksz] blur taps (LDS broadcast reads)
+    float *sK = sR + (size_t)tl.LH * 2 * tl.TWo;                             // [ksz] blur taps
+    __shared__ int sX[128], sY[32];     // source column / row of each output column / row of the tile
+    __shared__ float sFx[128], sFy[32]; // and the lerp fractions
     const int r = ksz >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < ksz; i += blockDim.x)
         sK[i] = kern[i];
     const int pi = blockIdx.z;
@@ -90,19 +113,77 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
     const int dx0 = blockIdx.x * tl.TWo, dy0 = blockIdx.y * tl.THo;
     const int ndx = min(tl.TWo, Wk - dx0), ndy = min(tl.THo, Hk - dy0);
-    const int x_lo = xofs[dx0] - r, x_hi = min(xofs[dx0 + ndx - 1] + 1, W - 1) + r;
-    const int y_lo = clampi(yofs[dy0], 0, H - 1) - r, y_hi = clampi(yofs[dy0 + ndy - 1] + 1, 0, H - 1) + r;
+    float ftmp;
+    int sx_first, sx_last, sy_first, sy_last;
+    if (tl.same_size) { // resize of equal sizes is a copy: source == destination coordinates
+        sx_first = dx0;
+        sx_last = dx0 + ndx - 1;
+        sy_first = dy0;
+        sy_last = dy0 + ndy - 1;
+    } else {
+        sx_first = lerp_coord(dx0, tl.scale_x, W, true, ftmp);
+        sx_last = lerp_coord(dx0 + ndx - 1, tl.scale_x, W, true, ftmp);
+        sy_first = lerp_coord(dy0, tl.scale_y, H, false, ftmp);
+        sy_last = lerp_coord(dy0 + ndy - 1, tl.scale_y, H, false, ftmp);
+        if (threadIdx.x < ndx) {
+            float f;
+            sX[threadIdx.x] = lerp_coord(dx0 + threadIdx.x, tl.scale_x, W, true, f);
+            sFx[threadIdx.x] = f;
+        } else if (threadIdx.x >= 128 && threadIdx.x - 128 < ndy) {
+            float f;
+            sY[threadIdx.x - 128] = lerp_coord(dy0 + threadIdx.x - 128, tl.scale_y, H, false, f);
+            sFy[threadIdx.x - 128] = f;
+        }
+    }
+    // staged columns start at a multiple of 4 so interior tiles can be copied as dwords
+    const int x_lo = (sx_first - r) & ~3, x_hi = min(sx_last + 1, W - 1) + r;
+    const int y_lo = clampi(sy_first, 0, H - 1) - r, y_hi = clampi(sy_last + 1, 0, H - 1) + r;
     const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // phase 1: stage the source region; a wave copies one row at a time, lanes along x
-    for (int ry = wave; ry < nrows; ry += 4) {
-        const uint8_t *srow = src + (size_t)reflect101(y_lo + ry, H) * W;
-        uint8_t *drow = sS + ry * tl.pitch;
-        for (int cx = lane; cx < ncols; cx += 64)
-            drow[cx] = srow[reflect101(x_lo + cx, W)];
+    // ---- phase 1: stage the source region.  Each wave owns rows wave, wave+4, ...; loads are
+    // issued eight rows at a time so their latencies overlap.
+    constexpr int U = 8;
+    const bool dwords = (W & 3) == 0 && x_lo >= 0 && x_lo + ((ncols + 3) & ~3) <= W;
+    if (dwords) {
+        const int nq = (ncols + 3) >> 2;
+        for (int c = lane; c < nq; c += 64) {
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101(y_lo + ry, H) * W + x_lo + 4 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        *reinterpret_cast<uint32_t *>(sS + ry * tl.pitch + 4 * c) = v[u];
+                }
+            }
+        }
+    } else {
+        for (int c = lane; c < ncols; c += 64) {
+            const int x = reflect101(x_lo + c, W);
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint8_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = src[(size_t)reflect101(y_lo + ry, H) * W + x];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        sS[ry * tl.pitch + c] = v[u];
+                }
+            }
+        }
     }
     __syncthreads();
-    // phase 2: row pass at the needed columns.  With many staged rows the lanes walk rows
+    // ---- phase 2: row pass at the needed columns.  With many staged rows the lanes walk rows
     // (conflict-free byte reads); with few (small kernels) they walk output columns.
     // A copy-sized level only needs column sx of each output (even slots).
     const int ostep = tl.same_size ? 2 : 1;
@@ -113,7 +194,7 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     for (int b_ = wave; b_ < n_b; b_ += 4) {
         for (int a_ = lane; a_ < n_a; a_ += 64) {
             const int ry = lanes_on_rows ? a_ : b_, o = (lanes_on_rows ? b_ : a_) * ostep;
-            int sx = xofs[dx0 + (o >> 1)];
+            int sx = tl.same_size ? dx0 + (o >> 1) : sX[o >> 1];
             int col = (o & 1) ? min(sx + 1, W - 1) : sx;
             const uint8_t *p = sS + ry * tl.pitch + (col - x_lo); // tap i sits at p[i - r]
             float acc;
@@ -140,18 +221,18 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
         }
     }
     __syncthreads();
-    // phase 3: column pass at the needed rows, then the lerps
+    // ---- phase 3: column pass at the needed rows, then the lerps
     float *dst = img + (size_t)pi * Wk * Hk;
+    const int st = 2 * tl.TWo;
     for (int idx = threadIdx.x; idx < ndy * tl.TWo; idx += blockDim.x) {
         int ty = idx / tl.TWo, tx = idx - ty * tl.TWo; // TWo is a power of two
         if (tx >= ndx)
             continue;
         int dx = dx0 + tx, dy = dy0 + ty;
-        int sy = yofs[dy];
+        const int sy = tl.same_size ? dy : sY[ty];
         int row0 = clampi(sy, 0, H - 1) - y_lo, row1 = clampi(sy + 1, 0, H - 1) - y_lo;
-        const float *c0 = sR + row0 * (2 * tl.TWo) + 2 * tx;
-        const float *c1 = sR + row1 * (2 * tl.TWo) + 2 * tx;
-        const int st = 2 * tl.TWo;
+        const float *c0 = sR + row0 * st + 2 * tx;
+        const float *c1 = sR + row1 * st + 2 * tx;
         float v00 = kc * c0[0];
         for (int i = 1; i <= r; i++)
             v00 += sK[r + i] * (c0[i * st] + c0[-i * st]);
@@ -171,9 +252,9 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
                     v11 += sK[r + i] * (c1[i * st + 1] + c1[-i * st + 1]);
                 }
             }
-            float fx = xfrac[dx], fy = yfrac[dy];
+            const float fx = sFx[tx], fy = sFy[ty];
             float h0, h1;
-            if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+            if (sX[tx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
                 h0 = v00;
                 h1 = v10;
             } else {
@@ -452,10 +533,13 @@ k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__
 // 16-byte LDS reads.  HALO = M rounded up to even keeps column pairs aligned.
 // ---------------------------------------------------------------------------------
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+struct dpair {
+    double x, y;
+};
 
 template <int M, bool VEC>
 __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ Min, float2 *__restrict__ flow_out,
-                                                     int Wk, int Hk, double scale, int seg, double (*s_v)[128])
+                                                     int Wk, int Hk, double scale, int seg, double (*s_e)[64], double (*s_o)[64])
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
@@ -517,8 +601,10 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
             }
         }
 #pragma unroll
-        for (int c = 0; c < 5; c++)
-            *reinterpret_cast<double2 *>(&s_v[c][2 * lane]) = make_double2(vs[c][0], vs[c][1]);
+        for (int c = 0; c < 5; c++) {
+            s_e[c][lane] = vs[c][0]; // even and odd columns in separate rows: 8-byte accesses at an
+            s_o[c][lane] = vs[c][1]; // 8-byte lane stride are bank-conflict free
+        }
         __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
         if (is_out) {
             double g0[5], g1[5];
@@ -532,7 +618,7 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                 for (int q = 0; q < NE / 2; q++) {
                     if (2 * q + 1 < HALO - M || 2 * q > HALO + M + 1)
                         continue;
-                    double2 d = *reinterpret_cast<const double2 *>(&s_v[c][2 * lane - HALO + 2 * q]);
+                    const dpair d{s_e[c][lane - HALO / 2 + q], s_o[c][lane - HALO / 2 + q]};
                     if (2 * q == HALO - M)
                         first = d.x;
                     else if (2 * q > HALO - M && 2 * q <= HALO + M)
@@ -570,12 +656,12 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
-    __shared__ __attribute__((aligned(16))) double s_v[5][128];
+    __shared__ double s_e[5][64], s_o[5][64];
     const int first = (int)blockIdx.x * OUTC - HALO;
     if (first >= 0 && first + 127 < Wk)
-        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_v);
+        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o);
     else
-        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_v);
+        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o);
 }
 
 // ---------------------------------------------------------------------------------
@@ -846,11 +932,9 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs)
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float) + (size_t)L.ksz * sizeof(float);
-    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem, (const uint8_t *)fb->frames.as<uint8_t>(),
-                  (const int2 *)fb->pairs.as<int2>(), fb->img.as<float>(), fb->W, fb->H, L.W, L.H,
-                  (const int *)L.img_lerp.xofs.as<int>(), (const float *)L.img_lerp.xfrac.as<float>(),
-                  (const int *)L.img_lerp.yofs.as<int>(), (const float *)L.img_lerp.yfrac.as<float>(),
-                  (const float *)L.kern.as<float>(), L.ksz, t);
+    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->img.as<float>(),
+                  fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
 }
 
 // Output tile of a level: as large as fits ~60 KB of LDS, given the source extent a tile needs.
@@ -861,23 +945,29 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
     make_lerp(W, Wk, true, xo, fr);
     make_lerp(H, Hk, false, yo, fr);
     const int r = ksz / 2;
-    auto extent = [&](const std::vector<int> &ofs, int n, int len, int tile) {
+    auto extent = [&](const std::vector<int> &ofs, int n, int len, int tile, bool align4) {
         int worst = 0;
         for (int d0 = 0; d0 < n; d0 += tile) {
             int d1 = std::min(n, d0 + tile) - 1;
-            int lo = std::max(0, std::min(ofs[d0], len - 1)), hi = std::max(0, std::min(ofs[d1] + 1, len - 1));
-            worst = std::max(worst, hi - lo + 1 + 2 * r);
+            int lo = std::max(0, std::min(ofs[d0], len - 1)) - r, hi = std::max(0, std::min(ofs[d1] + 1, len - 1)) + r;
+            if (align4)
+                lo &= ~3;
+            worst = std::max(worst, hi - lo + 1);
         }
         return worst;
     };
     int s = std::max(1, (W + Wk - 1) / Wk);
     ImgTile t;
     t.same_size = (W == Wk && H == Hk);
-    t.TWo = std::max(8, std::min(64, 256 / s));
-    t.THo = std::max(2, std::min(16, 128 / s));
+    t.scale_x = 1. / ((double)Wk / W);
+    t.scale_y = 1. / ((double)Hk / H);
+    t.TWo = 8;
+    while (t.TWo * 2 <= std::min(128, 256 / s))
+        t.TWo *= 2;
+    t.THo = std::max(2, std::min(32, 128 / s));
     for (;;) {
-        t.LW = extent(xo, Wk, W, t.TWo);
-        t.LH = extent(yo, Hk, H, t.THo);
+        t.LW = extent(xo, Wk, W, t.TWo, true) + 3; // dword copies may run up to 3 bytes past the last column
+        t.LH = extent(yo, Hk, H, t.THo, false);
         t.pitch = (t.LW + 3) & ~3;
         if (((t.pitch / 4) & 1) == 0)
             t.pitch += 4;
