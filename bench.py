@@ -196,8 +196,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     group = None
-    if world > 1 or args.gpus > 1:
-        if world != args.gpus:
+    if world > 1 or args.gpus > 1 or os.environ.get("TF_BENCH_FORCE_DIST"):  # the env var rehearses the RCCL path on 1 GPU
+        if world != args.gpus and not os.environ.get("TF_BENCH_FORCE_DIST"):
             raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run); WORLD_SIZE={world}")
         from transflow_amd.batch import Group  # imports torch BEFORE libtfhip.so so one HIP runtime is shared
         group = Group("nccl")

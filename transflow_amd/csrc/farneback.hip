@@ -1006,7 +1006,7 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf
     const unsigned strips = cdiv(w, OUTC);
     // ~16 waves per CU in flight; each segment re-sums its first window (2M+1 rows)
     long segs_wanted = std::max(1l, 4096 / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(256, std::max<long>(32, (h + segs_wanted - 1) / segs_wanted));
+    int seg = (int)std::min<long>(256, std::max<long>(8, (h + segs_wanted - 1) / segs_wanted));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M[mbuf_in].as<float>(),
                   flow_out, w, h, scale, seg);
