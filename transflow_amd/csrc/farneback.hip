@@ -191,6 +191,37 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     const bool lanes_on_rows = nrows >= 48;
     const int n_a = lanes_on_rows ? nrows : no, n_b = lanes_on_rows ? no : nrows;
     const float k0 = sK[0], kc = sK[r], kc1 = ksz >= 3 ? sK[r + 1] : 0.f, kc2 = ksz >= 5 ? sK[r + 2] : 0.f;
+    if (lanes_on_rows && ksz > 5) {
+        // long kernels: a lane owns one staged row and four output columns at a time, so four
+        // independent left-to-right sums are in flight and each tap is fetched once for the four
+        for (int b_ = wave; 4 * b_ < no; b_ += 4) {
+            int cofs[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int o = min(4 * b_ + j, no - 1);
+                int sx = sX[o >> 1];
+                cofs[j] = ((o & 1) ? min(sx + 1, W - 1) : sx) - x_lo - r;
+            }
+            for (int ry = lane; ry < nrows; ry += 64) {
+                const uint8_t *q = sS + ry * tl.pitch;
+                float acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[j] = k0 * (float)q[cofs[j]];
+#pragma unroll 4
+                for (int i = 1; i < ksz; i++) {
+                    const float t = sK[i];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[j] += t * (float)q[cofs[j] + i];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * b_ + j < no)
+                        sR[ry * (2 * tl.TWo) + 4 * b_ + j] = acc[j];
+            }
+        }
+    } else {
     for (int b_ = wave; b_ < n_b; b_ += 4) {
         for (int a_ = lane; a_ < n_a; a_ += 64) {
             const int ry = lanes_on_rows ? a_ : b_, o = (lanes_on_rows ? b_ : a_) * ostep;
@@ -219,6 +250,7 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
             }
             sR[ry * (2 * tl.TWo) + o] = acc;
         }
+    }
     }
     __syncthreads();
     // ---- phase 3: column pass at the needed rows, then the lerps
@@ -345,6 +377,106 @@ __global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, 
         dst[2 * Nk + o] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
         dst[3 * Nk + o] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
         dst[4 * Nk + o] = (float)(b6 * pc.ig55);
+    }
+}
+
+// A2, register-blocked form for a compile-time poly_n.  Same arithmetic, statement for
+// statement; what changes is how often LDS is read: the vertical pass slides a window of
+// 4+2N rows down a column in registers (4 outputs per item), the horizontal pass computes two
+// adjacent outputs from one window of 2+2N triples.  ~25 DS operations per pixel instead of ~62.
+typedef float float2w __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int N>
+__global__ void __launch_bounds__(256)
+k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 2 * N, LH = TH + 2 * N;
+    __shared__ float sI[LH * LW];
+    __shared__ float sT[3][TH][LW];
+    const int pi = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *src = img + (size_t)pi * Nk;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int idx = threadIdx.x; idx < LH * LW; idx += 256) {
+        int ry = idx / LW, cx = idx - ry * LW; // LW is a compile-time constant
+        int y = clampi(y0 - N + ry, 0, Hk - 1), x = clampi(x0 - N + cx, 0, Wk - 1);
+        sI[idx] = src[(size_t)y * Wk + x];
+    }
+    __syncthreads();
+    // vertical pass (float): item = (column, group of 4 rows)
+    for (int idx = threadIdx.x; idx < (TH / 4) * LW; idx += 256) {
+        const int g = idx / LW, cx = idx - g * LW;
+        float v[4 + 2 * N];
+#pragma unroll
+        for (int j = 0; j < 4 + 2 * N; j++)
+            v[j] = sI[(4 * g + j) * LW + cx];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float c = v[q + N];
+            float t0 = c * pc.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                float a = v[q + N - k], b = v[q + N + k]; // rows y-k and y+k (clamped when staged)
+                float p = a + b;
+                t0 = t0 + pc.g[k] * p;
+                t1 = t1 + pc.xg[k] * (b - a);
+                t2 = t2 + pc.xxg[k] * p;
+            }
+            sT[0][4 * g + q][cx] = t0;
+            sT[1][4 * g + q][cx] = t1;
+            sT[2][4 * g + q][cx] = t2;
+        }
+    }
+    __syncthreads();
+    // horizontal pass (double): item = (row, pair of columns)
+    float *dst = R + (size_t)pi * 5 * Nk;
+    for (int idx = threadIdx.x; idx < TH * (TW / 2); idx += 256) {
+        const int ty = idx / (TW / 2), cp = idx - ty * (TW / 2);
+        const int x = x0 + 2 * cp, y = y0 + ty;
+        if (x >= Wk || y >= Hk)
+            continue;
+        float w0[2 + 2 * N], w1[2 + 2 * N], w2[2 + 2 * N]; // triples at columns x-N .. x+1+N
+#pragma unroll
+        for (int j = 0; j < 2 + 2 * N; j++) {
+            w0[j] = sT[0][ty][2 * cp + j];
+            w1[j] = sT[1][ty][2 * cp + j];
+            w2[j] = sT[2][ty][2 * cp + j];
+        }
+        float out[2][5];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float *T0 = w0 + q + N, *T1 = w1 + q + N, *T2 = w2 + q + N;
+            float g0 = pc.g[0];
+            double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                double tg = T0[k] + T0[-k];
+                g0 = pc.g[k];
+                b1 += tg * g0;
+                b4 += tg * pc.xxg[k];
+                b2 += (T0[k] - T0[-k]) * pc.xg[k];
+                b3 += (T1[k] + T1[-k]) * g0;
+                b6 += (T1[k] - T1[-k]) * pc.xg[k];
+                b5 += (T2[k] + T2[-k]) * g0;
+            }
+            out[q][0] = (float)(b3 * pc.ig11);
+            out[q][1] = (float)(b2 * pc.ig11);
+            out[q][2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            out[q][3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            out[q][4] = (float)(b6 * pc.ig55);
+        }
+        const size_t o = (size_t)y * Wk + x;
+        if (x + 1 < Wk) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                float2w v2 = {out[0][c], out[1][c]};
+                *reinterpret_cast<float2w *>(dst + c * Nk + o) = v2;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                dst[c * Nk + o] = out[0][c];
+        }
     }
 }
 
@@ -957,6 +1089,7 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
         return worst;
     };
     int s = std::max(1, (W + Wk - 1) / Wk);
+    static const size_t lds_cap = (getenv("TF_IMG_LDS_KB") ? (size_t)atoi(getenv("TF_IMG_LDS_KB")) : 60) * 1024;
     ImgTile t;
     t.same_size = (W == Wk && H == Hk);
     t.scale_x = 1. / ((double)Wk / W);
@@ -972,7 +1105,7 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
         if (((t.pitch / 4) & 1) == 0)
             t.pitch += 4;
         size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float) + (size_t)ksz * sizeof(float);
-        if (smem <= 60 * 1024 || (t.TWo <= 2 && t.THo <= 1))
+        if (smem <= (ksz <= 5 ? std::min<size_t>(lds_cap, 32 * 1024) : lds_cap) || (t.TWo <= 2 && t.THo <= 1))
             break;
         if (t.THo > 1 && (t.THo >= t.TWo / 4 || t.TWo <= 2))
             t.THo = std::max(1, t.THo / 2);
@@ -986,9 +1119,15 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
 {
     const int n = fb->pc.n;
     dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
+    if (n == 5)
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->img.as<float>(),
+                      fb->R.as<float>(), w, h, fb->pc);
+    if (n == 7)
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->img.as<float>(),
+                      fb->R.as<float>(), w, h, fb->pc);
     size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
-    return launch(lvl_name("fb_polyexp", k), k_polyexp, grid, dim3(256), smem, (const float *)fb->img.as<float>(),
-                  fb->R.as<float>(), w, h, fb->pc);
+    return launch(lvl_name("fb_polyexp_generic", k), k_polyexp, grid, dim3(256), smem,
+                  (const float *)fb->img.as<float>(), fb->R.as<float>(), w, h, fb->pc);
 }
 
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
