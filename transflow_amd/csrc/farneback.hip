@@ -20,7 +20,7 @@
 //   img     f32 [pair][2][Hk*Wk]          level image of both frames (A1 output)
 //   R       f32 [pair][2][5][Hk*Wk]       polynomial coefficients, planar (SoA)
 //   M[2]    f32 [pair][5][Hk*Wk]          2x2 systems, planar, ping-pong
-//   lflow   f32 [2][pair][Hk*Wk][2]       per-level flow, ping-pong between levels
+//   lflow   f32 [3][pair][Hk*Wk][2]       per-level flow, rotating between iterations and levels
 // All stages are HBM-bound (<= ~60 flop/B); MFMA is not applicable.
 #include <cfloat>
 #include <cmath>
@@ -36,6 +36,9 @@ using namespace tf;
 namespace {
 
 constexpr int MAX_POLY_N = 15;
+
+// two floats at 4-byte alignment: one global_load_dwordx2 (the hardware takes unaligned dwordx2)
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
 struct PolyConst {
     int n;
@@ -480,13 +483,17 @@ k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk
     }
 }
 
+// OpenCV's border down-weighting table {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance d to an
+// edge (1 beyond 5 px), as selects instead of a memory table: a table lookup is a global load,
+// and its wait would drain every prefetched gather
+__device__ __forceinline__ float border_weight(int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); }
+
 // ---------------------------------------------------------------------------------
 // A3: one pixel of FarnebackUpdateMatrices.  R0/R1 planar; out[5] = M.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, const float *__restrict__ R1, size_t Nk,
                                                  int Wk, int Hk, int x, int y, float dx, float dy, float out[5])
 {
-    const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
     const size_t o = (size_t)y * Wk + x;
     float fx = x + dx, fy = y + dy;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
@@ -496,12 +503,24 @@ __device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, c
     if ((unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1)) {
         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         size_t q = (size_t)y1 * Wk + x1;
-        const float *p0 = R1 + q, *p1 = R1 + Nk + q, *p2 = R1 + 2 * Nk + q, *p3 = R1 + 3 * Nk + q, *p4 = R1 + 4 * Nk + q;
-        r2 = a00 * p0[0] + a01 * p0[1] + a10 * p0[Wk] + a11 * p0[Wk + 1];
-        r3 = a00 * p1[0] + a01 * p1[1] + a10 * p1[Wk] + a11 * p1[Wk + 1];
-        r4 = a00 * p2[0] + a01 * p2[1] + a10 * p2[Wk] + a11 * p2[Wk + 1];
-        r5 = a00 * p3[0] + a01 * p3[1] + a10 * p3[Wk] + a11 * p3[Wk + 1];
-        r6 = a00 * p4[0] + a01 * p4[1] + a10 * p4[Wk] + a11 * p4[Wk + 1];
+        // the two horizontal neighbours of each row come with one 8-byte load
+        const float *rp = R1 + q;
+        float2u t0, b0, t1, b1, t2, b2, t3, b3, t4, b4;
+        t0 = *reinterpret_cast<const float2u *>(rp);
+        b0 = *reinterpret_cast<const float2u *>(rp + Wk);
+        t1 = *reinterpret_cast<const float2u *>(rp + Nk);
+        b1 = *reinterpret_cast<const float2u *>(rp + Nk + Wk);
+        t2 = *reinterpret_cast<const float2u *>(rp + 2 * Nk);
+        b2 = *reinterpret_cast<const float2u *>(rp + 2 * Nk + Wk);
+        t3 = *reinterpret_cast<const float2u *>(rp + 3 * Nk);
+        b3 = *reinterpret_cast<const float2u *>(rp + 3 * Nk + Wk);
+        t4 = *reinterpret_cast<const float2u *>(rp + 4 * Nk);
+        b4 = *reinterpret_cast<const float2u *>(rp + 4 * Nk + Wk);
+        r2 = a00 * t0.x + a01 * t0.y + a10 * b0.x + a11 * b0.y;
+        r3 = a00 * t1.x + a01 * t1.y + a10 * b1.x + a11 * b1.y;
+        r4 = a00 * t2.x + a01 * t2.y + a10 * b2.x + a11 * b2.y;
+        r5 = a00 * t3.x + a01 * t3.y + a10 * b3.x + a11 * b3.y;
+        r6 = a00 * t4.x + a01 * t4.y + a10 * b4.x + a11 * b4.y;
         r4 = (R0[2 * Nk + o] + r4) * 0.5f;
         r5 = (R0[3 * Nk + o] + r5) * 0.5f;
         r6 = (R0[4 * Nk + o] + r6) * 0.25f;
@@ -515,9 +534,9 @@ __device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, c
     r3 = (R0[Nk + o] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
-    if ((unsigned)(x - 5) >= (unsigned)(Wk - 10) || (unsigned)(y - 5) >= (unsigned)(Hk - 10)) {
-        float scale = (x < 5 ? border[x] : 1.f) * (x >= Wk - 5 ? border[Wk - x - 1] : 1.f) *
-                      (y < 5 ? border[y] : 1.f) * (y >= Hk - 5 ? border[Hk - y - 1] : 1.f);
+    {
+        // multiplying by 1.f away from the borders is exact, so no branch is needed
+        float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
         r2 *= scale;
         r3 *= scale;
         r4 *= scale;
@@ -546,9 +565,11 @@ struct FlowInit {
 
 __global__ void k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, int Hk, FlowInit fi)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= Wk)
+    // 256 threads = 64 columns x 4 rows: the two R1 rows a bilinear tap straddles are shared by
+    // the block's neighbouring output rows instead of being fetched again by another block
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wk || y >= Hk)
         return;
     const int pair = blockIdx.z;
     const size_t Nk = (size_t)Wk * Hk;
@@ -664,7 +685,6 @@ k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__
 // row, and reads back the 2M+2 neighbours it needs for its two outputs with
 // 16-byte LDS reads.  HALO = M rounded up to even keeps column pairs aligned.
 // ---------------------------------------------------------------------------------
-typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 struct dpair {
     double x, y;
 };
@@ -794,6 +814,275 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
         blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o);
     else
         blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o);
+}
+
+// ---------------------------------------------------------------------------------
+// A5 as its own (cheap) kernel for the fused iteration below: level flow =
+// resize(coarser flow, INTER_LINEAR) * 1/pyr_scale.
+// ---------------------------------------------------------------------------------
+__global__ void k_flow_upsample(float2 *__restrict__ dst, int Wk, int Hk, FlowInit fi)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wk || y >= Hk)
+        return;
+    const int pair = blockIdx.z;
+    const float2 *c = fi.src + (size_t)pair * fi.Wc * fi.Hc;
+    int sx = fi.xofs[x], sy = fi.yofs[y];
+    float fx = fi.xfrac[x], fy = fi.yfrac[y];
+    int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
+    float2 h0, h1;
+    if (sx >= fi.Wc - 1) {
+        h0 = c[(size_t)sy0 * fi.Wc + sx];
+        h1 = c[(size_t)sy1 * fi.Wc + sx];
+    } else {
+        float2 a = c[(size_t)sy0 * fi.Wc + sx], b = c[(size_t)sy0 * fi.Wc + sx + 1];
+        float2 d = c[(size_t)sy1 * fi.Wc + sx], e = c[(size_t)sy1 * fi.Wc + sx + 1];
+        float a0 = 1.f - fx;
+        h0 = make_float2(a.x * a0 + b.x * fx, a.y * a0 + b.y * fx);
+        h1 = make_float2(d.x * a0 + e.x * fx, d.y * a0 + e.y * fx);
+    }
+    float b0 = 1.f - fy;
+    dst[(size_t)pair * Wk * Hk + (size_t)y * Wk + x] =
+        make_float2((h0.x * b0 + h1.x * fy) * fi.mul, (h0.y * b0 + h1.y * fy) * fi.mul);
+}
+
+// ---------------------------------------------------------------------------------
+// A3+A4 fused: one Farnebäck iteration without ever storing M.
+// One wave marches a 128-column strip (two columns per lane) down a row segment.  For
+// the row entering the blur window it computes M from (R0, gathered R1, flow_in) -- the
+// statements of update_matrix_px, split into an "issue the loads" and a "finish" half so
+// the gathers of row y+8 fly while row y is solved -- and keeps the 2m+1 rows of M the
+// window spans in an LDS ring owned by the wave (15 x 5 x 128 floats for m = 7).  The
+// vertical sums run in double registers (+ entering row - leaving row from the ring), the
+// horizontal sums and the 2x2 solve are those of k_blur_solve_wave.  HBM traffic per pixel
+// and iteration: R0 20 B + R1 gather + flow in/out 16 B, instead of writing M (20 B) and
+// reading it back twice (40 B).
+// ---------------------------------------------------------------------------------
+struct GatherRegs {
+    float2 r0[5];   // R0 at the two pixels, per channel (x: first pixel, y: second)
+    float2 t[2][5]; // R1 pair (x1, x1+1) on row y1, per pixel and channel
+    float2 b[2][5]; // R1 pair on row y1+1
+    float dx[2], dy[2], fx[2], fy[2];
+    bool inb[2];
+};
+
+// loads for the matrices of pixels (xa, y) and (xb, y); flow already known
+__device__ __forceinline__ void gather_issue(GatherRegs &g, const float *__restrict__ R0, const float *__restrict__ R1,
+                                             size_t Nk, int Wk, int Hk, int xa, int xb, int y, float2 fa, float2 fb)
+{
+    const int xs[2] = {xa, xb};
+    const float2 fl[2] = {fa, fb};
+    const size_t oa = (size_t)y * Wk + xa, ob = (size_t)y * Wk + xb;
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        g.r0[c] = make_float2(R0[c * Nk + oa], R0[c * Nk + ob]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        float dx = fl[j].x, dy = fl[j].y;
+        float fx = xs[j] + dx, fy = y + dy;
+        int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+        fx -= x1;
+        fy -= y1;
+        g.dx[j] = dx;
+        g.dy[j] = dy;
+        g.fx[j] = fx;
+        g.fy[j] = fy;
+        g.inb[j] = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
+        // out-of-frame taps load from a clamped (valid) address and are discarded: no branch
+        // around the loads, so they all stay in flight together
+        int x1c = clampi(x1, 0, Wk - 2), y1c = clampi(y1, 0, Hk - 2);
+        const float *rp = R1 + (size_t)y1c * Wk + x1c;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            float2u tv = *reinterpret_cast<const float2u *>(rp + c * Nk);
+            float2u bv = *reinterpret_cast<const float2u *>(rp + c * Nk + Wk);
+            g.t[j][c] = make_float2(tv.x, tv.y);
+            g.b[j][c] = make_float2(bv.x, bv.y);
+        }
+    }
+}
+
+// the arithmetic of update_matrix_px on the gathered values; m[j][5] for the two pixels
+__device__ __forceinline__ void gather_finish(const GatherRegs &g, int Wk, int Hk, int xa, int xb, int y,
+                                              float m[2][5])
+{
+    const int xs[2] = {xa, xb};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int x = xs[j];
+        const float R00 = j ? g.r0[0].y : g.r0[0].x, R01 = j ? g.r0[1].y : g.r0[1].x, R02 = j ? g.r0[2].y : g.r0[2].x,
+                    R03 = j ? g.r0[3].y : g.r0[3].x, R04 = j ? g.r0[4].y : g.r0[4].x;
+        const float fx = g.fx[j], fy = g.fy[j], dx = g.dx[j], dy = g.dy[j];
+        float r2, r3, r4, r5, r6;
+        if (g.inb[j]) {
+            float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+            r2 = a00 * g.t[j][0].x + a01 * g.t[j][0].y + a10 * g.b[j][0].x + a11 * g.b[j][0].y;
+            r3 = a00 * g.t[j][1].x + a01 * g.t[j][1].y + a10 * g.b[j][1].x + a11 * g.b[j][1].y;
+            r4 = a00 * g.t[j][2].x + a01 * g.t[j][2].y + a10 * g.b[j][2].x + a11 * g.b[j][2].y;
+            r5 = a00 * g.t[j][3].x + a01 * g.t[j][3].y + a10 * g.b[j][3].x + a11 * g.b[j][3].y;
+            r6 = a00 * g.t[j][4].x + a01 * g.t[j][4].y + a10 * g.b[j][4].x + a11 * g.b[j][4].y;
+            r4 = (R02 + r4) * 0.5f;
+            r5 = (R03 + r5) * 0.5f;
+            r6 = (R04 + r6) * 0.25f;
+        } else {
+            r2 = r3 = 0.f;
+            r4 = R02;
+            r5 = R03;
+            r6 = R04 * 0.5f;
+        }
+        r2 = (R00 - r2) * 0.5f;
+        r3 = (R01 - r3) * 0.5f;
+        r2 += r4 * dy + r6 * dx;
+        r3 += r6 * dy + r5 * dx;
+        {
+            float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
+            r2 *= scale;
+            r3 *= scale;
+            r4 *= scale;
+            r5 *= scale;
+            r6 *= scale;
+        }
+        m[j][0] = r4 * r4 + r6 * r6;
+        m[j][1] = (r4 + r5) * r6;
+        m[j][2] = r5 * r5 + r6 * r6;
+        m[j][3] = r4 * r2 + r6 * r3;
+        m[j][4] = r6 * r2 + r5 * r3;
+    }
+}
+
+template <int M, bool HAVE_FLOW>
+__global__ void __launch_bounds__(64)
+k_flow_iter(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
+            int Hk, double scale, int seg)
+{
+    constexpr int HALO = (M + 1) & ~1;
+    constexpr int OUTC = 128 - 2 * HALO;
+    constexpr int NE = 2 * HALO + 2;
+    constexpr int WIN = 2 * M + 1;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float2 *ring = reinterpret_cast<float2 *>(s_dyn);                         // [WIN][5][64] (two columns per lane)
+    double *s_e = reinterpret_cast<double *>(s_dyn + (size_t)WIN * 5 * 128);  // [5][64]
+    double *s_o = s_e + 5 * 64;                                               // [5][64]
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * OUTC - HALO + 2 * lane;
+    const int xa = clampi(c0, 0, Wk - 1), xb = clampi(c0 + 1, 0, Wk - 1); // replicated border columns
+    const int pair = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
+    const float2 *fin = HAVE_FLOW ? flow_in + (size_t)pair * Nk : nullptr;
+    const int r0 = blockIdx.y * seg, r1 = min(r0 + seg, Hk);
+
+    auto load_flow = [&](int row, float2 &fa, float2 &fb) {
+        if (HAVE_FLOW) {
+            fa = fin[(size_t)row * Wk + xa];
+            fb = fin[(size_t)row * Wk + xb];
+        } else {
+            fa = fb = make_float2(0.f, 0.f);
+        }
+    };
+
+    double vs[5][2];
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        vs[c][0] = vs[c][1] = 0.0;
+    // ---- fill the window for the first output row: rows r0-M .. r0+M-1 (clamped: a clamped
+    // row repeats the matrices of the edge row)
+    float mlast[2][5];
+    int last_row = -1;
+    int slot = 0;
+    for (int e = r0 - M; e < r0 + M; e++) {
+        const int row = clampi(e, 0, Hk - 1);
+        if (row != last_row) {
+            float2 fa, fb;
+            load_flow(row, fa, fb);
+            GatherRegs g;
+            gather_issue(g, R0, R1, Nk, Wk, Hk, xa, xb, row, fa, fb);
+            gather_finish(g, Wk, Hk, xa, xb, row, mlast);
+            last_row = row;
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            ring[(slot * 5 + c) * 64 + lane] = make_float2(mlast[0][c], mlast[1][c]);
+            vs[c][0] += (double)mlast[0][c];
+            vs[c][1] += (double)mlast[1][c];
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
+    }
+    // `slot` now addresses the ring row that enters with output row r0 (not yet part of vs:
+    // treat its previous content as zero)
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        ring[(slot * 5 + c) * 64 + lane] = make_float2(0.f, 0.f);
+
+    // software pipeline: G holds the gathers of the row entering the window of the current output
+    // row, F the flow of the row entering next.  Rows past the last image row are replicated:
+    // their matrices are recomputed from the clamped row (same values, no branch around loads).
+    GatherRegs G;
+    float2 Fa, Fb;
+    {
+        const int e = min(r0 + M, Hk - 1);
+        load_flow(e, Fa, Fb);
+        gather_issue(G, R0, R1, Nk, Wk, Hk, xa, xb, e, Fa, Fb);
+        load_flow(min(r0 + M + 1, Hk - 1), Fa, Fb);
+    }
+    const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
+    for (int y = r0; y < r1; y++) {
+        gather_finish(G, Wk, Hk, xa, xb, min(y + M, Hk - 1), mlast);
+        // next row's gathers (and the flow of the one after) fly during the rest of this iteration
+        gather_issue(G, R0, R1, Nk, Wk, Hk, xa, xb, min(y + M + 1, Hk - 1), Fa, Fb);
+        load_flow(min(y + M + 2, Hk - 1), Fa, Fb);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            float2 *rp = &ring[(slot * 5 + c) * 64 + lane];
+            const float2 old = *rp;
+            *rp = make_float2(mlast[0][c], mlast[1][c]);
+            vs[c][0] += (double)mlast[0][c] - (double)old.x;
+            vs[c][1] += (double)mlast[1][c] - (double)old.y;
+            s_e[c * 64 + lane] = vs[c][0];
+            s_o[c * 64 + lane] = vs[c][1];
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
+        __syncthreads();
+        if (is_out) {
+            double g0[5], g1[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                double first = 0, last = 0, common = 0;
+#pragma unroll
+                for (int q = 0; q < NE / 2; q++) {
+                    if (2 * q + 1 < HALO - M || 2 * q > HALO + M + 1)
+                        continue;
+                    const double dxv = s_e[c * 64 + lane - HALO / 2 + q], dyv = s_o[c * 64 + lane - HALO / 2 + q];
+                    if (2 * q == HALO - M)
+                        first = dxv;
+                    else if (2 * q > HALO - M && 2 * q <= HALO + M)
+                        common += dxv;
+                    else if (2 * q == HALO + M + 1)
+                        last = dxv;
+                    if (2 * q + 1 == HALO - M)
+                        first = dyv;
+                    else if (2 * q + 1 > HALO - M && 2 * q + 1 <= HALO + M)
+                        common += dyv;
+                    else if (2 * q + 1 == HALO + M + 1)
+                        last = dyv;
+                }
+                g0[c] = (first + common) * scale;
+                g1[c] = (common + last) * scale;
+            }
+            double idet0 = 1. / (g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
+            double idet1 = 1. / (g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
+            float2 f0 = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
+                                    (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
+            float2 f1 = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
+                                    (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+            float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
+            o[0] = f0;
+            if (c0 + 1 < Wk)
+                o[1] = f1;
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1033,9 +1322,13 @@ struct tf_fb {
     int slots = 0, max_pairs = 0;
     PolyConst pc;
     std::vector<Level *> lv;
-    DevBuf frames, img, R, M[2], lflow[2], pairs, winner, scratch;
+    DevBuf frames, img, R, M[2], lflow[3], pairs, winner, scratch;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
+    // A3+A4 as one kernel per iteration (k_flow_iter).  Correct (same parity tests) but slower than the
+    // two-kernel form on MI355X: the LDS ring admits 3 waves per CU, which leaves the march issue-bound
+    // (DESIGN.md section 8).  Opt-in with TF_FB_FUSED=1.
+    bool fused = getenv("TF_FB_FUSED") && atoi(getenv("TF_FB_FUSED")) != 0;
     ~tf_fb()
     {
         for (auto *l : lv)
@@ -1132,8 +1425,8 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
 
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
-    dim3 grid(cdiv(w, 128), h, n_pairs);
-    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(128), 0, (const float *)fb->R.as<float>(),
+    dim3 grid(cdiv(w, 64), cdiv(h, 4), n_pairs);
+    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->R.as<float>(),
                   fb->M[mbuf].as<float>(), w, h, fi);
 }
 
@@ -1176,6 +1469,44 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, floa
     return launch("fb_blur_solve_generic", k_blur_solve<false>, grid, dim3(BS_THREADS), 0,
                   (const float *)fb->M[mbuf_in].as<float>(), (float *)nullptr, flow_out,
                   (const float *)fb->R.as<float>(), w, h, m, scale, seg);
+}
+
+template <int M>
+static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k)
+{
+    constexpr int HALO = (M + 1) & ~1;
+    constexpr int OUTC = 128 - 2 * HALO;
+    constexpr int WIN = 2 * M + 1;
+    const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
+    const unsigned strips = cdiv(w, OUTC);
+    // LDS (ring + exchange rows) admits 3 waves per CU; each segment first fills 2M rows of
+    // the window, so keep segments long, but cut the image into enough of them to fill the chip
+    long segs_wanted = std::max(1l, (3 * 256 * 4) / std::max(1l, (long)strips * n_pairs));
+    int seg = (int)std::min<long>(h, std::max<long>(4 * WIN, (h + segs_wanted - 1) / segs_wanted));
+    dim3 grid(strips, cdiv(h, seg), n_pairs);
+    size_t smem = (size_t)WIN * 5 * 128 * sizeof(float) + 2 * 5 * 64 * sizeof(double);
+    const float *R = fb->R.as<float>();
+    if (flow_in)
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter<M, true>, grid, dim3(64), smem, R, flow_in, flow_out, w,
+                      h, scale, seg);
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter<M, false>, grid, dim3(64), smem, R, flow_in, flow_out, w, h,
+                  scale, seg);
+}
+
+// true if the fused iteration kernel exists for this window; launches it
+static bool fb_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k, int &rc)
+{
+    if (w < 2 || h < 2)
+        return false;
+    switch (fb->prm.winsize / 2) {
+    case 2: rc = launch_flow_iter<2>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    case 3: rc = launch_flow_iter<3>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    case 4: rc = launch_flow_iter<4>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    case 5: rc = launch_flow_iter<5>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    case 6: rc = launch_flow_iter<6>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    case 7: rc = launch_flow_iter<7>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    default: return false;
+    }
 }
 
 static int fb_validate_params(const tf_fb_params *p, int width, int height)
@@ -1262,6 +1593,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
         (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
+        (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
         (rc = fb->pairs.alloc(P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
         return fail(rc);
     *out = fb;
@@ -1320,7 +1652,9 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     }
     TF_HIP(hipMemcpyAsync(fb->pairs.p, pr.data(), pr.size() * 8, hipMemcpyHostToDevice, stream()));
     TF_HIP(hipStreamSynchronize(stream())); // pr is a stack-lifetime staging buffer
-    int cur = 0; // lflow buffer the current level writes
+    const int m = fb->prm.winsize / 2;
+    const bool fused = fb->fused && m >= 2 && m <= 7;
+    int coarse = -1; // lflow buffer holding the coarser level's result
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
         TF_TRY(fb_level_image(fb, k, n_pairs));
@@ -1330,7 +1664,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         if (k < fb->K) {
             Level &C = *fb->lv[k + 1];
             fi.mode = 1;
-            fi.src = fb->lflow[cur ^ 1].as<float2>();
+            fi.src = fb->lflow[coarse].as<float2>();
             fi.Wc = C.W;
             fi.Hc = C.H;
             fi.xofs = L.flow_lerp.xofs.as<int>();
@@ -1339,18 +1673,46 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             fi.yfrac = L.flow_lerp.yfrac.as<float>();
             fi.mul = (float)(1. / fb->prm.pyr_scale);
         }
-        TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0, k));
-        FlowInit fl;
-        memset(&fl, 0, sizeof(fl));
-        fl.mode = 2;
-        fl.src = fb->lflow[cur].as<float2>();
-        for (int i = 0; i < fb->prm.iterations; i++) {
-            TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, 0, fb->lflow[cur].as<float2>(), k));
-            if (i < fb->prm.iterations - 1) // M is a pure function of (R0, R1, flow): rebuild it in place
-                TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0, k));
+        // two buffers other than `coarse` for this level's iterations
+        int a = (coarse + 1) % 3, b = (coarse + 2) % 3;
+        if (coarse < 0) {
+            a = 0;
+            b = 1;
         }
-        fb->final_buf = cur;
-        cur ^= 1;
+        int result;
+        if (fused && L.W >= 2 && L.H >= 2) {
+            const float2 *src = nullptr; // zero flow at the coarsest scale (flags == 0)
+            if (k < fb->K) {
+                dim3 g(cdiv(L.W, 64), cdiv(L.H, 4), n_pairs);
+                TF_TRY(launch(lvl_name("fb_flow_upsample", k), k_flow_upsample, g, dim3(256), 0, fb->lflow[a].as<float2>(),
+                              L.W, L.H, fi));
+                src = fb->lflow[a].as<float2>();
+                std::swap(a, b); // first iteration reads a, writes b
+            }
+            int dst = a;
+            for (int i = 0; i < fb->prm.iterations; i++) {
+                int rc = TF_OK;
+                fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[dst].as<float2>(), k, rc);
+                TF_TRY(rc);
+                src = fb->lflow[dst].as<float2>();
+                result = dst;
+                dst = (dst == a) ? b : a; // the next iteration reads what this one wrote
+            }
+        } else {
+            TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0, k));
+            FlowInit fl;
+            memset(&fl, 0, sizeof(fl));
+            fl.mode = 2;
+            fl.src = fb->lflow[a].as<float2>();
+            for (int i = 0; i < fb->prm.iterations; i++) {
+                TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, 0, fb->lflow[a].as<float2>(), k));
+                if (i < fb->prm.iterations - 1) // M is a pure function of (R0, R1, flow): rebuild it in place
+                    TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0, k));
+            }
+            result = a;
+        }
+        coarse = result;
+        fb->final_buf = result;
     }
     fb->last_pairs = n_pairs;
     return TF_OK;
