@@ -146,6 +146,26 @@ def kernel_alg_bytes(name, wl, batch, iterations=3):
     return total
 
 
+def measured_traffic(name, wl, batch, launches_per_step, iterations=3):
+    """HBM bytes per launch of kernel `name` from the PMC passes recorded in profiles/ (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, 2*FETCH + WRITE after calibration on this library's
+    access widths -- profiles/README.md).  Bytes per level pixel measured at 4K level 0, scaled to the
+    pixels this workload's launches cover.  None when no measurement exists for the kernel."""
+    from transflow_amd import roofline as rf
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    if name not in table:
+        return None
+    n = [a * b for a, b in rf.level_sizes(wl["w"], wl["h"], 0.5, wl["levels"])]
+    per_level_launches = {"fb_update_matrices": iterations, "fb_blur_solve": iterations}.get(name, 1)
+    images = 2 if name in ("fb_polyexp", "fb_level_image") else 1
+    total = table[name]["bytes_per_px"] * sum(n) * batch * images * per_level_launches
+    return total / max(1.0, launches_per_step)
+
+
 def cpu_baseline(wl):
     """The oracle (a scalar C port of OpenCV's CPU path + the numpy remap), timed on
     this host on ONE frame pair of the same workload.  Checker code, used here only
@@ -254,6 +274,7 @@ def main():
     fps = frames / elapsed
     alg_dom = kernel_alg_bytes(dominant, wl, args.batch) * args.steps
     achieved = alg_dom / (dom_ms * 1e-3) / 1e9
+    traffic = measured_traffic(dominant, wl, args.batch, dom_cnt / max(1, args.steps))
     step_bytes = args.batch * (rf.farneback_bytes(wl["w"], wl["h"], 0.5, wl["levels"], 3)
                                + rf.remap_bytes(wl["w"], wl["h"], reset_mask=wl["reset"], forward=wl["direction"] == 0))
     out = {
@@ -269,7 +290,7 @@ def main():
                    "frame_pairs_per_step_per_gpu": args.batch,
                    "parallelism": f"frames sharded over {max(1, world)} GPU(s), one remap stream per GPU"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / rf.HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / rf.HBM_PEAK_GBS, "traffic": traffic,
                      "launches": dom_cnt, "avg_launch_ms": dom_ms / max(1, dom_cnt),
                      "algorithmic_bytes_per_launch": alg_dom / max(1, dom_cnt),
                      "whole_step": {"algorithmic_bytes": step_bytes,
