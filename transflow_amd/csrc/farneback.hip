@@ -563,12 +563,17 @@ struct FlowInit {
     float mul;
 };
 
-__global__ void k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, int Hk, FlowInit fi)
+constexpr int UM_TW = 64, UM_TH = 4;
+
+__global__ void __launch_bounds__(UM_TW *UM_TH)
+k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, int Hk, FlowInit fi)
 {
-    // 256 threads = 64 columns x 4 rows: the two R1 rows a bilinear tap straddles are shared by
-    // the block's neighbouring output rows instead of being fetched again by another block
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    // 256 threads = 64 columns x 4 rows: the two R1 rows a bilinear tap straddles are shared by the
+    // block's neighbouring output rows.  Measured R1 traffic model: 20 B x (rows+1)/rows x
+    // (lines+1)/lines of a flow-shifted 256-byte row segment (profiles/README.md); 128x8 tiles were
+    // measured and bring nothing more
+    int x = blockIdx.x * UM_TW + (threadIdx.x & (UM_TW - 1));
+    int y = blockIdx.y * UM_TH + threadIdx.x / UM_TW;
     if (x >= Wk || y >= Hk)
         return;
     const int pair = blockIdx.z;
@@ -691,11 +696,11 @@ struct dpair {
 
 template <int M, bool VEC>
 __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ Min, float2 *__restrict__ flow_out,
-                                                     int Wk, int Hk, double scale, int seg, double (*s_e)[64], double (*s_o)[64])
+                                                     int Wk, int Hk, double scale, int seg, double (*s_e)[64], double (*s_o)[64],
+                                                     double (*s_p)[64])
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
-    constexpr int NE = 2 * HALO + 2; // LDS elements a lane reads per channel
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * OUTC - HALO + 2 * lane;
     const int pair = blockIdx.z;
@@ -754,38 +759,36 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            s_e[c][lane] = vs[c][0]; // even and odd columns in separate rows: 8-byte accesses at an
-            s_o[c][lane] = vs[c][1]; // 8-byte lane stride are bank-conflict free
+            // the lane publishes its two column sums and their pair sum, each in its own LDS row
+            // (8-byte accesses at an 8-byte lane stride are bank-conflict free)
+            s_e[c][lane] = vs[c][0];
+            s_o[c][lane] = vs[c][1];
+            s_p[c][lane] = vs[c][0] + vs[c][1];
         }
         __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
         if (is_out) {
             double g0[5], g1[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                // element i of the lane's view is s_v[c][2*lane - HALO + i], i in [0, NE): output 0 sums
-                // i in [HALO-M, HALO+M], output 1 sums i in [HALO-M+1, HALO+M+1]; the 2M shared terms
-                // are added once
-                double first = 0, last = 0, common = 0;
+                // windows of the lane's columns 2l and 2l+1 as whole neighbour pairs plus one single
+                // column at each end: M+2 (odd M) LDS reads and adds instead of 2M+2
+                if (M & 1) {
+                    constexpr int h = (M - 1) / 2, k = (M + 1) / 2;
+                    double common = s_p[c][lane - h];
 #pragma unroll
-                for (int q = 0; q < NE / 2; q++) {
-                    if (2 * q + 1 < HALO - M || 2 * q > HALO + M + 1)
-                        continue;
-                    const dpair d{s_e[c][lane - HALO / 2 + q], s_o[c][lane - HALO / 2 + q]};
-                    if (2 * q == HALO - M)
-                        first = d.x;
-                    else if (2 * q > HALO - M && 2 * q <= HALO + M)
-                        common += d.x;
-                    else if (2 * q == HALO + M + 1)
-                        last = d.x;
-                    if (2 * q + 1 == HALO - M)
-                        first = d.y;
-                    else if (2 * q + 1 > HALO - M && 2 * q + 1 <= HALO + M)
-                        common += d.y;
-                    else if (2 * q + 1 == HALO + M + 1)
-                        last = d.y;
+                    for (int j = -h + 1; j <= h; j++)
+                        common += s_p[c][lane + j];
+                    g0[c] = (s_o[c][lane - k] + common) * scale; // columns 2l-M .. 2l+M
+                    g1[c] = (common + s_e[c][lane + k]) * scale; // columns 2l+1-M .. 2l+1+M
+                } else {
+                    constexpr int h = M / 2;
+                    double mid = s_p[c][lane - h + 1];
+#pragma unroll
+                    for (int j = -h + 2; j <= h - 1; j++)
+                        mid += s_p[c][lane + j];
+                    g0[c] = (s_p[c][lane - h] + mid + s_e[c][lane + h]) * scale;
+                    g1[c] = (s_o[c][lane - h] + mid + s_p[c][lane + h]) * scale;
                 }
-                g0[c] = (first + common) * scale;
-                g1[c] = (common + last) * scale;
             }
             double idet0 = 1. / (g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
             double idet1 = 1. / (g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
@@ -808,12 +811,12 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
-    __shared__ double s_e[5][64], s_o[5][64];
+    __shared__ double s_e[5][64], s_o[5][64], s_p[5][64];
     const int first = (int)blockIdx.x * OUTC - HALO;
     if (first >= 0 && first + 127 < Wk)
-        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o);
+        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o, s_p);
     else
-        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o);
+        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o, s_p);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1425,8 +1428,8 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
 
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
-    dim3 grid(cdiv(w, 64), cdiv(h, 4), n_pairs);
-    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->R.as<float>(),
+    dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
+    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(UM_TW * UM_TH), 0, (const float *)fb->R.as<float>(),
                   fb->M[mbuf].as<float>(), w, h, fi);
 }
 
