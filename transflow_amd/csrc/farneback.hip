@@ -197,7 +197,11 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     if (lanes_on_rows && ksz > 5) {
         // long kernels: a lane owns one staged row and four output columns at a time, so four
         // independent left-to-right sums are in flight and each tap is fetched once for the four
-        for (int b_ = wave; 4 * b_ < no; b_ += 4) {
+        // work item = (chunk of 64 staged rows, group of 4 output columns), dealt round-robin to
+        // the four waves so none idles when a tile has few column groups
+        const int ngroups = (no + 3) >> 2, nchunks = (nrows + 63) >> 6;
+        for (int item = wave; item < ngroups * nchunks; item += 4) {
+            const int b_ = item % ngroups, ry = (item / ngroups) * 64 + lane;
             int cofs[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -205,7 +209,7 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
                 int sx = sX[o >> 1];
                 cofs[j] = ((o & 1) ? min(sx + 1, W - 1) : sx) - x_lo - r;
             }
-            for (int ry = lane; ry < nrows; ry += 64) {
+            if (ry < nrows) {
                 const uint8_t *q = sS + ry * tl.pitch;
                 float acc[4];
 #pragma unroll
@@ -1366,7 +1370,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs)
 }
 
 // Output tile of a level: as large as fits ~60 KB of LDS, given the source extent a tile needs.
-static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
+static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz, int level)
 {
     std::vector<int> xo, yo;
     std::vector<float> fr;
@@ -1390,23 +1394,61 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz)
     t.same_size = (W == Wk && H == Hk);
     t.scale_x = 1. / ((double)Wk / W);
     t.scale_y = 1. / ((double)Hk / H);
-    t.TWo = 8;
-    while (t.TWo * 2 <= std::min(128, 256 / s))
-        t.TWo *= 2;
-    t.THo = std::max(2, std::min(32, 128 / s));
-    for (;;) {
-        t.LW = extent(xo, Wk, W, t.TWo, true) + 3; // dword copies may run up to 3 bytes past the last column
-        t.LH = extent(yo, Hk, H, t.THo, false);
+    auto fill = [&](int two, int tho) {
+        t.TWo = two;
+        t.THo = tho;
+        t.LW = extent(xo, Wk, W, two, true) + 3; // dword copies may run up to 3 bytes past the last column
+        t.LH = extent(yo, Hk, H, tho, false);
         t.pitch = (t.LW + 3) & ~3;
         if (((t.pitch / 4) & 1) == 0)
             t.pitch += 4;
-        size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float) + (size_t)ksz * sizeof(float);
-        if (smem <= (ksz <= 5 ? std::min<size_t>(lds_cap, 32 * 1024) : lds_cap) || (t.TWo <= 2 && t.THo <= 1))
+        return (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * two * sizeof(float) + (size_t)ksz * sizeof(float);
+    };
+    if (const char *ov = getenv("TF_IMG_TILES")) { // "level:TWo:THo,..." experiment override
+        for (const char *p = ov; p && *p;) {
+            int l = 0, a = 0, b = 0;
+            if (sscanf(p, "%d:%d:%d", &l, &a, &b) == 3 && l == level && fill(a, b) <= 64 * 1024)
+                return t;
+            p = strchr(p, ',');
+            if (p)
+                p++;
+        }
+    }
+    if (ksz > 5) {
+        // long kernels (measured on MI355X, tools/tile_sweep.sh): tiles spanning ~128 source columns,
+        // as many output rows as fill whole rounds of 64 staged rows (the row pass costs
+        // ceil(LH/64) lane-rounds per column group) within ~40 KB of LDS so several blocks share a CU
+        const size_t cap = std::min<size_t>(lds_cap, 40 * 1024);
+        int btw = 4;
+        while (btw * 2 <= std::max(4, 128 / s))
+            btw *= 2;
+        int bth = 1;
+        double best = 1e30;
+        for (int tho = 1; tho <= 32; tho++) {
+            size_t smem = fill(btw, tho);
+            if (smem > cap && tho > 1)
+                break;
+            double rounds = (double)((t.LH + 63) / 64) * 64 / tho; // lane-rows per output row
+            if (rounds <= best) {
+                best = rounds;
+                bth = tho;
+            }
+        }
+        fill(btw, bth);
+        return t;
+    }
+    int two = 8;
+    while (two * 2 <= std::min(128, 256 / s))
+        two *= 2;
+    int tho = std::max(2, std::min(32, 128 / s));
+    for (;;) {
+        size_t smem = fill(two, tho);
+        if (smem <= std::min<size_t>(lds_cap, 32 * 1024) || (two <= 2 && tho <= 1))
             break;
-        if (t.THo > 1 && (t.THo >= t.TWo / 4 || t.TWo <= 2))
-            t.THo = std::max(1, t.THo / 2);
+        if (tho > 1 && (tho >= two / 4 || two <= 2))
+            tho = std::max(1, tho / 2);
         else
-            t.TWo = std::max(2, t.TWo / 2);
+            two = std::max(2, two / 2);
     }
     return t;
 }
@@ -1577,7 +1619,10 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             return fail(set_error(TF_ERR_HIP, "hipMemcpy failed"));
         if ((rc = L->img_lerp.upload_tabs(width, height, L->W, L->H)))
             return fail(rc);
-        L->tile = choose_tile(width, height, L->W, L->H, L->ksz);
+        L->tile = choose_tile(width, height, L->W, L->H, L->ksz, k);
+        if (getenv("TF_DEBUG_TILES"))
+            fprintf(stderr, "level %d: %dx%d ksz=%d tile %dx%d LW=%d LH=%d pitch=%d\n", k, L->W, L->H, L->ksz,
+                    L->tile.TWo, L->tile.THo, L->tile.LW, L->tile.LH, L->tile.pitch);
         {
             size_t smem = (size_t)L->tile.LH * L->tile.pitch + (size_t)L->tile.LH * 2 * L->tile.TWo * sizeof(float) +
                           (size_t)L->ksz * sizeof(float);
