@@ -57,6 +57,9 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// REFLECT_101 when the overshoot is known to be smaller than the image (one reflection suffices)
+__device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
+
 // ---------------------------------------------------------------------------------
 // A1: level image = resize(GaussianBlur(float(frame)), level size), one kernel per level.
 // A block produces a tile of TWo x THo level pixels.  It stages the uint8 source region
@@ -70,6 +73,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // ---------------------------------------------------------------------------------
 struct ImgTile {
     int TWo, THo;           // output tile (TWo a power of two)
+    int tw_shift;           // log2(TWo)
+    int rstride;            // floats per staged row of the row-pass buffer: 2*TWo, or TWo for a copy-sized level
     int LW, LH;             // source columns / rows staged per tile (upper bounds)
     int pitch;              // bytes per staged source row, multiple of 4 with pitch/4 odd
     int same_size;          // level size == frame size: resize is a copy
@@ -104,7 +109,7 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     uint8_t *sS = s_raw;                                                     // [LH][pitch] source bytes
     float *sR = reinterpret_cast<float *>(s_raw + (size_t)tl.LH * tl.pitch); // [LH][2*TWo] row-pass values
-    float *sK = sR + (size_t)tl.LH * 2 * tl.TWo;                             // [ksz] blur taps
+    float *sK = sR + (size_t)tl.LH * tl.rstride;                             // [ksz] blur taps
     __shared__ int sX[128], sY[32];     // source column / row of each output column / row of the tile
     __shared__ float sFx[128], sFy[32]; // and the lerp fractions
     const int r = ksz >> 1;
@@ -145,6 +150,7 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
     // ---- phase 1: stage the source region.  Each wave owns rows wave, wave+4, ...; loads are
     // issued eight rows at a time so their latencies overlap.
     constexpr int U = 8;
+    const bool small_halo = r < H && r < W; // one reflection is enough
     const bool dwords = (W & 3) == 0 && x_lo >= 0 && x_lo + ((ncols + 3) & ~3) <= W;
     if (dwords) {
         const int nq = (ncols + 3) >> 2;
@@ -155,7 +161,8 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
                 for (int u = 0; u < U; u++) {
                     int ry = j0 + 4 * u;
                     if (ry < nrows)
-                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101(y_lo + ry, H) * W + x_lo + 4 * c);
+                        v[u] = *reinterpret_cast<const uint32_t *>(
+                            src + (size_t)(small_halo ? reflect101_once(y_lo + ry, H) : reflect101(y_lo + ry, H)) * W + x_lo + 4 * c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -225,7 +232,7 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (4 * b_ + j < no)
-                        sR[ry * (2 * tl.TWo) + 4 * b_ + j] = acc[j];
+                        sR[ry * tl.rstride + 4 * b_ + j] = acc[j];
             }
         }
     } else {
@@ -255,23 +262,24 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
                 for (; i < ksz; i++)
                     acc += sK[i] * (float)q[i];
             }
-            sR[ry * (2 * tl.TWo) + o] = acc;
+            sR[ry * tl.rstride + (tl.same_size ? (o >> 1) : o)] = acc;
         }
     }
     }
     __syncthreads();
     // ---- phase 3: column pass at the needed rows, then the lerps
     float *dst = img + (size_t)pi * Wk * Hk;
-    const int st = 2 * tl.TWo;
-    for (int idx = threadIdx.x; idx < ndy * tl.TWo; idx += blockDim.x) {
-        int ty = idx / tl.TWo, tx = idx - ty * tl.TWo; // TWo is a power of two
+    const int st = tl.rstride;
+    const int cs = tl.same_size ? 1 : 2; // row-pass slots per output column
+    for (int idx = threadIdx.x; idx < (ndy << tl.tw_shift); idx += blockDim.x) {
+        const int ty = idx >> tl.tw_shift, tx = idx & (tl.TWo - 1);
         if (tx >= ndx)
             continue;
         int dx = dx0 + tx, dy = dy0 + ty;
         const int sy = tl.same_size ? dy : sY[ty];
         int row0 = clampi(sy, 0, H - 1) - y_lo, row1 = clampi(sy + 1, 0, H - 1) - y_lo;
-        const float *c0 = sR + row0 * st + 2 * tx;
-        const float *c1 = sR + row1 * st + 2 * tx;
+        const float *c0 = sR + row0 * st + cs * tx;
+        const float *c1 = sR + row1 * st + cs * tx;
         float v00 = kc * c0[0];
         for (int i = 1; i <= r; i++)
             v00 += sK[r + i] * (c0[i * st] + c0[-i * st]);
@@ -1363,7 +1371,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs)
     Level &L = *fb->lv[k];
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
-    size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * t.TWo * sizeof(float) + (size_t)L.ksz * sizeof(float);
+    size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
     return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->img.as<float>(),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
@@ -1402,7 +1410,11 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz, int level)
         t.pitch = (t.LW + 3) & ~3;
         if (((t.pitch / 4) & 1) == 0)
             t.pitch += 4;
-        return (size_t)t.LH * t.pitch + (size_t)t.LH * 2 * two * sizeof(float) + (size_t)ksz * sizeof(float);
+        t.rstride = t.same_size ? two : 2 * two;
+        t.tw_shift = 0;
+        while ((1 << t.tw_shift) < two)
+            t.tw_shift++;
+        return (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)ksz * sizeof(float);
     };
     if (const char *ov = getenv("TF_IMG_TILES")) { // "level:TWo:THo,..." experiment override
         for (const char *p = ov; p && *p;) {
@@ -1624,7 +1636,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             fprintf(stderr, "level %d: %dx%d ksz=%d tile %dx%d LW=%d LH=%d pitch=%d\n", k, L->W, L->H, L->ksz,
                     L->tile.TWo, L->tile.THo, L->tile.LW, L->tile.LH, L->tile.pitch);
         {
-            size_t smem = (size_t)L->tile.LH * L->tile.pitch + (size_t)L->tile.LH * 2 * L->tile.TWo * sizeof(float) +
+            size_t smem = (size_t)L->tile.LH * L->tile.pitch + (size_t)L->tile.LH * L->tile.rstride * sizeof(float) +
                           (size_t)L->ksz * sizeof(float);
             if (smem > 64 * 1024)
                 return fail(set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: level %d needs %zu bytes of LDS per tile "
