@@ -117,6 +117,9 @@ int tf_fb_post_process_host(tf_fb *fb, float *flow_inout, int direction);   /* h
    R and M are [H][W][5] interleaved on the host side. */
 int tf_fb_stage_level_image(tf_fb *fb, const uint8_t *grey, ptrdiff_t stride, int level, float *out /*[Hk][Wk]*/);
 int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out /*[h][w][5]*/);
+/* A1 then A2 of one frame at one level, through whichever kernels the full path uses there
+   (level 0 runs them fused): r_out [Hk][Wk][5]. */
+int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t stride, int level, float *r_out);
 int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, const float *flow, int w, int h,
                                 float *m_out /*[h][w][5]*/);
 int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out /*[h][w][2]*/);

@@ -37,6 +37,19 @@ def test_level_images_bit_exact(FB, shape, levels):
     fb.close()
 
 
+@pytest.mark.parametrize("shape", [(270, 480), (135, 241), (33, 70), (1080, 1920)])
+@pytest.mark.parametrize("poly", [(5, 1.2), (7, 1.5), (3, 1.0)])
+def test_level_then_polyexp_bit_exact(FB, shape, poly):
+    """A1 followed by A2 through the kernels the full path uses (fused at level 0 for poly_n 5/7)."""
+    h, w = shape
+    a, _ = synth_pair(h, w, seed=13)
+    fb = FB(w, h, levels=2, poly_n=poly[0], poly_sigma=poly[1])
+    for k in range(len(fb.level_sizes())):
+        exp = O.polyexp(O.level_image(a, 0.5, k), *poly)
+        np.testing.assert_array_equal(fb.stage_level_polyexp(a, k), exp, err_msg=f"level {k}")
+    fb.close()
+
+
 @pytest.mark.parametrize("shape", [(64, 64), (67, 131), (16, 200), (270, 480), (5, 7)])
 @pytest.mark.parametrize("poly", [(5, 1.2), (7, 1.5), (3, 0.0)])
 def test_polyexp_bit_exact(FB, shape, poly):

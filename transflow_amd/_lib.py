@@ -73,6 +73,7 @@ PROTOTYPES = {
     "tf_fb_post_process_host": (_I, [_P, _P, _I]),
     "tf_fb_stage_level_image": (_I, [_P, _P, C.c_ssize_t, _I, _P]),
     "tf_fb_stage_polyexp": (_I, [_P, _P, _I, _I, _P]),
+    "tf_fb_stage_level_polyexp": (_I, [_P, _P, C.c_ssize_t, _I, _P]),
     "tf_fb_stage_update_matrices": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "tf_fb_stage_blur_solve": (_I, [_P, _P, _I, _I, _P]),
     "tf_fb_level_count": (_I, [_P, _PI]),

@@ -495,6 +495,180 @@ k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk
     }
 }
 
+// A1+A2 fused for the full-resolution level (resize is a copy, the blur has 3 taps): the level
+// image never leaves the CU.  Stages the u8 region by REAL image coordinates (REFLECT_101 ring of
+// one pixel), blurs it into LDS exactly as k_level_image does (row pass, then column pass), then
+// runs k_polyexp_t's two passes, reading the blurred tile with CLAMPED coordinates (OpenCV's
+// polynomial expansion replicates edge rows/columns of the already blurred image).
+template <int N>
+__global__ void __launch_bounds__(256)
+k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ R, int W,
+                   int H, float kc, float k1, PolyConst pc)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 2 * N, LH = TH + 2 * N; // blurred tile (virtual extent)
+    constexpr int SW = ((LW + 2 + 3 + 3) + 3) & ~3, SH = LH + 2; // staged bytes: one more pixel all round, dword slack
+    // LDS: the staged bytes and the row-pass values are dead once the blurred tile exists, so the
+    // three planes of the expansion's vertical pass reuse their space
+    constexpr int BYTES_A = SH * SW + SH * LW * 4, BYTES_T = 3 * TH * LW * 4;
+    constexpr int BYTES_U = ((BYTES_A > BYTES_T ? BYTES_A : BYTES_T) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) uint8_t s_u[BYTES_U];
+    __shared__ float sI[LH * LW]; // blurred level image, indexed by real coordinate offsets
+    uint8_t *sS = s_u;                                          // [SH][SW] staged bytes
+    float *sRow = reinterpret_cast<float *>(s_u + SH * SW);     // [SH][LW] row-pass values, rows yr0-1 .. yr1+1
+    float(*sT)[TH][LW] = reinterpret_cast<float(*)[TH][LW]>(s_u); // [3][TH][LW], after the blur
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const size_t Nk = (size_t)W * H;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // real image region the tile's (clamped) reads touch
+    const int xr0 = max(x0 - N, 0), xr1 = min(x0 + TW - 1 + N, W - 1);
+    const int yr0 = max(y0 - N, 0), yr1 = min(y0 + TH - 1 + N, H - 1);
+    const int nx = xr1 - xr0 + 1, ny = yr1 - yr0 + 1;
+    // stage bytes for columns xr0-1 .. xr1+1, rows yr0-1 .. yr1+1 (reflected outside the image);
+    // the staged columns start at a multiple of 4 so interior tiles copy dwords
+    const int xs = (xr0 - 1) & ~3, off = xr0 - 1 - xs; // column xr0-1 sits at byte `off` of a staged row
+    const int ncols = xr1 + 1 - xs + 1;
+    const bool dwords = (W & 3) == 0 && xs >= 0 && xs + ((ncols + 3) & ~3) <= W;
+    constexpr int U = 8;
+    if (dwords) {
+        const int nq = (ncols + 3) >> 2;
+        for (int c = lane; c < nq; c += 64) {
+            for (int j0 = wave; j0 < ny + 2; j0 += 4 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101(yr0 - 1 + ry, H) * W + xs + 4 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        *reinterpret_cast<uint32_t *>(sS + ry * SW + 4 * c) = v[u];
+                }
+            }
+        }
+    } else {
+        for (int c = lane; c < ncols; c += 64) {
+            const int x = reflect101(xs + c, W);
+            for (int j0 = wave; j0 < ny + 2; j0 += 4 * U) {
+                uint8_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        v[u] = src[(size_t)reflect101(yr0 - 1 + ry, H) * W + x];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        sS[ry * SW + c] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // row pass (tap order of k_level_image, ksz == 3)
+    for (int idx = threadIdx.x; idx < (ny + 2) * LW; idx += 256) {
+        int ry = idx / LW, cx = idx - ry * LW;
+        if (cx < nx) {
+            const uint8_t *p = sS + ry * SW + off + cx + 1;
+            sRow[idx] = (float)p[0] * kc + ((float)p[-1] + (float)p[1]) * k1;
+        }
+    }
+    __syncthreads();
+    // column pass -> blurred image at real coordinates (xr0 + cx, yr0 + ry)
+    for (int idx = threadIdx.x; idx < ny * LW; idx += 256) {
+        int ry = idx / LW, cx = idx - ry * LW;
+        if (cx < nx) {
+            const float *c = sRow + (ry + 1) * LW + cx;
+            float v = kc * c[0];
+            v += k1 * (c[LW] + c[-LW]);
+            sI[idx] = v;
+        }
+    }
+    __syncthreads();
+    // polynomial expansion, vertical pass: virtual row y0-N+j reads real row clamp(...) - yr0
+    for (int idx = threadIdx.x; idx < (TH / 4) * LW; idx += 256) {
+        const int g = idx / LW, cx = idx - g * LW;
+        const int xc = clampi(x0 - N + cx, 0, W - 1) - xr0;
+        float v[4 + 2 * N];
+#pragma unroll
+        for (int j = 0; j < 4 + 2 * N; j++)
+            v[j] = sI[(clampi(y0 - N + 4 * g + j, 0, H - 1) - yr0) * LW + xc];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float c = v[q + N];
+            float t0 = c * pc.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                float a = v[q + N - k], b = v[q + N + k];
+                float p = a + b;
+                t0 = t0 + pc.g[k] * p;
+                t1 = t1 + pc.xg[k] * (b - a);
+                t2 = t2 + pc.xxg[k] * p;
+            }
+            sT[0][4 * g + q][cx] = t0;
+            sT[1][4 * g + q][cx] = t1;
+            sT[2][4 * g + q][cx] = t2;
+        }
+    }
+    __syncthreads();
+    float *dst = R + (size_t)pi * 5 * Nk;
+    for (int idx = threadIdx.x; idx < TH * (TW / 2); idx += 256) {
+        const int ty = idx / (TW / 2), cp = idx - ty * (TW / 2);
+        const int x = x0 + 2 * cp, y = y0 + ty;
+        if (x >= W || y >= H)
+            continue;
+        float w0[2 + 2 * N], w1[2 + 2 * N], w2[2 + 2 * N];
+#pragma unroll
+        for (int j = 0; j < 2 + 2 * N; j++) {
+            w0[j] = sT[0][ty][2 * cp + j];
+            w1[j] = sT[1][ty][2 * cp + j];
+            w2[j] = sT[2][ty][2 * cp + j];
+        }
+        float out[2][5];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float *T0 = w0 + q + N, *T1 = w1 + q + N, *T2 = w2 + q + N;
+            float g0 = pc.g[0];
+            double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                double tg = T0[k] + T0[-k];
+                g0 = pc.g[k];
+                b1 += tg * g0;
+                b4 += tg * pc.xxg[k];
+                b2 += (T0[k] - T0[-k]) * pc.xg[k];
+                b3 += (T1[k] + T1[-k]) * g0;
+                b6 += (T1[k] - T1[-k]) * pc.xg[k];
+                b5 += (T2[k] + T2[-k]) * g0;
+            }
+            out[q][0] = (float)(b3 * pc.ig11);
+            out[q][1] = (float)(b2 * pc.ig11);
+            out[q][2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            out[q][3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            out[q][4] = (float)(b6 * pc.ig55);
+        }
+        const size_t o = (size_t)y * W + x;
+        if (x + 1 < W) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                float2w v2 = {out[0][c], out[1][c]};
+                *reinterpret_cast<float2w *>(dst + c * Nk + o) = v2;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                dst[c * Nk + o] = out[0][c];
+        }
+    }
+}
+
 // OpenCV's border down-weighting table {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance d to an
 // edge (1 beyond 5 px), as selects instead of a memory table: a table lookup is a global load,
 // and its wait would drain every prefetched gather
@@ -1323,6 +1497,7 @@ struct Level {
     int W, H, ksz;
     double sigma;
     ImgTile tile;
+    std::vector<float> kern_host;
     DevBuf kern;
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
     LerpDev flow_lerp; // level k+1 -> this level
@@ -1480,6 +1655,29 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
                   (const float *)fb->img.as<float>(), fb->R.as<float>(), w, h, fb->pc);
 }
 
+// A1+A2 fusion applies to a level that is a copy-sized resize of the frame with the 3-tap blur
+// (level 0 of every pyramid) and a poly_n the blocked expansion is instantiated for.
+static bool fb_can_fuse_level(tf_fb *fb, int k)
+{
+    static const bool off = getenv("TF_FB_NO_A1A2") && atoi(getenv("TF_FB_NO_A1A2")) != 0;
+    const Level &L = *fb->lv[k];
+    return !off && L.W == fb->W && L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
+}
+
+static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
+{
+    Level &L = *fb->lv[k];
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
+    const float kc = L.kern_host[1], k1 = L.kern_host[2];
+    if (fb->pc.n == 5)
+        return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
+                      (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->R.as<float>(),
+                      L.W, L.H, kc, k1, fb->pc);
+    return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), 0,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->R.as<float>(), L.W,
+                  L.H, kc, k1, fb->pc);
+}
+
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
     dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
@@ -1625,6 +1823,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         if (L->W < 1 || L->H < 1)
             return fail(set_error(TF_ERR_ARG, "tf_fb_create: level %d is empty", k));
         std::vector<float> kern = gaussian_kernel(L->ksz, L->sigma);
+        L->kern_host = kern;
         if ((rc = L->kern.alloc(kern.size() * 4)))
             return fail(rc);
         if (hipMemcpy(L->kern.p, kern.data(), kern.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -1717,8 +1916,12 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     int coarse = -1; // lflow buffer holding the coarser level's result
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
-        TF_TRY(fb_level_image(fb, k, n_pairs));
-        TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
+        if (fb_can_fuse_level(fb, k)) {
+            TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
+        } else {
+            TF_TRY(fb_level_image(fb, k, n_pairs));
+            TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
+        }
         FlowInit fi;
         memset(&fi, 0, sizeof(fi));
         if (k < fb->K) {
@@ -1883,6 +2086,23 @@ static int download_planar5(float *host_interleaved, const float *src_planar, si
     TF_HIP(hipMemcpyAsync(host_interleaved, staging.p, n * 20, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
     return TF_OK;
+}
+
+TF_API int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t stride, int level, float *r_out)
+{
+    TF_REQUIRE(fb && grey && r_out, "tf_fb_stage_level_polyexp: null pointer");
+    TF_REQUIRE(level >= 0 && level <= fb->K, "tf_fb_stage_level_polyexp: level %d out of range", level);
+    TF_TRY(tf_fb_set_frame(fb, 0, grey, stride));
+    int2 pr = make_int2(0, 0);
+    TF_HIP(hipMemcpy(fb->pairs.p, &pr, 8, hipMemcpyHostToDevice));
+    Level &L = *fb->lv[level];
+    if (fb_can_fuse_level(fb, level)) {
+        TF_TRY(fb_level0_polyexp(fb, level, 1));
+    } else {
+        TF_TRY(fb_level_image(fb, level, 1));
+        TF_TRY(fb_polyexp(fb, L.W, L.H, 2, level));
+    }
+    return download_planar5(r_out, fb->R.as<float>(), (size_t)L.W * L.H, fb->scratch);
 }
 
 TF_API int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out)

@@ -119,6 +119,13 @@ class Farneback:
         check(self._lib.tf_fb_stage_level_image(self._h, _ptr(a), a.strides[0], int(level), _ptr(out)))
         return out
 
+    def stage_level_polyexp(self, frame, level: int) -> np.ndarray:
+        a = self._grey(frame)
+        w, h = self.level_sizes()[level]
+        out = np.empty((h, w, 5), np.float32)
+        check(self._lib.tf_fb_stage_level_polyexp(self._h, _ptr(a), a.strides[0], int(level), _ptr(out)))
+        return out
+
     def stage_polyexp(self, img) -> np.ndarray:
         img = np.ascontiguousarray(img, np.float32)
         h, w = img.shape
