@@ -57,6 +57,19 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Blocks are dealt round-robin over the 8 XCDs, each with its own L2 (MI355X_MICROARCH.md, dispatch):
+// renumber the blocks of a 2-D grid so that one XCD walks a contiguous raster range of tiles and
+// spatial neighbours (shared halo columns, shared rows, the cache line a misaligned strip spills
+// into) meet in the same L2.  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ void xcd_tile(unsigned &bx, unsigned &by)
+{
+    const unsigned nt = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = bid & 7, qn = nt >> 3, rn = nt & 7;
+    const unsigned t = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    bx = t % gridDim.x;
+    by = t / gridDim.x;
+}
+
 // REFLECT_101 when the overshoot is known to be smaller than the image (one reflection suffices)
 __device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
 
@@ -758,8 +771,11 @@ k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, in
     // block's neighbouring output rows.  Measured R1 traffic model: 20 B x (rows+1)/rows x
     // (lines+1)/lines of a flow-shifted 256-byte row segment (profiles/README.md); 128x8 tiles were
     // measured and bring nothing more
-    int x = blockIdx.x * UM_TW + (threadIdx.x & (UM_TW - 1));
-    int y = blockIdx.y * UM_TH + threadIdx.x / UM_TW;
+    // XCD-aware tile order: vertically adjacent tiles (which share R1 rows) meet in one L2
+    unsigned bx, by;
+    xcd_tile(bx, by);
+    int x = bx * UM_TW + (threadIdx.x & (UM_TW - 1));
+    int y = by * UM_TH + threadIdx.x / UM_TW;
     if (x >= Wk || y >= Hk)
         return;
     const int pair = blockIdx.z;
@@ -888,11 +904,13 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
     const int lane = threadIdx.x;
-    const int c0 = blockIdx.x * OUTC - HALO + 2 * lane;
+    unsigned bx, by;
+    xcd_tile(bx, by);
+    const int c0 = bx * OUTC - HALO + 2 * lane;
     const int pair = blockIdx.z;
     const size_t Nk = (size_t)Wk * Hk;
     const float *Mi = Min + (size_t)pair * 5 * Nk;
-    const int r0 = blockIdx.y * seg, r1 = min(r0 + seg, Hk);
+    const int r0 = by * seg, r1 = min(r0 + seg, Hk);
     // VEC: the whole strip lies inside the image (wave-uniform), so every lane loads its two
     // columns with one 8-byte load; otherwise two clamped scalar loads (replicated border)
     const int ca = clampi(c0, 0, Wk - 1), cb = clampi(c0 + 1, 0, Wk - 1);
@@ -998,7 +1016,9 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
     __shared__ double s_e[5][64], s_o[5][64], s_p[5][64];
-    const int first = (int)blockIdx.x * OUTC - HALO;
+    unsigned bx, by;
+    xcd_tile(bx, by);
+    const int first = (int)bx * OUTC - HALO;
     if (first >= 0 && first + 127 < Wk)
         blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o, s_p);
     else
