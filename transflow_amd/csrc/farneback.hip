@@ -40,6 +40,10 @@ constexpr int MAX_POLY_N = 15;
 // two floats at 4-byte alignment: one global_load_dwordx2 (the hardware takes unaligned dwordx2)
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
+#ifndef BLUR_PREFETCH
+#define BLUR_PREFETCH 3 // rows of M kept in flight per wave in the blur march (2: 1219 us, 3: 1177, 4: 1225 at 4K x16)
+#endif
+
 struct PolyConst {
     int n;
     float g[MAX_POLY_N + 1], xg[MAX_POLY_N + 1], xxg[MAX_POLY_N + 1];
@@ -762,9 +766,101 @@ struct FlowInit {
     float mul;
 };
 
-constexpr int UM_TW = 64, UM_TH = 4;
+struct GatherRegs {
+    float2 r0[5];   // R0 at the two pixels, per channel (x: first pixel, y: second)
+    float2 t[2][5]; // R1 pair (x1, x1+1) on row y1, per pixel and channel
+    float2 b[2][5]; // R1 pair on row y1+1
+    float dx[2], dy[2], fx[2], fy[2];
+    bool inb[2];
+};
 
-__global__ void __launch_bounds__(UM_TW *UM_TH)
+// loads for the matrices of pixels (xa, y) and (xb, y); flow already known
+__device__ __forceinline__ void gather_issue(GatherRegs &g, const float *__restrict__ R0, const float *__restrict__ R1,
+                                             size_t Nk, int Wk, int Hk, int xa, int xb, int y, float2 fa, float2 fb)
+{
+    const int xs[2] = {xa, xb};
+    const float2 fl[2] = {fa, fb};
+    const size_t oa = (size_t)y * Wk + xa, ob = (size_t)y * Wk + xb;
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        g.r0[c] = make_float2(R0[c * Nk + oa], R0[c * Nk + ob]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        float dx = fl[j].x, dy = fl[j].y;
+        float fx = xs[j] + dx, fy = y + dy;
+        int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+        fx -= x1;
+        fy -= y1;
+        g.dx[j] = dx;
+        g.dy[j] = dy;
+        g.fx[j] = fx;
+        g.fy[j] = fy;
+        g.inb[j] = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
+        // out-of-frame taps load from a clamped (valid) address and are discarded: no branch
+        // around the loads, so they all stay in flight together
+        int x1c = clampi(x1, 0, Wk - 2), y1c = clampi(y1, 0, Hk - 2);
+        const float *rp = R1 + (size_t)y1c * Wk + x1c;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            float2u tv = *reinterpret_cast<const float2u *>(rp + c * Nk);
+            float2u bv = *reinterpret_cast<const float2u *>(rp + c * Nk + Wk);
+            g.t[j][c] = make_float2(tv.x, tv.y);
+            g.b[j][c] = make_float2(bv.x, bv.y);
+        }
+    }
+}
+
+// the arithmetic of update_matrix_px on the gathered values; m[j][5] for the two pixels
+__device__ __forceinline__ void gather_finish(const GatherRegs &g, int Wk, int Hk, int xa, int xb, int y,
+                                              float m[2][5])
+{
+    const int xs[2] = {xa, xb};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int x = xs[j];
+        const float R00 = j ? g.r0[0].y : g.r0[0].x, R01 = j ? g.r0[1].y : g.r0[1].x, R02 = j ? g.r0[2].y : g.r0[2].x,
+                    R03 = j ? g.r0[3].y : g.r0[3].x, R04 = j ? g.r0[4].y : g.r0[4].x;
+        const float fx = g.fx[j], fy = g.fy[j], dx = g.dx[j], dy = g.dy[j];
+        float r2, r3, r4, r5, r6;
+        if (g.inb[j]) {
+            float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+            r2 = a00 * g.t[j][0].x + a01 * g.t[j][0].y + a10 * g.b[j][0].x + a11 * g.b[j][0].y;
+            r3 = a00 * g.t[j][1].x + a01 * g.t[j][1].y + a10 * g.b[j][1].x + a11 * g.b[j][1].y;
+            r4 = a00 * g.t[j][2].x + a01 * g.t[j][2].y + a10 * g.b[j][2].x + a11 * g.b[j][2].y;
+            r5 = a00 * g.t[j][3].x + a01 * g.t[j][3].y + a10 * g.b[j][3].x + a11 * g.b[j][3].y;
+            r6 = a00 * g.t[j][4].x + a01 * g.t[j][4].y + a10 * g.b[j][4].x + a11 * g.b[j][4].y;
+            r4 = (R02 + r4) * 0.5f;
+            r5 = (R03 + r5) * 0.5f;
+            r6 = (R04 + r6) * 0.25f;
+        } else {
+            r2 = r3 = 0.f;
+            r4 = R02;
+            r5 = R03;
+            r6 = R04 * 0.5f;
+        }
+        r2 = (R00 - r2) * 0.5f;
+        r3 = (R01 - r3) * 0.5f;
+        r2 += r4 * dy + r6 * dx;
+        r3 += r6 * dy + r5 * dx;
+        {
+            float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
+            r2 *= scale;
+            r3 *= scale;
+            r4 *= scale;
+            r5 *= scale;
+            r6 *= scale;
+        }
+        m[j][0] = r4 * r4 + r6 * r6;
+        m[j][1] = (r4 + r5) * r6;
+        m[j][2] = r5 * r5 + r6 * r6;
+        m[j][3] = r4 * r2 + r6 * r3;
+        m[j][4] = r6 * r2 + r5 * r3;
+    }
+}
+
+constexpr int UM_TW = 128, UM_TH = 4; // tile: 128 columns x 4 rows, 256 threads, two pixels each
+
+__global__ void __launch_bounds__(256)
 k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, int Hk, FlowInit fi)
 {
     // 256 threads = 64 columns x 4 rows: the two R1 rows a bilinear tap straddles are shared by the
@@ -774,44 +870,66 @@ k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, in
     // XCD-aware tile order: vertically adjacent tiles (which share R1 rows) meet in one L2
     unsigned bx, by;
     xcd_tile(bx, by);
-    int x = bx * UM_TW + (threadIdx.x & (UM_TW - 1));
-    int y = by * UM_TH + threadIdx.x / UM_TW;
-    if (x >= Wk || y >= Hk)
+    // a thread owns two pixels of one row, 64 columns apart (both halves of a 128-column tile row
+    // are coalesced), and gathers for both with every load in flight at once
+    const int xa = bx * UM_TW + (threadIdx.x & 63), xb = xa + 64;
+    const int y = by * UM_TH + (threadIdx.x >> 6);
+    if (xa >= Wk || y >= Hk)
         return;
+    const bool has_b = xb < Wk;
+    const int xbc = has_b ? xb : xa;
     const int pair = blockIdx.z;
     const size_t Nk = (size_t)Wk * Hk;
-    float dx = 0.f, dy = 0.f;
+    float2 fa = make_float2(0.f, 0.f), fb = fa;
     if (fi.mode == 1) {
         const float2 *c = fi.src + (size_t)pair * fi.Wc * fi.Hc;
-        int sx = fi.xofs[x], sy = fi.yofs[y];
-        float fx = fi.xfrac[x], fy = fi.yfrac[y];
-        int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
-        float2 h0, h1;
-        if (sx >= fi.Wc - 1) {
-            h0 = c[(size_t)sy0 * fi.Wc + sx];
-            h1 = c[(size_t)sy1 * fi.Wc + sx];
-        } else {
-            float2 a = c[(size_t)sy0 * fi.Wc + sx], b = c[(size_t)sy0 * fi.Wc + sx + 1];
-            float2 d = c[(size_t)sy1 * fi.Wc + sx], e = c[(size_t)sy1 * fi.Wc + sx + 1];
-            float a0 = 1.f - fx;
-            h0 = make_float2(a.x * a0 + b.x * fx, a.y * a0 + b.y * fx);
-            h1 = make_float2(d.x * a0 + e.x * fx, d.y * a0 + e.y * fx);
+        const int sy = fi.yofs[y];
+        const float fy = fi.yfrac[y], b0 = 1.f - fy;
+        const int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
+        const int xs[2] = {xa, xbc};
+        float2 res[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int sx = fi.xofs[xs[j]];
+            const float fx = fi.xfrac[xs[j]];
+            const int sx1 = min(sx + 1, fi.Wc - 1);
+            float2 a = c[(size_t)sy0 * fi.Wc + sx], b = c[(size_t)sy0 * fi.Wc + sx1];
+            float2 d = c[(size_t)sy1 * fi.Wc + sx], e = c[(size_t)sy1 * fi.Wc + sx1];
+            float2 h0, h1;
+            if (sx >= fi.Wc - 1) { // resize.cpp: columns past xmax copy S[sx]
+                h0 = a;
+                h1 = d;
+            } else {
+                float a0 = 1.f - fx;
+                h0 = make_float2(a.x * a0 + b.x * fx, a.y * a0 + b.y * fx);
+                h1 = make_float2(d.x * a0 + e.x * fx, d.y * a0 + e.y * fx);
+            }
+            res[j] = make_float2((h0.x * b0 + h1.x * fy) * fi.mul, (h0.y * b0 + h1.y * fy) * fi.mul);
         }
-        float b0 = 1.f - fy;
-        dx = (h0.x * b0 + h1.x * fy) * fi.mul;
-        dy = (h0.y * b0 + h1.y * fy) * fi.mul;
+        fa = res[0];
+        fb = res[1];
     } else if (fi.mode == 2) {
-        float2 f = fi.src[(size_t)pair * Nk + (size_t)y * Wk + x];
-        dx = f.x;
-        dy = f.y;
+        const float2 *f = fi.src + (size_t)pair * Nk + (size_t)y * Wk;
+        fa = f[xa];
+        fb = f[xbc];
     }
     const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
-    float m[5];
-    update_matrix_px(R0, R1, Nk, Wk, Hk, x, y, dx, dy, m);
-    float *Mo = M + (size_t)pair * 5 * Nk + (size_t)y * Wk + x;
+    float m[2][5];
+    if (Wk >= 2 && Hk >= 2) {
+        GatherRegs g;
+        gather_issue(g, R0, R1, Nk, Wk, Hk, xa, xbc, y, fa, fb);
+        gather_finish(g, Wk, Hk, xa, xbc, y, m);
+    } else { // degenerate one-pixel-wide levels: no in-frame bilinear cell exists
+        update_matrix_px(R0, R1, Nk, Wk, Hk, xa, y, fa.x, fa.y, m[0]);
+        update_matrix_px(R0, R1, Nk, Wk, Hk, xbc, y, fb.x, fb.y, m[1]);
+    }
+    float *Mo = M + (size_t)pair * 5 * Nk + (size_t)y * Wk;
 #pragma unroll
-    for (int c = 0; c < 5; c++)
-        Mo[c * Nk] = m[c];
+    for (int c = 0; c < 5; c++) {
+        Mo[c * Nk + xa] = m[0][c];
+        if (has_b)
+            Mo[c * Nk + xb] = m[1][c];
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -943,23 +1061,32 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
             vs[c][1] += (double)v[c].y;
         }
     }
-    float2 nin[5], nout[5]; // rows entering / leaving the window at the NEXT step
-    if (r0 + 1 < r1) {
-        load_row(min(r0 + 1 + M, Hk - 1), nin);
-        load_row(max(r0 - M, 0), nout);
+    // rows entering / leaving the window, prefetched PD steps ahead (slot t % PD serves step
+    // r0+1+t); always loaded from clamped row indices, so no branch surrounds a load
+    constexpr int PD = BLUR_PREFETCH;
+    float2 pin[PD][5], pout[PD][5];
+#pragma unroll
+    for (int t = 0; t < PD; t++) {
+        load_row(min(r0 + 1 + t + M, Hk - 1), pin[t]);
+        load_row(clampi(r0 + t - M, 0, Hk - 1), pout[t]);
     }
     const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
-    for (int y = r0; y < r1; y++) {
+    for (int yb = r0; yb < r1; yb += PD) {
+#pragma unroll
+      for (int h = 0; h < PD; h++) {
+        const int y = yb + h;
+        if (y >= r1)
+            break;
         if (y > r0) {
+            float2(&in)[5] = pin[(h + PD - 1) % PD];
+            float2(&out)[5] = pout[(h + PD - 1) % PD];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                vs[c][0] += (double)nin[c].x - (double)nout[c].x;
-                vs[c][1] += (double)nin[c].y - (double)nout[c].y;
+                vs[c][0] += (double)in[c].x - (double)out[c].x;
+                vs[c][1] += (double)in[c].y - (double)out[c].y;
             }
-            if (y + 1 < r1) {
-                load_row(min(y + 1 + M, Hk - 1), nin);
-                load_row(max(y - M, 0), nout);
-            }
+            load_row(min(y + PD + M, Hk - 1), in);                // step y+PD: entering row
+            load_row(clampi(y + PD - 1 - M, 0, Hk - 1), out);     //            leaving row
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1006,11 +1133,12 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                 o[1] = f1;
         }
         __syncthreads(); // the next row's writes must not overtake this row's reads
+      }
     }
 }
 
 template <int M>
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, 3)
 k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, double scale, int seg)
 {
     constexpr int HALO = (M + 1) & ~1;
@@ -1068,98 +1196,6 @@ __global__ void k_flow_upsample(float2 *__restrict__ dst, int Wk, int Hk, FlowIn
 // and iteration: R0 20 B + R1 gather + flow in/out 16 B, instead of writing M (20 B) and
 // reading it back twice (40 B).
 // ---------------------------------------------------------------------------------
-struct GatherRegs {
-    float2 r0[5];   // R0 at the two pixels, per channel (x: first pixel, y: second)
-    float2 t[2][5]; // R1 pair (x1, x1+1) on row y1, per pixel and channel
-    float2 b[2][5]; // R1 pair on row y1+1
-    float dx[2], dy[2], fx[2], fy[2];
-    bool inb[2];
-};
-
-// loads for the matrices of pixels (xa, y) and (xb, y); flow already known
-__device__ __forceinline__ void gather_issue(GatherRegs &g, const float *__restrict__ R0, const float *__restrict__ R1,
-                                             size_t Nk, int Wk, int Hk, int xa, int xb, int y, float2 fa, float2 fb)
-{
-    const int xs[2] = {xa, xb};
-    const float2 fl[2] = {fa, fb};
-    const size_t oa = (size_t)y * Wk + xa, ob = (size_t)y * Wk + xb;
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-        g.r0[c] = make_float2(R0[c * Nk + oa], R0[c * Nk + ob]);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        float dx = fl[j].x, dy = fl[j].y;
-        float fx = xs[j] + dx, fy = y + dy;
-        int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-        fx -= x1;
-        fy -= y1;
-        g.dx[j] = dx;
-        g.dy[j] = dy;
-        g.fx[j] = fx;
-        g.fy[j] = fy;
-        g.inb[j] = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
-        // out-of-frame taps load from a clamped (valid) address and are discarded: no branch
-        // around the loads, so they all stay in flight together
-        int x1c = clampi(x1, 0, Wk - 2), y1c = clampi(y1, 0, Hk - 2);
-        const float *rp = R1 + (size_t)y1c * Wk + x1c;
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            float2u tv = *reinterpret_cast<const float2u *>(rp + c * Nk);
-            float2u bv = *reinterpret_cast<const float2u *>(rp + c * Nk + Wk);
-            g.t[j][c] = make_float2(tv.x, tv.y);
-            g.b[j][c] = make_float2(bv.x, bv.y);
-        }
-    }
-}
-
-// the arithmetic of update_matrix_px on the gathered values; m[j][5] for the two pixels
-__device__ __forceinline__ void gather_finish(const GatherRegs &g, int Wk, int Hk, int xa, int xb, int y,
-                                              float m[2][5])
-{
-    const int xs[2] = {xa, xb};
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int x = xs[j];
-        const float R00 = j ? g.r0[0].y : g.r0[0].x, R01 = j ? g.r0[1].y : g.r0[1].x, R02 = j ? g.r0[2].y : g.r0[2].x,
-                    R03 = j ? g.r0[3].y : g.r0[3].x, R04 = j ? g.r0[4].y : g.r0[4].x;
-        const float fx = g.fx[j], fy = g.fy[j], dx = g.dx[j], dy = g.dy[j];
-        float r2, r3, r4, r5, r6;
-        if (g.inb[j]) {
-            float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-            r2 = a00 * g.t[j][0].x + a01 * g.t[j][0].y + a10 * g.b[j][0].x + a11 * g.b[j][0].y;
-            r3 = a00 * g.t[j][1].x + a01 * g.t[j][1].y + a10 * g.b[j][1].x + a11 * g.b[j][1].y;
-            r4 = a00 * g.t[j][2].x + a01 * g.t[j][2].y + a10 * g.b[j][2].x + a11 * g.b[j][2].y;
-            r5 = a00 * g.t[j][3].x + a01 * g.t[j][3].y + a10 * g.b[j][3].x + a11 * g.b[j][3].y;
-            r6 = a00 * g.t[j][4].x + a01 * g.t[j][4].y + a10 * g.b[j][4].x + a11 * g.b[j][4].y;
-            r4 = (R02 + r4) * 0.5f;
-            r5 = (R03 + r5) * 0.5f;
-            r6 = (R04 + r6) * 0.25f;
-        } else {
-            r2 = r3 = 0.f;
-            r4 = R02;
-            r5 = R03;
-            r6 = R04 * 0.5f;
-        }
-        r2 = (R00 - r2) * 0.5f;
-        r3 = (R01 - r3) * 0.5f;
-        r2 += r4 * dy + r6 * dx;
-        r3 += r6 * dy + r5 * dx;
-        {
-            float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
-            r2 *= scale;
-            r3 *= scale;
-            r4 *= scale;
-            r5 *= scale;
-            r6 *= scale;
-        }
-        m[j][0] = r4 * r4 + r6 * r6;
-        m[j][1] = (r4 + r5) * r6;
-        m[j][2] = r5 * r5 + r6 * r6;
-        m[j][3] = r4 * r2 + r6 * r3;
-        m[j][4] = r6 * r2 + r5 * r3;
-    }
-}
-
 template <int M, bool HAVE_FLOW>
 __global__ void __launch_bounds__(64)
 k_flow_iter(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
@@ -1701,7 +1737,7 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
     dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
-    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(UM_TW * UM_TH), 0, (const float *)fb->R.as<float>(),
+    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->R.as<float>(),
                   fb->M[mbuf].as<float>(), w, h, fi);
 }
 
