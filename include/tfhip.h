@@ -112,6 +112,22 @@ int tf_fb_flow_ptr(tf_fb *fb, int pair, void **dev);
 int tf_fb_post_process(tf_fb *fb, int pair, int direction);                 /* device flow of `pair` */
 int tf_fb_post_process_host(tf_fb *fb, float *flow_inout, int direction);   /* host array, same H,W */
 
+/* The optional pre-steps of post_process (source.py:339-345), applied before the direction
+   handling: flow filters `scale`, `threshold`, `clip` (transflow/flow/filters.py:36-72) with the
+   value the filter's lambda returned for this frame, then the flow mask multiply.  `wide` tells
+   how numpy typed that value: 0 = Python float/int (NEP 50 weak scalar: arithmetic in float32),
+   1 = numpy.float64 (arithmetic in float64, result cast to float32).  mask: float32 [H][W] or NULL. */
+typedef enum tf_flow_op_kind { TF_FLOW_SCALE = 0, TF_FLOW_THRESHOLD = 1, TF_FLOW_CLIP = 2 } tf_flow_op_kind;
+typedef struct tf_flow_op {
+    int kind;
+    int wide;
+    double value;
+} tf_flow_op;
+#define TF_MAX_FLOW_OPS 8
+int tf_fb_post_process_ex(tf_fb *fb, int pair, int direction, int n_ops, const tf_flow_op *ops, const void *mask_dev);
+int tf_fb_post_process_host_ex(tf_fb *fb, float *flow_inout, int direction, int n_ops, const tf_flow_op *ops,
+                               const float *mask); /* direction -1: pre-steps only */
+
 /* Stage-level entry points (debug/parity tests): run one stage of the pyramid on
    host arrays with exactly the kernels the full path uses.  Layouts as OpenCV's:
    R and M are [H][W][5] interleaved on the host side. */

@@ -69,6 +69,49 @@ def post_process(flow: np.ndarray, direction: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
+# N1  optional pre-steps of post_process: filters and mask
+#     transflow/flow/filters.py:36-72, transflow/flow/sources/source.py:339-343
+# --------------------------------------------------------------------------
+def _pair_norm(flow: np.ndarray) -> np.ndarray:
+    """numpy.linalg.norm(flow.reshape(N, 2), axis=1) for float32: sqrt(x*x + y*y) in float32."""
+    x, y = flow[:, :, 0], flow[:, :, 1]
+    return np.sqrt(x * x + y * y)
+
+
+def filter_scale(flow: np.ndarray, value) -> None:
+    """filters.py:41-42, in place.  `value` keeps its Python/numpy type: a Python float is a weak
+    scalar (float32 arithmetic), a numpy.float64 is not (float64 arithmetic, cast back)."""
+    flow *= value
+
+
+def filter_threshold(flow: np.ndarray, value) -> None:
+    """filters.py:50-55, in place."""
+    flow[_pair_norm(flow) <= value] = 0
+
+
+def filter_clip(flow: np.ndarray, value) -> None:
+    """filters.py:63-71, in place: float64 factors (1 below the threshold), value/norm above."""
+    norm = _pair_norm(flow)
+    factors = np.ones(norm.shape)
+    hit = norm >= value
+    factors[hit] = value / norm[hit]
+    flow[:, :, 0] *= factors
+    flow[:, :, 1] *= factors
+
+
+FILTERS = {"scale": filter_scale, "threshold": filter_threshold, "clip": filter_clip}
+
+
+def pre_steps(flow: np.ndarray, ops=(), mask=None) -> np.ndarray:
+    """source.py:339-343: filters in place, then (if a mask is set) a NEW array mask*flow."""
+    for name, value in ops:
+        FILTERS[name](flow, value)
+    if mask is not None:
+        flow = np.multiply(np.asarray(mask, np.float32).reshape(flow.shape[0], flow.shape[1], 1), flow)
+    return flow
+
+
+# --------------------------------------------------------------------------
 # Layer parameters                    transflow/config.py:57-104
 # --------------------------------------------------------------------------
 class LayerParams:

@@ -258,3 +258,53 @@ def test_fused_step_clips_like_post_process(tf):
     # without the clip the same flow leaves the frame: flagged, offending pixels stay put
     layer.step_dev(comp, raw_dev.ptr, pm_dev.ptr, 3, clip_flow=False)
     assert layer.out_of_frame()
+
+
+def test_flow_presteps_golden_gpu(tf):
+    """scale / threshold / clip filters and the flow mask on the GPU (tf_fb_post_process_host_ex),
+    through the FlowSource mirror, against the reference's outputs -- bit for bit, including which
+    array the reference mutates in place (NaNs of clip=0 at a zero vector included)."""
+    from transflow_amd.flow import FlowFilter, FlowSource
+    z = np.load(os.path.join(GOLDEN, "flow_presteps.npz"))
+    h, w = z["mask"].shape[:2]
+    for i in range(int(z["count"])):
+        for direction in (0, 1):
+            for use_mask in (0, 1):
+                key = f"{i}_{direction}_{use_mask}"
+                filters = [FlowFilter.from_string(p) for p in str(z["specs"][i]).split(";")]
+                fs = FlowSource(direction, w, h, 30.0, None, 0, 0, 0, mask=z["mask"] if use_mask else None,
+                                flow_filters=filters)
+                fs.output_frame_index = int(round(float(z[f"t_{key}"]) * fs.framerate))
+                assert fs.t == float(z[f"t_{key}"])
+                work = z[f"in_{key}"].copy()
+                out = fs.post_process(work)
+                np.testing.assert_array_equal(out, z[f"out_{key}"], err_msg=key)
+                np.testing.assert_array_equal(work, z[f"raw_after_{key}"], err_msg="raw " + key)
+                assert (out is work) == (not use_mask)
+                fs.close()
+
+
+def test_flow_presteps_device_path(tf):
+    """The resident form (tf_fb_post_process_ex) equals the host form."""
+    from transflow_amd.device import DevBuffer
+    farneback, _ = tf
+    h, w = 120, 160
+    rng = np.random.default_rng(8)
+    fb = farneback.Farneback(w, h, levels=0)
+    a = rng.integers(0, 255, (h, w), dtype=np.uint8)
+    b = np.roll(a, 2, axis=1)
+    fb.set_frame(0, a)
+    fb.set_frame(1, b)
+    fb.calc_slots([0], [1])
+    raw = fb.get_flow(0)
+    mask = rng.random((h, w)).astype(np.float32)
+    ops = [("scale", 1.5), ("clip", np.float64(2.0)), ("threshold", 0.2)]
+    exp = fb.post_process_host_ex(raw.copy(), 0, ops, mask)
+    mdev = DevBuffer.from_array(mask)
+    fb.post_process_ex(0, 0, ops, mdev.ptr)
+    np.testing.assert_array_equal(fb.get_flow(0), exp)
+    with pytest.raises(NotImplementedError):
+        fb.post_process_host_ex(raw.copy(), 0, [("scale", np.ones(3))])
+    with pytest.raises(ValueError):
+        fb.post_process_host_ex(raw.copy(), 0, [("scale", 1.0)] * 9)
+    fb.close()

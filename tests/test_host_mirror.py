@@ -90,7 +90,14 @@ def test_builder_timing_arithmetic():
     b.build()
     assert b.lock_expr_skip(1.5) and not b.lock_expr_skip(0.5)
     with pytest.raises(NotImplementedError):
-        _builder(mask_path="ones").build()
+        _builder(kernel_path="k.npy").build()
+    b = _builder(flow_filters="scale=2*t; threshold = 0.5")
+    b.build()
+    assert [f.name for f in b.flow_filters] == ["scale", "threshold"] and b.flow_filters[0].expr(1.5) == 3.0
+    with pytest.raises(NotImplementedError):
+        _builder(flow_filters="polar=r:a").build()
+    with pytest.raises(ValueError):
+        _builder(flow_filters="blur=3").build()
 
 
 def test_direction_and_lockmode_parsing():

@@ -90,3 +90,27 @@ def test_move_rejects_out_of_frame():
     flow[3, 3] = (2, 0)
     with pytest.raises(IndexError):
         layer.update(flow)
+
+
+def _prestep_cases():
+    z = np.load(os.path.join(GOLDEN, "flow_presteps.npz"))
+    for i in range(int(z["count"])):
+        for direction in (0, 1):
+            for use_mask in (0, 1):
+                yield z, i, direction, use_mask, f"{i}_{direction}_{use_mask}"
+
+
+def test_flow_presteps_golden():
+    """Flow filters + flow mask + post_process (reference source.py:337-363, filters.py:36-72)."""
+    from transflow_amd.flow import FlowFilter
+    for z, i, direction, use_mask, key in _prestep_cases():
+        filters = [FlowFilter.from_string(p) for p in str(z["specs"][i]).split(";")]
+        t = float(z[f"t_{key}"])
+        raw = z[f"in_{key}"].copy()
+        with np.errstate(all="ignore"):
+            flow = R.pre_steps(raw, [(f.name, f.expr(t)) for f in filters], z["mask"] if use_mask else None)
+            out = R.post_process(flow, direction)
+        np.testing.assert_array_equal(out, z[f"out_{key}"], err_msg=key)
+        if not (use_mask == 0):
+            # with a mask the reference builds a new array: the raw flow keeps only the filters' effect
+            np.testing.assert_array_equal(raw, z[f"raw_after_{key}"], err_msg=key)

@@ -288,7 +288,49 @@ def capture_masks():
     np.savez_compressed(os.path.join(OUT, "masks.npz"), **d)
 
 
+
+def capture_flow_presteps():
+    """FlowSource.post_process with flow filters and a flow mask (source.py:339-343,
+    filters.py:36-72) -- the values the filters' lambdas return keep their Python/numpy type."""
+    from transflow.flow.filters import FlowFilter
+    rng = np.random.default_rng(404)
+    h, w = 37, 53
+    cases = [
+        ("scale=2.5*t", 0.4), ("scale=numpy.float64(0.3)+t", 0.2), ("threshold=1.5+t", 0.5),
+        ("threshold=numpy.float64(2.0)", 0.0), ("clip=2.0", 0.0), ("clip=numpy.float64(1.0)+t", 1.0),
+        ("scale=-1;threshold=0.8;clip=3", 0.0), ("clip=0", 0.0),
+    ]
+    d = {"count": np.int32(len(cases)), "specs": np.array([c[0] for c in cases]),
+         "ts": np.array([c[1] for c in cases])}
+    mask = rng.random((h, w, 1)).astype(np.float32)
+    d["mask"] = mask
+    for i, (spec, t) in enumerate(cases):
+        for direction in (FlowSource.Direction.FORWARD, FlowSource.Direction.BACKWARD):
+            for use_mask in (False, True):
+                fs = make_fs(direction, h, w)
+                fs.flow_filters = [FlowFilter.from_args(p[:p.index("=")].strip(), tuple(p[p.index("=") + 1:].strip().split(":")))
+                                   for p in spec.split(";")]
+                fs.mask = mask if use_mask else None
+                fs.output_frame_index = int(round(t * fs.framerate))
+                raw = rng.normal(0, 2.0, (h, w, 2)).astype(np.float32)
+                raw[0, 0] = 0   # a zero vector: norm 0 (0/0 in clip=0)
+                work = raw.copy()
+                with np.errstate(all="ignore"):
+                    out = fs.post_process(work)
+                key = f"{i}_{direction.value}_{int(use_mask)}"
+                d[f"in_{key}"] = raw
+                d[f"out_{key}"] = np.asarray(out)
+                d[f"raw_after_{key}"] = work      # filters act in place on the raw flow
+                d[f"t_{key}"] = np.float64(fs.t)
+    np.savez_compressed(os.path.join(OUT, "flow_presteps.npz"), **d)
+    print("flow pre-step cases:", len(cases) * 4)
+
+
 if __name__ == "__main__":
+    if "--presteps-only" in sys.argv:
+        capture_flow_presteps()
+        sys.exit(0)
+    capture_flow_presteps()
     capture_masks()
     if "--masks-only" in sys.argv:
         sys.exit(0)

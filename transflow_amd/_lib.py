@@ -27,6 +27,10 @@ class TfFbParams(C.Structure):
                 ("flags", C.c_int)]
 
 
+class TfFlowOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("wide", C.c_int), ("value", C.c_double)]
+
+
 class TfLayerCfg(C.Structure):
     _fields_ = [("transparent_pixels_can_move", C.c_int), ("pixels_can_move_to_empty_spot", C.c_int),
                 ("pixels_can_move_to_filled_spot", C.c_int), ("moving_pixels_leave_empty_spot", C.c_int),
@@ -71,6 +75,8 @@ PROTOTYPES = {
     "tf_fb_flow_ptr": (_I, [_P, _I, _PP]),
     "tf_fb_post_process": (_I, [_P, _I, _I]),
     "tf_fb_post_process_host": (_I, [_P, _P, _I]),
+    "tf_fb_post_process_ex": (_I, [_P, _I, _I, _I, C.POINTER(TfFlowOp), _P]),
+    "tf_fb_post_process_host_ex": (_I, [_P, _P, _I, _I, C.POINTER(TfFlowOp), _P]),
     "tf_fb_stage_level_image": (_I, [_P, _P, C.c_ssize_t, _I, _P]),
     "tf_fb_stage_polyexp": (_I, [_P, _P, _I, _I, _P]),
     "tf_fb_stage_level_polyexp": (_I, [_P, _P, C.c_ssize_t, _I, _P]),

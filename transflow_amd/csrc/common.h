@@ -78,4 +78,7 @@ struct DevBuf {
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// numpy.clip semantics: minimum(maximum(v, lo), hi) with NaN propagated (fminf/fmaxf drop it)
+__device__ __forceinline__ float clip_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
+
 } // namespace tf

@@ -298,8 +298,8 @@ k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4
         const int i = t / W, j = t % W;
         float2 f = flow[t];
         if (sp.clip_flow) {
-            f.x = fminf(fmaxf(f.x, (float)(-j)), (float)(W - 1 - j));
-            f.y = fminf(fmaxf(f.y, (float)(-i)), (float)(H - 1 - i));
+            f.x = clip_nan(f.x, (float)(-j), (float)(W - 1 - j));
+            f.y = clip_nan(f.y, (float)(-i), (float)(H - 1 - i));
         }
         // --- move (movement.py:20-60)
         int4 me = old[t];
@@ -387,8 +387,8 @@ __global__ void k_remap_clip_flow(float2 *flow, int W, int H)
         return;
     int i = t / W, j = t % W;
     float2 f = flow[t];
-    f.x = fminf(fmaxf(f.x, (float)(-j)), (float)(W - 1 - j));
-    f.y = fminf(fmaxf(f.y, (float)(-i)), (float)(H - 1 - i));
+    f.x = clip_nan(f.x, (float)(-j), (float)(W - 1 - j));
+    f.y = clip_nan(f.y, (float)(-i), (float)(H - 1 - i));
     flow[t] = f;
 }
 

@@ -8,7 +8,8 @@
 `install()` replaces the two factories pipeline.py calls
 (transflow/pipeline.py:325 FlowSource.from_args, :445 Compositor.from_args) with
 dispatchers that build HipFlowSource / HipCompositor when the request is one this
-backend serves -- a video path (or webcam index) with the Farnebäck method, layers of
+backend serves -- a video path (or webcam index) with the Farnebäck method (flow mask and the
+scale/threshold/clip filters included; no convolution kernel, no polar filter), layers of
 class `moveref` -- and fall through to the reference's own factory otherwise
 (archives, motion vectors, other flow methods, other layer classes).
 INTEGRATION.md shows the three-line patch a maintainer would add instead.
@@ -28,7 +29,8 @@ def _flow_from_args(original):
                   flow_filters=None, size=None, direction=None, seek_ckpt=None, seek_time=None,
                   duration_time=None, repeat=1, lock_expr=None, lock_mode="stay"):
         served = (isinstance(flow_path, str) and not use_mvs and not flow_path.endswith(".flow.zip")
-                  and mask_path is None and kernel_path is None and flow_filters is None and cv_config != "window")
+                  and kernel_path is None and (flow_filters is None or "polar" not in flow_filters)
+                  and cv_config != "window")
         if served and cv_config is not None and os.path.isfile(cv_config):
             try:
                 FlowConfig.from_file(cv_config)

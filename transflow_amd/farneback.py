@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import TfFbParams, check
+from ._lib import TfFbParams, TfFlowOp, check
 
 FORWARD = 0   # FlowSource.Direction.FORWARD  (flow/sources/source.py:21)
 BACKWARD = 1  # FlowSource.Direction.BACKWARD (flow/sources/source.py:22)
@@ -100,6 +100,44 @@ class Farneback:
             raise ValueError("post_process needs a C-contiguous float32 array of shape (H, W, 2)")
         check(self._lib.tf_fb_post_process_host(self._h, _ptr(flow), int(direction)))
         return flow
+
+    FLOW_OPS = {"scale": 0, "threshold": 1, "clip": 2}
+
+    @staticmethod
+    def _ops_array(ops):
+        """ops: iterable of (name, value); value typed as the filter's lambda returned it."""
+        items = []
+        for name, value in ops:
+            if isinstance(value, np.generic):
+                if not np.issubdtype(value.dtype, np.floating) and not np.issubdtype(value.dtype, np.integer):
+                    raise NotImplementedError(f"flow filter value of type {value.dtype}")
+                wide = int(value.dtype == np.float64)          # strong float64 scalar: float64 arithmetic
+            elif isinstance(value, (int, float)):
+                wide = 0                                        # weak Python scalar: float32 arithmetic
+            else:
+                raise NotImplementedError(f"flow filter value of type {type(value).__name__} (array-valued "
+                                          "expressions are not supported on the device)")
+            items.append(TfFlowOp(Farneback.FLOW_OPS[name], wide, float(value)))
+        arr = (TfFlowOp * max(1, len(items)))(*items)
+        return arr, len(items)
+
+    def post_process_host_ex(self, flow: np.ndarray, direction: int | None, ops=(), mask=None) -> np.ndarray:
+        """Filters + mask + (direction handling unless direction is None), in place."""
+        if (not isinstance(flow, np.ndarray) or flow.dtype != np.float32 or not flow.flags.c_contiguous
+                or flow.shape != (self.height, self.width, 2)):
+            raise ValueError("post_process needs a C-contiguous float32 array of shape (H, W, 2)")
+        arr, n = self._ops_array(ops)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.float32).reshape(self.height, self.width)
+        check(self._lib.tf_fb_post_process_host_ex(self._h, _ptr(flow), -1 if direction is None else int(direction), n,
+                                                   arr, None if m is None else _ptr(m)))
+        return flow
+
+    def post_process_ex(self, pair: int, direction: int, ops=(), mask_dev: int | None = None) -> None:
+        arr, n = self._ops_array(ops)
+        check(self._lib.tf_fb_post_process_ex(self._h, int(pair), int(direction), n, arr,
+                                              C.c_void_p(mask_dev) if mask_dev else None))
 
     # -- geometry / stage entry points (parity tests) -----------------------------------
     def level_sizes(self):

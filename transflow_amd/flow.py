@@ -25,6 +25,40 @@ from .config import FlowConfig
 logger = logging.getLogger(__name__)
 
 
+class FlowFilter:
+    """A flow filter of the reference (transflow/flow/filters.py): `name=expr` where expr is a
+    Python expression of t evaluated on the host for every frame; the arithmetic on the flow runs
+    on the GPU.  `polar` (array-valued user expressions) is not available on the device."""
+
+    NAMES = ("scale", "threshold", "clip")
+
+    def __init__(self, name: str, expr_string: str):
+        if name == "polar":
+            raise NotImplementedError("the 'polar' flow filter evaluates user expressions on arrays; "
+                                      "transflow_amd has no device form of it")
+        if name not in self.NAMES:
+            raise ValueError(f"Unknown filter name '{name}'")                     # filters.py:33
+        self.name = name
+        self.expr_string = expr_string
+        import math
+        import random
+        import re
+
+        import numpy
+        # the names the reference's utils module (where its eval runs, utils.py:407-412) offers
+        scope = {"math": math, "numpy": numpy, "random": random, "re": re, "os": os}
+        self.expr = eval("lambda t: " + expr_string, scope)
+
+    @classmethod
+    def from_string(cls, text: str):
+        """'scale=2*t' -> FlowFilter('scale', '2*t')   (source.py:143-149)"""
+        i = text.index("=")
+        args = tuple(text[i + 1:].strip().split(":"))
+        if len(args) != 1 and text[:i].strip() != "polar":
+            raise ValueError(f"Invalid number of arguments: {text[:i].strip()} {args}")  # filters.py:21-31
+        return cls(text[:i].strip(), args[0] if len(args) == 1 else ":".join(args))
+
+
 class FlowSource:
     """Base class; same constructor, attributes and iteration protocol as the reference's."""
 
@@ -107,10 +141,17 @@ class FlowSource:
                     "lock_expr_skip": self.lock_expr_skip}
 
         def build(self):
-            if self.mask_path is not None or self.kernel_path is not None or self.flow_filters_string is not None:
-                # flow mask / convolution kernel / filters are not on the GPU yet;
-                # there is deliberately no host fallback
-                raise NotImplementedError("flow mask, kernel and filters are not implemented by transflow_amd yet")
+            if self.kernel_path is not None:
+                # the convolution kernel pre-step (source.py:344-348) is not on the GPU yet; there is
+                # deliberately no host fallback
+                raise NotImplementedError("flow convolution kernels are not implemented by transflow_amd yet")
+            if self.mask_path is not None:                                              # source.py:127-129
+                from .masks import load_float_mask
+                self.mask = load_float_mask(self.mask_path)
+                self.mask = self.mask.reshape((*self.mask.shape, 1))
+            if self.flow_filters_string is not None:                                    # source.py:141-149
+                self.flow_filters = [FlowFilter.from_string(part)
+                                     for part in self.flow_filters_string.strip().split(";")]
             if self.lock_expr_string is not None:                                       # source.py:133-139
                 if self.lock_mode == FlowSource.LockMode.STAY:
                     text = self.lock_expr_string if "(" in self.lock_expr_string else f"({self.lock_expr_string})"
@@ -167,8 +208,11 @@ class FlowSource:
         self.length = length
         self.end_frame = end_frame
         self.mask, self.kernel, self.flow_filters = mask, kernel, list(flow_filters)
-        if self.mask is not None or self.kernel is not None or self.flow_filters:
-            raise NotImplementedError("flow mask, kernel and filters are not implemented by transflow_amd yet")
+        if self.kernel is not None:
+            raise NotImplementedError("flow convolution kernels are not implemented by transflow_amd yet")
+        for f in self.flow_filters:
+            if not isinstance(f, FlowFilter):
+                raise ValueError("flow_filters must be transflow_amd.flow.FlowFilter objects")
         self.lock_mode = FlowSource.LockMode.from_arg(lock_mode)
         self.lock_expr_stay, self.lock_expr_skip = lock_expr_stay, lock_expr_skip
         self.input_frame_index = 0
@@ -255,8 +299,17 @@ class FlowSource:
         if self._pp is None:
             from .farneback import Farneback
             self._pp = Farneback(self.width, self.height, levels=0)
-        self._pp.post_process_host(flow, self.direction.value)
-        return flow
+        ops = [(f.name, f.expr(self.t)) for f in self.flow_filters]   # filters.py: lambdas of t, host side
+        if self.mask is None:
+            self._pp.post_process_host_ex(flow, self.direction.value, ops)
+            return flow
+        # the reference applies the filters IN PLACE on the raw flow (so prev_flow sees them) and
+        # then builds a NEW array with the mask multiply (source.py:339-343)
+        if ops:
+            self._pp.post_process_host_ex(flow, None, ops)
+        out = flow.copy()
+        self._pp.post_process_host_ex(out, self.direction.value, (), self.mask)
+        return out
 
     def close(self):
         if self._pp is not None:
