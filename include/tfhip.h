@@ -39,6 +39,9 @@ typedef enum tf_status {
 int tf_abi_version(void);
 /* Select the GPU for this process/thread and create the library stream.  Idempotent. */
 int tf_init(int device);
+/* 1 once this process has initialised the HIP runtime through the library (a process forked after
+   that point cannot use the GPU: fork first, as transflow/pipeline.py does). */
+int tf_is_initialized(void);
 int tf_device_count(int *count);
 const char *tf_last_error(void);
 /* Block until everything queued on the library stream has finished. */

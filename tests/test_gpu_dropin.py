@@ -182,3 +182,4 @@ def test_pipeline_loop_matches_oracle_sequence():
             ora.update(flow, [pixmap])          # oracle remap driven by the SAME flow: bit-exact
             np.testing.assert_array_equal(comp.layers[0].data, ora.data)
             np.testing.assert_array_equal(frame, R.composite(white, [ora.render()]))
+

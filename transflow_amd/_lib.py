@@ -48,6 +48,7 @@ _PI = C.POINTER(C.c_int)
 PROTOTYPES = {
     "tf_abi_version": (_I, []),
     "tf_init": (_I, [_I]),
+    "tf_is_initialized": (_I, []),
     "tf_device_count": (_I, [_PI]),
     "tf_last_error": (C.c_char_p, []),
     "tf_sync": (_I, []),

@@ -151,6 +151,8 @@ TF_API int tf_abi_version(void) { return TFHIP_ABI_VERSION; }
 
 TF_API int tf_init(int device) { return init_device(device); }
 
+TF_API int tf_is_initialized(void) { return g_inited ? 1 : 0; }
+
 TF_API int tf_device_count(int *count)
 {
     TF_REQUIRE(count, "tf_device_count: null pointer");
