@@ -15,8 +15,16 @@
 namespace tf {
 
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-hipStream_t stream();
+hipStream_t stream();      // the stream launches go to: the library stream unless a StreamScope is active
+hipStream_t main_stream(); // the library stream (tf_stream)
 int ensure_init();
+
+// Routes the launches (and profiler events) of the enclosing scope to another stream.
+struct StreamScope {
+    explicit StreamScope(hipStream_t s);
+    ~StreamScope();
+    hipStream_t prev;
+};
 
 #define TF_HIP(expr)                                                                              \
     do {                                                                                          \

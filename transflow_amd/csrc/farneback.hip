@@ -1604,6 +1604,8 @@ struct Level {
     ImgTile tile;
     std::vector<float> kern_host;
     DevBuf kern;
+    DevBuf img, R;              // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
+    hipEvent_t ready = nullptr; // recorded on the preparation stream once R is complete
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
     LerpDev flow_lerp; // level k+1 -> this level
 };
@@ -1618,16 +1620,27 @@ struct tf_fb {
     PolyConst pc;
     std::vector<Level *> lv;
     DevBuf frames, img, R, M[2], lflow[3], pairs, winner, scratch;
+    hipStream_t prep_stream = nullptr; // A1+A2 of every level run here, ahead of and beside the flow chain
+    hipEvent_t chain_done = nullptr;   // the chain has finished with the R buffers of the previous call
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
     // A3+A4 as one kernel per iteration (k_flow_iter).  Correct (same parity tests) but slower than the
     // two-kernel form on MI355X: the LDS ring admits 3 waves per CU, which leaves the march issue-bound
     // (DESIGN.md section 8).  Opt-in with TF_FB_FUSED=1.
     bool fused = getenv("TF_FB_FUSED") && atoi(getenv("TF_FB_FUSED")) != 0;
+    float *Rk(int k) { return (k <= 0 ? R : lv[k]->R).as<float>(); }
+    float *imgk(int k) { return (k <= 0 ? img : lv[k]->img).as<float>(); }
     ~tf_fb()
     {
-        for (auto *l : lv)
+        for (auto *l : lv) {
+            if (l->ready)
+                (void)hipEventDestroy(l->ready);
             delete l;
+        }
+        if (chain_done)
+            (void)hipEventDestroy(chain_done);
+        if (prep_stream)
+            (void)hipStreamDestroy(prep_stream);
     }
 };
 
@@ -1653,7 +1666,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs)
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
     return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
-                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->img.as<float>(),
+                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->imgk(k),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
 }
 
@@ -1750,14 +1763,14 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
     const int n = fb->pc.n;
     dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
     if (n == 5)
-        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->img.as<float>(),
-                      fb->R.as<float>(), w, h, fb->pc);
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->imgk(k),
+                      fb->Rk(k), w, h, fb->pc);
     if (n == 7)
-        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->img.as<float>(),
-                      fb->R.as<float>(), w, h, fb->pc);
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->imgk(k),
+                      fb->Rk(k), w, h, fb->pc);
     size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
     return launch(lvl_name("fb_polyexp_generic", k), k_polyexp, grid, dim3(256), smem,
-                  (const float *)fb->img.as<float>(), fb->R.as<float>(), w, h, fb->pc);
+                  (const float *)fb->imgk(k), fb->Rk(k), w, h, fb->pc);
 }
 
 // A1+A2 fusion applies to a level that is a copy-sized resize of the frame with the 3-tap blur
@@ -1776,17 +1789,17 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
-                      (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->R.as<float>(),
+                      (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k),
                       L.W, L.H, kc, k1, fb->pc);
     return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), 0,
-                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->R.as<float>(), L.W,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), L.W,
                   L.H, kc, k1, fb->pc);
 }
 
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
     dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
-    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->R.as<float>(),
+    return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->Rk(k),
                   fb->M[mbuf].as<float>(), w, h, fi);
 }
 
@@ -1845,7 +1858,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     int seg = (int)std::min<long>(h, std::max<long>(4 * WIN, (h + segs_wanted - 1) / segs_wanted));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     size_t smem = (size_t)WIN * 5 * 128 * sizeof(float) + 2 * 5 * 64 * sizeof(double);
-    const float *R = fb->R.as<float>();
+    const float *R = fb->Rk(k);
     if (flow_in)
         return launch(lvl_name("fb_flow_iter", k), k_flow_iter<M, true>, grid, dim3(64), smem, R, flow_in, flow_out, w,
                       h, scale, seg);
@@ -1960,6 +1973,18 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
         (rc = fb->pairs.alloc(P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
         return fail(rc);
+    for (int k = 1; k <= fb->K; k++) {
+        Level &L = *fb->lv[k];
+        const size_t nk = (size_t)L.W * L.H;
+        if ((rc = L.img.alloc(P * 2 * nk * 4)) || (rc = L.R.alloc(P * 10 * nk * 4)))
+            return fail(rc);
+    }
+    for (int k = 0; k <= fb->K; k++)
+        if (hipEventCreateWithFlags(&fb->lv[k]->ready, hipEventDisableTiming) != hipSuccess)
+            return fail(set_error(TF_ERR_HIP, "hipEventCreate failed"));
+    if (hipEventCreateWithFlags(&fb->chain_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&fb->prep_stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(set_error(TF_ERR_HIP, "creating the preparation stream failed"));
     *out = fb;
     return TF_OK;
 }
@@ -2018,15 +2043,36 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     TF_HIP(hipStreamSynchronize(stream())); // pr is a stack-lifetime staging buffer
     const int m = fb->prm.winsize / 2;
     const bool fused = fb->fused && m >= 2 && m <= 7;
+    // A1+A2 of every level depend on the frames only: they run on the preparation stream, coarse
+    // level first, while the flow chain (which needs the coarser level's result) follows on the
+    // library stream as each level's coefficients become ready.  The small coarse-level kernels of
+    // one stream fill the gaps of the other.
+    static const bool overlap_on = !(getenv("TF_FB_NO_OVERLAP") && atoi(getenv("TF_FB_NO_OVERLAP")) != 0);
+    const bool overlap = overlap_on && fb->K > 0; // a single scale has nothing to overlap with
+    {
+        hipStream_t ps = overlap ? fb->prep_stream : main_stream();
+        if (overlap) {
+            TF_HIP(hipEventRecord(fb->chain_done, main_stream())); // frames/pairs uploaded, previous chain finished
+            TF_HIP(hipStreamWaitEvent(ps, fb->chain_done, 0));
+        }
+        StreamScope scope(ps);
+        for (int k = fb->K; k >= 0; k--) {
+            Level &L = *fb->lv[k];
+            if (fb_can_fuse_level(fb, k)) {
+                TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
+            } else {
+                TF_TRY(fb_level_image(fb, k, n_pairs));
+                TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
+            }
+            if (overlap)
+                TF_HIP(hipEventRecord(L.ready, ps));
+        }
+    }
     int coarse = -1; // lflow buffer holding the coarser level's result
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
-        if (fb_can_fuse_level(fb, k)) {
-            TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
-        } else {
-            TF_TRY(fb_level_image(fb, k, n_pairs));
-            TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
-        }
+        if (overlap)
+            TF_HIP(hipStreamWaitEvent(main_stream(), L.ready, 0));
         FlowInit fi;
         memset(&fi, 0, sizeof(fi));
         if (k < fb->K) {
@@ -2217,7 +2263,7 @@ TF_API int tf_fb_stage_level_image(tf_fb *fb, const uint8_t *grey, ptrdiff_t str
     TF_HIP(hipMemcpy(fb->pairs.p, &pr, 8, hipMemcpyHostToDevice));
     TF_TRY(fb_level_image(fb, level, 1));
     Level &L = *fb->lv[level];
-    TF_HIP(hipMemcpyAsync(out, fb->img.p, (size_t)L.W * L.H * 4, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipMemcpyAsync(out, fb->imgk(level), (size_t)L.W * L.H * 4, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
     return TF_OK;
 }
@@ -2259,7 +2305,7 @@ TF_API int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t s
         TF_TRY(fb_level_image(fb, level, 1));
         TF_TRY(fb_polyexp(fb, L.W, L.H, 2, level));
     }
-    return download_planar5(r_out, fb->R.as<float>(), (size_t)L.W * L.H, fb->scratch);
+    return download_planar5(r_out, fb->Rk(level), (size_t)L.W * L.H, fb->scratch);
 }
 
 TF_API int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out)

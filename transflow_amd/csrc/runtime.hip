@@ -25,7 +25,13 @@ int set_error(int code, const char *fmt, ...)
     return code;
 }
 
-hipStream_t stream() { return g_stream; }
+static thread_local hipStream_t g_override = nullptr;
+
+hipStream_t stream() { return g_override ? g_override : g_stream; }
+hipStream_t main_stream() { return g_stream; }
+
+StreamScope::StreamScope(hipStream_t s) : prev(g_override) { g_override = s; }
+StreamScope::~StreamScope() { g_override = prev; }
 
 static int init_device(int device)
 {
@@ -106,7 +112,7 @@ static void prof_drain()
 {
     if (g_recs.empty())
         return;
-    (void)hipStreamSynchronize(g_stream);
+    (void)hipDeviceSynchronize();
     for (auto &r : g_recs) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
@@ -128,7 +134,7 @@ ProfScope::ProfScope(const char *name) : slot(-1)
     if (g_recs.size() >= 4096)
         prof_drain();
     ProfRec r{name, get_event(), get_event()};
-    (void)hipEventRecord(r.a, g_stream);
+    (void)hipEventRecord(r.a, stream());
     slot = (int)g_recs.size();
     g_recs.push_back(r);
 }
@@ -136,7 +142,7 @@ ProfScope::ProfScope(const char *name) : slot(-1)
 ProfScope::~ProfScope()
 {
     if (slot >= 0)
-        (void)hipEventRecord(g_recs[slot].b, g_stream);
+        (void)hipEventRecord(g_recs[slot].b, stream());
 }
 
 } // namespace tf
