@@ -139,9 +139,9 @@ def kernel_alg_bytes(name, wl, batch, iterations=3):
         mult = 1
         if name == "fb_blur_solve":
             mult = iterations
-        elif name == "fb_update_matrices" and k < len(n):
-            # first launch of a level carries S3 (flow init); the I-1 rebuilds are plain S4
-            total += (iterations - 1) * batch * 68 * n[k]
+        elif name in ("fb_update_matrices", "fb_flow_iter"):
+            # first launch of a level carries S3 (flow init); the I-1 rebuilds are plain S4 (+S5 when fused)
+            total += (iterations - 1) * batch * (68 if name == "fb_update_matrices" else 96) * n[k]
         total += mult * rf.kernel_bytes(name, n[0], n[k], nc, batch)
     return total
 

@@ -1185,148 +1185,173 @@ __global__ void k_flow_upsample(float2 *__restrict__ dst, int Wk, int Hk, FlowIn
 }
 
 // ---------------------------------------------------------------------------------
-// A3+A4 fused: one Farnebäck iteration without ever storing M.
-// One wave marches a 128-column strip (two columns per lane) down a row segment.  For
-// the row entering the blur window it computes M from (R0, gathered R1, flow_in) -- the
-// statements of update_matrix_px, split into an "issue the loads" and a "finish" half so
-// the gathers of row y+8 fly while row y is solved -- and keeps the 2m+1 rows of M the
-// window spans in an LDS ring owned by the wave (15 x 5 x 128 floats for m = 7).  The
-// vertical sums run in double registers (+ entering row - leaving row from the ring), the
-// horizontal sums and the 2x2 solve are those of k_blur_solve_wave.  HBM traffic per pixel
-// and iteration: R0 20 B + R1 gather + flow in/out 16 B, instead of writing M (20 B) and
-// reading it back twice (40 B).
+// A3+A4 fused, ONE column per lane: the window ring is 19 KB per wave (15 x 5 x 64 floats for
+// m = 7), so seven waves share a CU instead of three.  A wave marches a 64-column strip
+// (64 - 2m outputs); adjacent strips meet in one XCD's L2 (xcd_tile), which absorbs the halo
+// columns.  PF rows of gathers are kept in flight (branch-free, clamped rows).  The window sum
+// uses pair sums p[l] = v[l] + v[l+1] (one wave shuffle): m+1 LDS reads and m adds per channel.
 // ---------------------------------------------------------------------------------
+struct Gather1 {
+    float r0[5];
+    float2 t[5], b[5];
+    float dx, dy, fx, fy;
+    bool inb;
+};
+
+__device__ __forceinline__ void gather1_issue(Gather1 &g, const float *__restrict__ R0, const float *__restrict__ R1,
+                                              size_t Nk, int Wk, int Hk, int x, int y, float2 fl)
+{
+    const size_t o = (size_t)y * Wk + x;
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        g.r0[c] = R0[c * Nk + o];
+    float fx = x + fl.x, fy = y + fl.y;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    g.dx = fl.x;
+    g.dy = fl.y;
+    g.fx = fx - x1;
+    g.fy = fy - y1;
+    g.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
+    const float *rp = R1 + (size_t)clampi(y1, 0, Hk - 2) * Wk + clampi(x1, 0, Wk - 2);
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        float2u tv = *reinterpret_cast<const float2u *>(rp + c * Nk);
+        float2u bv = *reinterpret_cast<const float2u *>(rp + c * Nk + Wk);
+        g.t[c] = make_float2(tv.x, tv.y);
+        g.b[c] = make_float2(bv.x, bv.y);
+    }
+}
+
+__device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk, int x, int y, float m[5])
+{
+    const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
+    float r2, r3, r4, r5, r6;
+    if (g.inb) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * g.t[0].x + a01 * g.t[0].y + a10 * g.b[0].x + a11 * g.b[0].y;
+        r3 = a00 * g.t[1].x + a01 * g.t[1].y + a10 * g.b[1].x + a11 * g.b[1].y;
+        r4 = a00 * g.t[2].x + a01 * g.t[2].y + a10 * g.b[2].x + a11 * g.b[2].y;
+        r5 = a00 * g.t[3].x + a01 * g.t[3].y + a10 * g.b[3].x + a11 * g.b[3].y;
+        r6 = a00 * g.t[4].x + a01 * g.t[4].y + a10 * g.b[4].x + a11 * g.b[4].y;
+        r4 = (g.r0[2] + r4) * 0.5f;
+        r5 = (g.r0[3] + r5) * 0.5f;
+        r6 = (g.r0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = g.r0[2];
+        r5 = g.r0[3];
+        r6 = g.r0[4] * 0.5f;
+    }
+    r2 = (g.r0[0] - r2) * 0.5f;
+    r3 = (g.r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    {
+        float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
+        r2 *= scale;
+        r3 *= scale;
+        r4 *= scale;
+        r5 *= scale;
+        r6 *= scale;
+    }
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
 template <int M, bool HAVE_FLOW>
 __global__ void __launch_bounds__(64)
-k_flow_iter(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
-            int Hk, double scale, int seg)
+k_flow_iter1(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
+             int Hk, double scale, int seg)
 {
-    constexpr int HALO = (M + 1) & ~1;
-    constexpr int OUTC = 128 - 2 * HALO;
-    constexpr int NE = 2 * HALO + 2;
-    constexpr int WIN = 2 * M + 1;
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    float2 *ring = reinterpret_cast<float2 *>(s_dyn);                         // [WIN][5][64] (two columns per lane)
-    double *s_e = reinterpret_cast<double *>(s_dyn + (size_t)WIN * 5 * 128);  // [5][64]
-    double *s_o = s_e + 5 * 64;                                               // [5][64]
+    static_assert(M & 1, "the pair-sum window needs an odd half-width");
+    constexpr int HALO = M, OUTC = 64 - 2 * HALO, WIN = 2 * M + 1, PF = 2;
+    __shared__ float ring[WIN][5][64];
+    __shared__ double s_v[5][64], s_p[5][64];
     const int lane = threadIdx.x;
-    const int c0 = blockIdx.x * OUTC - HALO + 2 * lane;
-    const int xa = clampi(c0, 0, Wk - 1), xb = clampi(c0 + 1, 0, Wk - 1); // replicated border columns
+    unsigned bx, by;
+    xcd_tile(bx, by);
+    const int c0 = (int)bx * OUTC - HALO + lane;
+    const int x = clampi(c0, 0, Wk - 1); // replicated border columns
     const int pair = blockIdx.z;
     const size_t Nk = (size_t)Wk * Hk;
     const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
     const float2 *fin = HAVE_FLOW ? flow_in + (size_t)pair * Nk : nullptr;
-    const int r0 = blockIdx.y * seg, r1 = min(r0 + seg, Hk);
+    const int r0 = by * seg, r1 = min(r0 + seg, Hk);
 
-    auto load_flow = [&](int row, float2 &fa, float2 &fb) {
-        if (HAVE_FLOW) {
-            fa = fin[(size_t)row * Wk + xa];
-            fb = fin[(size_t)row * Wk + xb];
-        } else {
-            fa = fb = make_float2(0.f, 0.f);
-        }
+    auto load_flow = [&](int row) {
+        return HAVE_FLOW ? fin[(size_t)min(row, Hk - 1) * Wk + x] : make_float2(0.f, 0.f);
     };
 
-    double vs[5][2];
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-        vs[c][0] = vs[c][1] = 0.0;
-    // ---- fill the window for the first output row: rows r0-M .. r0+M-1 (clamped: a clamped
-    // row repeats the matrices of the edge row)
-    float mlast[2][5];
-    int last_row = -1;
-    int slot = 0;
+    double vs[5] = {0, 0, 0, 0, 0};
+    float mlast[5];
+    // ---- the first window: rows r0-M .. r0+M-1 (a clamped row repeats the edge row's matrices)
+    int last_row = -1, slot = 0;
     for (int e = r0 - M; e < r0 + M; e++) {
         const int row = clampi(e, 0, Hk - 1);
         if (row != last_row) {
-            float2 fa, fb;
-            load_flow(row, fa, fb);
-            GatherRegs g;
-            gather_issue(g, R0, R1, Nk, Wk, Hk, xa, xb, row, fa, fb);
-            gather_finish(g, Wk, Hk, xa, xb, row, mlast);
+            Gather1 g;
+            gather1_issue(g, R0, R1, Nk, Wk, Hk, x, row, load_flow(row));
+            gather1_finish(g, Wk, Hk, x, row, mlast);
             last_row = row;
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            ring[(slot * 5 + c) * 64 + lane] = make_float2(mlast[0][c], mlast[1][c]);
-            vs[c][0] += (double)mlast[0][c];
-            vs[c][1] += (double)mlast[1][c];
+            ring[slot][c][lane] = mlast[c];
+            vs[c] += (double)mlast[c];
         }
         slot = slot + 1 == WIN ? 0 : slot + 1;
     }
-    // `slot` now addresses the ring row that enters with output row r0 (not yet part of vs:
-    // treat its previous content as zero)
 #pragma unroll
     for (int c = 0; c < 5; c++)
-        ring[(slot * 5 + c) * 64 + lane] = make_float2(0.f, 0.f);
-
-    // software pipeline: G holds the gathers of the row entering the window of the current output
-    // row, F the flow of the row entering next.  Rows past the last image row are replicated:
-    // their matrices are recomputed from the clamped row (same values, no branch around loads).
-    GatherRegs G;
-    float2 Fa, Fb;
-    {
-        const int e = min(r0 + M, Hk - 1);
-        load_flow(e, Fa, Fb);
-        gather_issue(G, R0, R1, Nk, Wk, Hk, xa, xb, e, Fa, Fb);
-        load_flow(min(r0 + M + 1, Hk - 1), Fa, Fb);
-    }
-    const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
-    for (int y = r0; y < r1; y++) {
-        gather_finish(G, Wk, Hk, xa, xb, min(y + M, Hk - 1), mlast);
-        // next row's gathers (and the flow of the one after) fly during the rest of this iteration
-        gather_issue(G, R0, R1, Nk, Wk, Hk, xa, xb, min(y + M + 1, Hk - 1), Fa, Fb);
-        load_flow(min(y + M + 2, Hk - 1), Fa, Fb);
+        ring[slot][c][lane] = 0.f; // the slot the first entering row replaces
+    // ---- software pipeline: G[t] holds the gathers of entering row r0+M+t (slot t % PF), F the
+    // flow of the row after those
+    Gather1 G[PF];
+    float2 F;
 #pragma unroll
-        for (int c = 0; c < 5; c++) {
-            float2 *rp = &ring[(slot * 5 + c) * 64 + lane];
-            const float2 old = *rp;
-            *rp = make_float2(mlast[0][c], mlast[1][c]);
-            vs[c][0] += (double)mlast[0][c] - (double)old.x;
-            vs[c][1] += (double)mlast[1][c] - (double)old.y;
-            s_e[c * 64 + lane] = vs[c][0];
-            s_o[c * 64 + lane] = vs[c][1];
-        }
-        slot = slot + 1 == WIN ? 0 : slot + 1;
-        __syncthreads();
-        if (is_out) {
-            double g0[5], g1[5];
+    for (int t = 0; t < PF; t++)
+        gather1_issue(G[t], R0, R1, Nk, Wk, Hk, x, min(r0 + M + t, Hk - 1), load_flow(r0 + M + t));
+    F = load_flow(r0 + M + PF);
+    const bool is_out = lane >= HALO && lane < 64 - HALO && c0 < Wk;
+    for (int yb = r0; yb < r1; yb += PF) {
+#pragma unroll
+        for (int h = 0; h < PF; h++) {
+            const int y = yb + h;
+            if (y >= r1)
+                break;
+            gather1_finish(G[h], Wk, Hk, x, min(y + M, Hk - 1), mlast);
+            gather1_issue(G[h], R0, R1, Nk, Wk, Hk, x, min(y + M + PF, Hk - 1), F); // row entering PF steps later
+            F = load_flow(y + M + PF + 1);
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                double first = 0, last = 0, common = 0;
-#pragma unroll
-                for (int q = 0; q < NE / 2; q++) {
-                    if (2 * q + 1 < HALO - M || 2 * q > HALO + M + 1)
-                        continue;
-                    const double dxv = s_e[c * 64 + lane - HALO / 2 + q], dyv = s_o[c * 64 + lane - HALO / 2 + q];
-                    if (2 * q == HALO - M)
-                        first = dxv;
-                    else if (2 * q > HALO - M && 2 * q <= HALO + M)
-                        common += dxv;
-                    else if (2 * q == HALO + M + 1)
-                        last = dxv;
-                    if (2 * q + 1 == HALO - M)
-                        first = dyv;
-                    else if (2 * q + 1 > HALO - M && 2 * q + 1 <= HALO + M)
-                        common += dyv;
-                    else if (2 * q + 1 == HALO + M + 1)
-                        last = dyv;
-                }
-                g0[c] = (first + common) * scale;
-                g1[c] = (common + last) * scale;
+                const float old = ring[slot][c][lane];
+                ring[slot][c][lane] = mlast[c];
+                vs[c] += (double)mlast[c] - (double)old;
+                s_v[c][lane] = vs[c];
+                s_p[c][lane] = vs[c] + __shfl_down(vs[c], 1); // lane 63 pairs with itself: never read
             }
-            double idet0 = 1. / (g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
-            double idet1 = 1. / (g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
-            float2 f0 = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
-                                    (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
-            float2 f1 = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
-                                    (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
-            float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
-            o[0] = f0;
-            if (c0 + 1 < Wk)
-                o[1] = f1;
+            slot = slot + 1 == WIN ? 0 : slot + 1;
+            __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
+            if (is_out) {
+                double g[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    // columns l-M .. l+M = v[l-M] + pairs starting at l-M+1, l-M+3, ..., l+M-1
+                    double a = s_v[c][lane - M];
+#pragma unroll
+                    for (int j = -M + 1; j <= M - 1; j += 2)
+                        a += s_p[c][lane + j];
+                    g[c] = a * scale;
+                }
+                const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+                flow_out[(size_t)pair * Nk + (size_t)y * Wk + c0] =
+                    make_float2((float)((g[0] * g[4] - g[1] * g[3]) * idet), (float)((g[2] * g[3] - g[1] * g[4]) * idet));
+            }
+            __syncthreads(); // the next row's writes must not overtake this row's reads
         }
-        __syncthreads();
     }
 }
 
@@ -1604,7 +1629,7 @@ struct Level {
     ImgTile tile;
     std::vector<float> kern_host;
     DevBuf kern;
-    DevBuf img, R;              // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
+    DevBuf img, R[2];           // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
     hipEvent_t ready = nullptr; // recorded on the preparation stream once R is complete
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
     LerpDev flow_lerp; // level k+1 -> this level
@@ -1619,16 +1644,23 @@ struct tf_fb {
     int slots = 0, max_pairs = 0;
     PolyConst pc;
     std::vector<Level *> lv;
-    DevBuf frames, img, R, M[2], lflow[3], pairs, winner, scratch;
-    hipStream_t prep_stream = nullptr; // A1+A2 of every level run here, ahead of and beside the flow chain
-    hipEvent_t chain_done = nullptr;   // the chain has finished with the R buffers of the previous call
+    // R exists twice when the preparation stream is in use: call i+1 expands its frames into one set
+    // while the flow chain of call i still reads the other (`cur` = the set of the call being issued)
+    DevBuf frames, img, R[2], M[2], lflow[3], pairs, winner, scratch;
+    int nsets = 1, cur = 0;
+    hipStream_t prep_stream = nullptr;         // A1+A2 of every level run here, ahead of and beside the flow chain
+    hipEvent_t chain_done[2] = {nullptr, nullptr}; // the chain has finished with R set s
+    bool chain_pending[2] = {false, false};
+    int2 *pairs_host = nullptr;                // pinned staging of the slot pairs
+    hipEvent_t pairs_copied = nullptr;
+    bool pairs_pending = false;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
-    // A3+A4 as one kernel per iteration (k_flow_iter).  Correct (same parity tests) but slower than the
-    // two-kernel form on MI355X: the LDS ring admits 3 waves per CU, which leaves the march issue-bound
-    // (DESIGN.md section 8).  Opt-in with TF_FB_FUSED=1.
+    // A3+A4 as one kernel per iteration (k_flow_iter1: M never stored).  Correct (same parity tests) and
+    // within 5 % of the two-kernel form on MI355X, not faster: what it saves in M traffic it spends on
+    // halo columns.  Opt-in with TF_FB_FUSED=1.
     bool fused = getenv("TF_FB_FUSED") && atoi(getenv("TF_FB_FUSED")) != 0;
-    float *Rk(int k) { return (k <= 0 ? R : lv[k]->R).as<float>(); }
+    float *Rk(int k) { return (k <= 0 ? R[cur] : lv[k]->R[cur]).as<float>(); }
     float *imgk(int k) { return (k <= 0 ? img : lv[k]->img).as<float>(); }
     ~tf_fb()
     {
@@ -1637,12 +1669,23 @@ struct tf_fb {
                 (void)hipEventDestroy(l->ready);
             delete l;
         }
-        if (chain_done)
-            (void)hipEventDestroy(chain_done);
+        for (auto e : chain_done)
+            if (e)
+                (void)hipEventDestroy(e);
+        if (pairs_copied)
+            (void)hipEventDestroy(pairs_copied);
+        if (pairs_host)
+            (void)hipHostFree(pairs_host);
         if (prep_stream)
             (void)hipStreamDestroy(prep_stream);
     }
 };
+
+static bool fb_overlap_enabled()
+{
+    static const bool on = !(getenv("TF_FB_NO_OVERLAP") && atoi(getenv("TF_FB_NO_OVERLAP")) != 0);
+    return on;
+}
 
 // Profiler labels: with TF_PROF_LEVELS=1 in the environment every Farneback launch is
 // labelled with its pyramid level ("fb_polyexp.k2"), otherwise by kernel only.
@@ -1841,28 +1884,24 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, floa
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     return launch("fb_blur_solve_generic", k_blur_solve<false>, grid, dim3(BS_THREADS), 0,
                   (const float *)fb->M[mbuf_in].as<float>(), (float *)nullptr, flow_out,
-                  (const float *)fb->R.as<float>(), w, h, m, scale, seg);
+                  (const float *)fb->Rk(0), w, h, m, scale, seg);
 }
 
 template <int M>
 static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k)
 {
-    constexpr int HALO = (M + 1) & ~1;
-    constexpr int OUTC = 128 - 2 * HALO;
-    constexpr int WIN = 2 * M + 1;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
-    const unsigned strips = cdiv(w, OUTC);
-    // LDS (ring + exchange rows) admits 3 waves per CU; each segment first fills 2M rows of
-    // the window, so keep segments long, but cut the image into enough of them to fill the chip
-    long segs_wanted = std::max(1l, (3 * 256 * 4) / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(h, std::max<long>(4 * WIN, (h + segs_wanted - 1) / segs_wanted));
-    dim3 grid(strips, cdiv(h, seg), n_pairs);
-    size_t smem = (size_t)WIN * 5 * 128 * sizeof(float) + 2 * 5 * 64 * sizeof(double);
     const float *R = fb->Rk(k);
+    constexpr int OUTC = 64 - 2 * M;
+    const unsigned strips = cdiv(w, OUTC);
+    // the 19-24 KB of LDS per wave admit ~6 waves per CU: aim at a few rounds of them
+    long segs_wanted = std::max(1l, (7 * 256 * 3) / std::max(1l, (long)strips * n_pairs));
+    int seg = (int)std::min<long>(h, std::max<long>(2 * (2 * M + 1), (h + segs_wanted - 1) / segs_wanted));
+    dim3 grid(strips, cdiv(h, seg), n_pairs);
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter<M, true>, grid, dim3(64), smem, R, flow_in, flow_out, w,
-                      h, scale, seg);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter<M, false>, grid, dim3(64), smem, R, flow_in, flow_out, w, h,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter1<M, true>, grid, dim3(64), 0, R, flow_in, flow_out, w, h,
+                      scale, seg);
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter1<M, false>, grid, dim3(64), 0, R, flow_in, flow_out, w, h,
                   scale, seg);
 }
 
@@ -1871,12 +1910,9 @@ static bool fb_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flo
 {
     if (w < 2 || h < 2)
         return false;
-    switch (fb->prm.winsize / 2) {
-    case 2: rc = launch_flow_iter<2>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    switch (fb->prm.winsize / 2) { // odd half-widths: the pair-sum window
     case 3: rc = launch_flow_iter<3>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
-    case 4: rc = launch_flow_iter<4>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
     case 5: rc = launch_flow_iter<5>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
-    case 6: rc = launch_flow_iter<6>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
     case 7: rc = launch_flow_iter<7>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
     default: return false;
     }
@@ -1966,8 +2002,9 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             return fail(rc);
     }
     const size_t N0 = (size_t)width * height, P = (size_t)max_pairs;
+    fb->nsets = (fb_overlap_enabled() && fb->K > 0) ? 2 : 1; // a single scale has nothing to overlap with
     if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
-        (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
+        (rc = fb->R[0].alloc(P * 10 * N0 * 4)) || (fb->nsets > 1 && (rc = fb->R[1].alloc(P * 10 * N0 * 4))) ||
         (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
@@ -1976,14 +2013,20 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
     for (int k = 1; k <= fb->K; k++) {
         Level &L = *fb->lv[k];
         const size_t nk = (size_t)L.W * L.H;
-        if ((rc = L.img.alloc(P * 2 * nk * 4)) || (rc = L.R.alloc(P * 10 * nk * 4)))
+        if ((rc = L.img.alloc(P * 2 * nk * 4)) || (rc = L.R[0].alloc(P * 10 * nk * 4)) ||
+            (fb->nsets > 1 && (rc = L.R[1].alloc(P * 10 * nk * 4))))
             return fail(rc);
     }
     for (int k = 0; k <= fb->K; k++)
         if (hipEventCreateWithFlags(&fb->lv[k]->ready, hipEventDisableTiming) != hipSuccess)
             return fail(set_error(TF_ERR_HIP, "hipEventCreate failed"));
-    if (hipEventCreateWithFlags(&fb->chain_done, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&fb->prep_stream, hipStreamNonBlocking) != hipSuccess)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipEventCreateWithFlags(&fb->chain_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&fb->chain_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&fb->pairs_copied, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&fb->pairs_host, P * sizeof(int2), hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithPriority(&fb->prep_stream, hipStreamNonBlocking, least) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "creating the preparation stream failed"));
     *out = fb;
     return TF_OK;
@@ -2033,28 +2076,33 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     TF_REQUIRE(n_pairs >= 1 && n_pairs <= fb->max_pairs, "tf_fb_calc_slots: n_pairs %d not in [1,%d]", n_pairs,
                fb->max_pairs);
     TF_TRY(ensure_init());
-    std::vector<int2> pr((size_t)n_pairs);
-    for (int i = 0; i < n_pairs; i++) {
+    for (int i = 0; i < n_pairs; i++)
         TF_REQUIRE(prev_slots[i] >= 0 && prev_slots[i] < fb->slots && next_slots[i] >= 0 && next_slots[i] < fb->slots,
                    "tf_fb_calc_slots: pair %d uses a slot outside [0,%d)", i, fb->slots);
-        pr[i] = make_int2(prev_slots[i], next_slots[i]);
+    if (fb->pairs_pending) { // the previous call's copy out of the staging buffer (long done in practice)
+        TF_HIP(hipEventSynchronize(fb->pairs_copied));
+        fb->pairs_pending = false;
     }
-    TF_HIP(hipMemcpyAsync(fb->pairs.p, pr.data(), pr.size() * 8, hipMemcpyHostToDevice, stream()));
-    TF_HIP(hipStreamSynchronize(stream())); // pr is a stack-lifetime staging buffer
+    for (int i = 0; i < n_pairs; i++)
+        fb->pairs_host[i] = make_int2(prev_slots[i], next_slots[i]);
     const int m = fb->prm.winsize / 2;
-    const bool fused = fb->fused && m >= 2 && m <= 7;
+    const bool fused = fb->fused && (m == 3 || m == 5 || m == 7);
     // A1+A2 of every level depend on the frames only: they run on the preparation stream, coarse
     // level first, while the flow chain (which needs the coarser level's result) follows on the
-    // library stream as each level's coefficients become ready.  The small coarse-level kernels of
-    // one stream fill the gaps of the other.
-    static const bool overlap_on = !(getenv("TF_FB_NO_OVERLAP") && atoi(getenv("TF_FB_NO_OVERLAP")) != 0);
-    const bool overlap = overlap_on && fb->K > 0; // a single scale has nothing to overlap with
+    // library stream as each level's coefficients become ready.  The call returns without waiting,
+    // and R exists twice: the next call's preparation (VALU-bound) runs beside this call's
+    // full-resolution iterations (HBM-bound) instead of in front of its own chain.
+    const bool overlap = fb->nsets > 1;
+    const int set = fb->cur;
     {
         hipStream_t ps = overlap ? fb->prep_stream : main_stream();
-        if (overlap) {
-            TF_HIP(hipEventRecord(fb->chain_done, main_stream())); // frames/pairs uploaded, previous chain finished
-            TF_HIP(hipStreamWaitEvent(ps, fb->chain_done, 0));
-        }
+        // R set `set` was last read by the chain two calls ago.  Frames: tf_fb_set_frame returns with the
+        // frame in place; a caller writing frames on the device orders that itself (tfhip.h).
+        if (overlap && fb->chain_pending[set])
+            TF_HIP(hipStreamWaitEvent(ps, fb->chain_done[set], 0));
+        TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, ps));
+        TF_HIP(hipEventRecord(fb->pairs_copied, ps));
+        fb->pairs_pending = true;
         StreamScope scope(ps);
         for (int k = fb->K; k >= 0; k--) {
             Level &L = *fb->lv[k];
@@ -2128,6 +2176,11 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         coarse = result;
         fb->final_buf = result;
     }
+    if (overlap) {
+        TF_HIP(hipEventRecord(fb->chain_done[set], main_stream()));
+        fb->chain_pending[set] = true;
+    }
+    fb->cur = (set + 1) % fb->nsets;
     fb->last_pairs = n_pairs;
     return TF_OK;
 }
@@ -2316,7 +2369,7 @@ TF_API int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float 
     size_t n = (size_t)w * h;
     TF_HIP(hipMemcpyAsync(fb->img.p, img, n * 4, hipMemcpyHostToDevice, stream()));
     TF_TRY(fb_polyexp(fb, w, h, 1));
-    return download_planar5(r_out, fb->R.as<float>(), n, fb->scratch);
+    return download_planar5(r_out, fb->Rk(0), n, fb->scratch);
 }
 
 TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, const float *flow, int w, int h,
@@ -2326,9 +2379,9 @@ TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *
     TF_TRY(check_stage_size(fb, w, h));
     TF_TRY(ensure_init());
     size_t n = (size_t)w * h;
-    TF_TRY(upload_planar5(fb->R.as<float>(), r0, n, fb->scratch));
+    TF_TRY(upload_planar5(fb->Rk(0), r0, n, fb->scratch));
     TF_HIP(hipStreamSynchronize(stream()));
-    TF_TRY(upload_planar5(fb->R.as<float>() + 5 * n, r1, n, fb->scratch));
+    TF_TRY(upload_planar5(fb->Rk(0) + 5 * n, r1, n, fb->scratch));
     TF_HIP(hipMemcpyAsync(fb->lflow[0].p, flow, n * 8, hipMemcpyHostToDevice, stream()));
     FlowInit fi;
     memset(&fi, 0, sizeof(fi));

@@ -6,6 +6,8 @@
 
 #include "common.h"
 
+#include <cstdlib>
+
 namespace tf {
 
 static thread_local std::string g_last_error;
@@ -52,7 +54,14 @@ static int init_device(int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_error(TF_ERR_UNSUPPORTED, "tf_init: device %d is %s; this library is built for gfx950 only",
                          device, prop.gcnArchName);
-    TF_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    {
+        // the library stream carries the dependent chain of every job, side streams (tf_fb's preparation
+        // stream) are meant to fill its gaps: highest priority here, lowest there (measured on MI355X:
+        // no effect either way, the two queues share the CUs evenly)
+        int least = 0, greatest = 0;
+        TF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        TF_HIP(hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, greatest));
+    }
     g_device = device;
     g_inited = true;
     return TF_OK;

@@ -58,4 +58,8 @@ def kernel_bytes(name: str, n0: int, nk: int, nc: int, pairs: int) -> int:
         return pairs * (68 * nk + (8 * nc + 8 * nk if nc else 8 * nk))
     if name == "fb_blur_solve":                                # S5
         return pairs * 28 * nk
+    if name == "fb_level_polyexp":                             # S1+S2 in one kernel: stage-once sum of both
+        return pairs * 2 * (n0 + 4 * nk + 24 * nk)
+    if name == "fb_flow_iter":                                 # S4+S5 in one kernel (TF_FB_FUSED=1)
+        return kernel_bytes("fb_update_matrices", n0, nk, nc, pairs) + pairs * 28 * nk
     raise KeyError(name)
