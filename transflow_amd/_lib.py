@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfhip.so")
+# TFHIP_LIBRARY: developer override to load an alternate build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("TFHIP_LIBRARY") or os.path.join(_HERE, "libtfhip.so")
 
 TF_OK = 0
 TF_ERR_ARG = -1

@@ -1086,7 +1086,12 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                 vs[c][1] += (double)in[c].y - (double)out[c].y;
             }
             load_row(min(y + PD + M, Hk - 1), in);                // step y+PD: entering row
+#ifdef TF_ABL_NOLEAVE
+#pragma unroll
+            for (int c = 0; c < 5; c++) out[c] = make_float2(in[c].x * 0.5f, in[c].y * 0.5f);
+#else
             load_row(clampi(y + PD - 1 - M, 0, Hk - 1), out);     //            leaving row
+#endif
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1099,6 +1104,10 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
         __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
         if (is_out) {
             double g0[5], g1[5];
+#ifdef TF_ABL_NOWINDOW
+#pragma unroll
+            for (int c = 0; c < 5; c++) { g0[c] = s_e[c][lane] * scale; g1[c] = s_o[c][lane] * scale; }
+#else
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 // windows of the lane's columns 2l and 2l+1 as whole neighbour pairs plus one single
@@ -1121,6 +1130,7 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                     g1[c] = (s_o[c][lane - h] + mid + s_p[c][lane + h]) * scale;
                 }
             }
+#endif
             double idet0 = 1. / (g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
             double idet1 = 1. / (g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
             float2 f0 = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
@@ -1702,13 +1712,26 @@ static const char *lvl_name(const char *base, int k)
     return it->second.c_str();
 }
 
+// Extra dynamic LDS per preparation-kernel workgroup (bytes): caps how many of them a CU hosts, which
+// leaves wave slots to the HBM-bound flow chain running beside them on the library stream.  Measured
+// at 4K batch 16: 14 KB on the expansion kernels (4 workgroups per CU instead
+// of 7) and 8 KB on the level-image kernel give +5 % frames/s; more starves the preparation.
+static size_t prep_pad(const tf_fb *fb, bool image_kernel = false)
+{
+    static const long pad = getenv("TF_PREP_PAD_KB") ? atol(getenv("TF_PREP_PAD_KB")) : 14;
+    static const long pad_img = getenv("TF_PREP_PAD_IMG_KB") ? atol(getenv("TF_PREP_PAD_IMG_KB")) : 8;
+    if (fb->nsets < 2) // no second stream, nothing to leave room for
+        return 0;
+    return (size_t)std::max(0l, image_kernel ? pad_img : pad) * 1024;
+}
+
 static int fb_level_image(tf_fb *fb, int k, int n_pairs)
 {
     Level &L = *fb->lv[k];
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
-    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
+    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), std::min<size_t>(smem + prep_pad(fb, true), 64 * 1024),
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->imgk(k),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
 }
@@ -1806,10 +1829,10 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
     const int n = fb->pc.n;
     dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
     if (n == 5)
-        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->imgk(k),
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), prep_pad(fb), (const float *)fb->imgk(k),
                       fb->Rk(k), w, h, fb->pc);
     if (n == 7)
-        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->imgk(k),
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), prep_pad(fb), (const float *)fb->imgk(k),
                       fb->Rk(k), w, h, fb->pc);
     size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
     return launch(lvl_name("fb_polyexp_generic", k), k_polyexp, grid, dim3(256), smem,
@@ -1831,10 +1854,10 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
     dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
-        return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
+        return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), prep_pad(fb),
                       (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k),
                       L.W, L.H, kc, k1, fb->pc);
-    return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), 0,
+    return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), prep_pad(fb),
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), L.W,
                   L.H, kc, k1, fb->pc);
 }
@@ -1855,6 +1878,8 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf
     // ~16 waves per CU in flight; each segment re-sums its first window (2M+1 rows)
     long segs_wanted = std::max(1l, 4096 / std::max(1l, (long)strips * n_pairs));
     int seg = (int)std::min<long>(256, std::max<long>(8, (h + segs_wanted - 1) / segs_wanted));
+    if (getenv("TF_BLUR_SEG"))
+        seg = std::max(8, atoi(getenv("TF_BLUR_SEG")));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M[mbuf_in].as<float>(),
                   flow_out, w, h, scale, seg);
