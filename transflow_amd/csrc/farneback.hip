@@ -119,6 +119,8 @@ __device__ __forceinline__ int lerp_coord(int d, double scale, int src, bool zer
     return s;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(256)
 k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W,
               int H, int Wk, int Hk, const float *__restrict__ kern, int ksz, ImgTile tl)
@@ -226,6 +228,84 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
         const int ngroups = (no + 3) >> 2, nchunks = (nrows + 63) >> 6;
         for (int item = wave; item < ngroups * nchunks; item += 4) {
             const int b_ = item % ngroups, ry = (item / ngroups) * 64 + lane;
+            // the four columns are two interpolation pairs (sx, sx+1): base columns A and B
+            const int sxA = __builtin_amdgcn_readfirstlane(sX[min(4 * b_, no - 1) >> 1]);
+            const int sxB = __builtin_amdgcn_readfirstlane(sX[min(4 * b_ + 2, no - 1) >> 1]);
+            if (sxA + 1 < W && sxB + 1 < W) {
+                // Column sx+1 reads the byte stream of column sx one tap later, so each pair shares one
+                // stream: aligned dword reads (conflict-free: pitch/4 is odd) re-aligned to the
+                // stream's first byte, each byte converted once, and the two streams carried as the
+                // halves of float pairs so that a tap costs two packed multiplies and two packed adds
+                // for four sums.  Every sum still adds its taps left to right.
+                const int a0 = sxA - x_lo - r, b0 = sxB - x_lo - r;
+                const int da = a0 >> 2, db = b0 >> 2;
+                const unsigned sa = a0 & 3, sb = b0 & 3;
+                if (ry < nrows) {
+                    const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + ry * tl.pitch);
+                    uint32_t loA = q32[da], loB = q32[db], hiA = q32[da + 1], hiB = q32[db + 1];
+                    uint32_t wA = __builtin_amdgcn_alignbyte(hiA, loA, sa), wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+                    f32x2 p0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+                    f32x2 p1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+                    f32x2 p2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+                    f32x2 p3 = {(float)(wA >> 24), (float)(wB >> 24)};
+                    f32x2 acc0, acc1; // {A, B} and {A+1, B+1}
+                    int i = 0, t = 2;
+                    for (; i + 4 <= ksz; i += 4, t++) {
+                        loA = hiA;
+                        loB = hiB;
+                        hiA = q32[da + t];
+                        hiB = q32[db + t];
+                        wA = __builtin_amdgcn_alignbyte(hiA, loA, sa);
+                        wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+                        const f32x2 c0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+                        const f32x2 c1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+                        const f32x2 c2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+                        const f32x2 c3 = {(float)(wA >> 24), (float)(wB >> 24)};
+                        const float t0 = sK[i], t1 = sK[i + 1], t2 = sK[i + 2], t3 = sK[i + 3];
+                        if (i == 0) {
+                            acc0 = t0 * p0;
+                            acc1 = t0 * p1;
+                        } else {
+                            acc0 += t0 * p0;
+                            acc1 += t0 * p1;
+                        }
+                        acc0 += t1 * p1;
+                        acc1 += t1 * p2;
+                        acc0 += t2 * p2;
+                        acc1 += t2 * p3;
+                        acc0 += t3 * p3;
+                        acc1 += t3 * c0;
+                        p0 = c0;
+                        p1 = c1;
+                        p2 = c2;
+                        p3 = c3;
+                    }
+                    if (i < ksz) { // up to three taps left; they need p0..p3 only
+                        float tt = sK[i];
+                        acc0 += tt * p0;
+                        acc1 += tt * p1;
+                        if (i + 1 < ksz) {
+                            tt = sK[i + 1];
+                            acc0 += tt * p1;
+                            acc1 += tt * p2;
+                        }
+                        if (i + 2 < ksz) {
+                            tt = sK[i + 2];
+                            acc0 += tt * p2;
+                            acc1 += tt * p3;
+                        }
+                    }
+                    float *out = sR + ry * tl.rstride + 4 * b_;
+                    out[0] = acc0.x;
+                    out[1] = acc1.x;
+                    if (4 * b_ + 2 < no) {
+                        out[2] = acc0.y;
+                        out[3] = acc1.y;
+                    }
+                }
+                continue;
+            }
+            // a pair at the right image border (sx + 1 clamps to sx): plain per-column streams
             int cofs[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1086,12 +1166,7 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                 vs[c][1] += (double)in[c].y - (double)out[c].y;
             }
             load_row(min(y + PD + M, Hk - 1), in);                // step y+PD: entering row
-#ifdef TF_ABL_NOLEAVE
-#pragma unroll
-            for (int c = 0; c < 5; c++) out[c] = make_float2(in[c].x * 0.5f, in[c].y * 0.5f);
-#else
             load_row(clampi(y + PD - 1 - M, 0, Hk - 1), out);     //            leaving row
-#endif
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1104,10 +1179,6 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
         __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
         if (is_out) {
             double g0[5], g1[5];
-#ifdef TF_ABL_NOWINDOW
-#pragma unroll
-            for (int c = 0; c < 5; c++) { g0[c] = s_e[c][lane] * scale; g1[c] = s_o[c][lane] * scale; }
-#else
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 // windows of the lane's columns 2l and 2l+1 as whole neighbour pairs plus one single
@@ -1130,7 +1201,6 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                     g1[c] = (s_o[c][lane - h] + mid + s_p[c][lane + h]) * scale;
                 }
             }
-#endif
             double idet0 = 1. / (g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
             double idet1 = 1. / (g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
             float2 f0 = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
