@@ -498,6 +498,30 @@ __global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, 
 // adjacent outputs from one window of 2+2N triples.  ~25 DS operations per pixel instead of ~62.
 typedef float float2w __attribute__((ext_vector_type(2), aligned(4)));
 
+// FarnebackPolyExp's vertical pass for four consecutive rows of two adjacent columns: v[j] holds
+// rows y0-N+j of the column pair; results go to the three planes at rows 0..3 (row stride LW).
+template <int N>
+__device__ __forceinline__ void polyexp_vertical4(const f32x2 (&v)[4 + 2 * N], const PolyConst &pc, float *T0, float *T1,
+                                                  float *T2, int LW)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x2 c = v[q + N];
+        f32x2 t0 = c * pc.g[0], t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 1; k <= N; k++) {
+            const f32x2 a = v[q + N - k], b = v[q + N + k]; // rows y-k and y+k (clamped when staged)
+            const f32x2 p = a + b;
+            t0 = t0 + pc.g[k] * p;
+            t1 = t1 + pc.xg[k] * (b - a);
+            t2 = t2 + pc.xxg[k] * p;
+        }
+        *reinterpret_cast<f32x2 *>(T0 + q * LW) = t0;
+        *reinterpret_cast<f32x2 *>(T1 + q * LW) = t1;
+        *reinterpret_cast<f32x2 *>(T2 + q * LW) = t2;
+    }
+}
+
 template <int N>
 __global__ void __launch_bounds__(256)
 k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
@@ -515,29 +539,16 @@ k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk
         sI[idx] = src[(size_t)y * Wk + x];
     }
     __syncthreads();
-    // vertical pass (float): item = (column, group of 4 rows)
-    for (int idx = threadIdx.x; idx < (TH / 4) * LW; idx += 256) {
-        const int g = idx / LW, cx = idx - g * LW;
-        float v[4 + 2 * N];
+    // vertical pass (float): item = (pair of columns, group of 4 rows); the two columns ride in
+    // the halves of packed fp32 operations
+    static_assert(LW % 2 == 0, "column pairs");
+    for (int idx = threadIdx.x; idx < (TH / 4) * (LW / 2); idx += 256) {
+        const int g = idx / (LW / 2), cx = 2 * (idx - g * (LW / 2));
+        f32x2 v[4 + 2 * N];
 #pragma unroll
         for (int j = 0; j < 4 + 2 * N; j++)
-            v[j] = sI[(4 * g + j) * LW + cx];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float c = v[q + N];
-            float t0 = c * pc.g[0], t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int k = 1; k <= N; k++) {
-                float a = v[q + N - k], b = v[q + N + k]; // rows y-k and y+k (clamped when staged)
-                float p = a + b;
-                t0 = t0 + pc.g[k] * p;
-                t1 = t1 + pc.xg[k] * (b - a);
-                t2 = t2 + pc.xxg[k] * p;
-            }
-            sT[0][4 * g + q][cx] = t0;
-            sT[1][4 * g + q][cx] = t1;
-            sT[2][4 * g + q][cx] = t2;
-        }
+            v[j] = *reinterpret_cast<const f32x2 *>(&sI[(4 * g + j) * LW + cx]);
+        polyexp_vertical4<N>(v, pc, &sT[0][4 * g][cx], &sT[1][4 * g][cx], &sT[2][4 * g][cx], LW);
     }
     __syncthreads();
     // horizontal pass (double): item = (row, pair of columns)
@@ -690,29 +701,24 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
     }
     __syncthreads();
     // polynomial expansion, vertical pass: virtual row y0-N+j reads real row clamp(...) - yr0
-    for (int idx = threadIdx.x; idx < (TH / 4) * LW; idx += 256) {
-        const int g = idx / LW, cx = idx - g * LW;
-        const int xc = clampi(x0 - N + cx, 0, W - 1) - xr0;
-        float v[4 + 2 * N];
+    // (an interior tile reads rows/columns 4g+j / cx directly; a border tile clamps them)
+    const bool interior = x0 - N >= 0 && x0 + TW - 1 + N <= W - 1 && y0 - N >= 0 && y0 + TH - 1 + N <= H - 1;
+    for (int idx = threadIdx.x; idx < (TH / 4) * (LW / 2); idx += 256) {
+        const int g = idx / (LW / 2), cx = 2 * (idx - g * (LW / 2));
+        f32x2 v[4 + 2 * N];
+        if (interior) {
 #pragma unroll
-        for (int j = 0; j < 4 + 2 * N; j++)
-            v[j] = sI[(clampi(y0 - N + 4 * g + j, 0, H - 1) - yr0) * LW + xc];
+            for (int j = 0; j < 4 + 2 * N; j++)
+                v[j] = *reinterpret_cast<const f32x2 *>(&sI[(4 * g + j) * LW + cx]);
+        } else {
+            const int xa = clampi(x0 - N + cx, 0, W - 1) - xr0, xb = clampi(x0 - N + cx + 1, 0, W - 1) - xr0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float c = v[q + N];
-            float t0 = c * pc.g[0], t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int k = 1; k <= N; k++) {
-                float a = v[q + N - k], b = v[q + N + k];
-                float p = a + b;
-                t0 = t0 + pc.g[k] * p;
-                t1 = t1 + pc.xg[k] * (b - a);
-                t2 = t2 + pc.xxg[k] * p;
+            for (int j = 0; j < 4 + 2 * N; j++) {
+                const float *row = sI + (clampi(y0 - N + 4 * g + j, 0, H - 1) - yr0) * LW;
+                v[j] = f32x2{row[xa], row[xb]};
             }
-            sT[0][4 * g + q][cx] = t0;
-            sT[1][4 * g + q][cx] = t1;
-            sT[2][4 * g + q][cx] = t2;
         }
+        polyexp_vertical4<N>(v, pc, &sT[0][4 * g][cx], &sT[1][4 * g][cx], &sT[2][4 * g][cx], LW);
     }
     __syncthreads();
     float *dst = R + (size_t)pi * 5 * Nk;
