@@ -301,6 +301,29 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl)
     if world == 1 and not args.no_extra:
+        # the same kernel with nothing beside it: a second handle created with the preparation stream
+        # disabled (in the timed region above the next call's frame expansion runs beside the chain)
+        os.environ["TF_FB_NO_OVERLAP"] = "1"
+        try:
+            j = Job(wl, args.batch, seed=2000, device=local_rank)
+        finally:
+            del os.environ["TF_FB_NO_OVERLAP"]
+        for _ in range(2):
+            j.step()
+        j.sync()
+        j.prof_reset()
+        j.prof(True, dominant)
+        n = 5
+        for _ in range(n):
+            j.step()
+        j.sync()
+        j.prof(False)
+        cnt, ms = j.prof_report()[dominant]
+        ach = kernel_alg_bytes(dominant, wl, args.batch) * n / (ms * 1e-3) / 1e9
+        out["roofline"]["exclusive"] = {"what": "same kernel, same workload, preparation stream disabled (nothing runs beside it); untimed region",
+                                        "launches": cnt, "avg_launch_ms": ms / max(1, cnt), "achieved": ach,
+                                        "frac": ach / rf.HBM_PEAK_GBS}
+        del j
         extra = {}
         for name in ("1080p", "1080p-1level"):
             if name == args.workload:

@@ -476,8 +476,8 @@ __global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, 
         for (int k = 1; k <= n; k++) {
             double tg = T0[k] + T0[-k];
             g0 = pc.g[k];
-            b1 += tg * g0;
-            b4 += tg * pc.xxg[k];
+            b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+            b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
             b2 += (T0[k] - T0[-k]) * pc.xg[k];
             b3 += (T1[k] + T1[-k]) * g0;
             b6 += (T1[k] - T1[-k]) * pc.xg[k];
@@ -575,8 +575,8 @@ k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk
             for (int k = 1; k <= N; k++) {
                 double tg = T0[k] + T0[-k];
                 g0 = pc.g[k];
-                b1 += tg * g0;
-                b4 += tg * pc.xxg[k];
+                b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+                b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
                 b2 += (T0[k] - T0[-k]) * pc.xg[k];
                 b3 += (T1[k] + T1[-k]) * g0;
                 b6 += (T1[k] - T1[-k]) * pc.xg[k];
@@ -744,8 +744,8 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
             for (int k = 1; k <= N; k++) {
                 double tg = T0[k] + T0[-k];
                 g0 = pc.g[k];
-                b1 += tg * g0;
-                b4 += tg * pc.xxg[k];
+                b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+                b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
                 b2 += (T0[k] - T0[-k]) * pc.xg[k];
                 b3 += (T1[k] + T1[-k]) * g0;
                 b6 += (T1[k] - T1[-k]) * pc.xg[k];
@@ -1767,11 +1767,8 @@ struct tf_fb {
     }
 };
 
-static bool fb_overlap_enabled()
-{
-    static const bool on = !(getenv("TF_FB_NO_OVERLAP") && atoi(getenv("TF_FB_NO_OVERLAP")) != 0);
-    return on;
-}
+// read when a handle is created: TF_FB_NO_OVERLAP=1 keeps everything on the library stream
+static bool fb_overlap_enabled() { return !(getenv("TF_FB_NO_OVERLAP") && atoi(getenv("TF_FB_NO_OVERLAP")) != 0); }
 
 // Profiler labels: with TF_PROF_LEVELS=1 in the environment every Farneback launch is
 // labelled with its pyramid level ("fb_polyexp.k2"), otherwise by kernel only.
