@@ -148,12 +148,20 @@ int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_
 int tf_fb_level_count(tf_fb *fb, int *n_scales); /* K+1 */
 int tf_fb_level_size(tf_fb *fb, int level, int *w, int *h);
 
-/* ---- compositor remap (one `moveref` layer) -------------------------------------
- * Replaces MoveReferenceLayer (transflow/compositor/layers/move_reference.py:6-14):
- * MovementLayer.update (movement.py:20-64), ReferenceLayer.update
- * (reference.py:58-109), Layer.render (layer.py:32-34).  tf_layer_cfg carries the
- * LayerConfig fields the layer reads (transflow/config.py:88-98).
+/* ---- compositor layers -----------------------------------------------------------
+ * One handle = one layer of the compositor.  layer_class selects which of the reference's
+ * layer classes it is (Layer.from_args, transflow/compositor/layers/layer.py:44-56):
+ *   TF_LAYER_MOVEREF       MoveReferenceLayer (move_reference.py:6-14): MovementLayer.update
+ *                          (movement.py:20-64) then ReferenceLayer.update (reference.py:58-109)
+ *   TF_LAYER_SUM           SumLayer (sum.py:7-14): (i, j) += floor(flow), then ReferenceLayer.update
+ *   TF_LAYER_STATIC        StaticLayer (static.py:7-17): pixmaps copied where introduced
+ *   TF_LAYER_INTRODUCTION  IntroductionLayer (introduction.py:8-73): 8-channel canvas
+ *                          (r, g, b, alpha, source, i, j, frame), moved by the flow, then fed
+ * and Layer.render (layer.py:32-34) for all of them.  tf_layer_cfg carries the LayerConfig
+ * fields the layers read (transflow/config.py:88-105).
  */
+enum { TF_LAYER_MOVEREF = 0, TF_LAYER_SUM = 1, TF_LAYER_STATIC = 2, TF_LAYER_INTRODUCTION = 3 };
+
 typedef struct tf_layer_cfg {
     int transparent_pixels_can_move;    /* False */
     int pixels_can_move_to_empty_spot;  /* True  */
@@ -164,6 +172,16 @@ typedef struct tf_layer_cfg {
     double reset_constant_step;         /* 1   */
     double reset_linear_factor;         /* 0.1 */
     int reset_source;                   /* False */
+    int layer_class;                    /* TF_LAYER_*; 0 = moveref */
+    /* introduction.py:24-44.  As the reference is written, on_empty_spots, unmoving_pixels and
+       the mask write of on_all_empty_spots index with the Python value False and select nothing;
+       they are carried for completeness, on_all_empty_spots still turns `consider_flow` off (:40). */
+    int introduce_pixels_on_empty_spots;  /* True  (no effect) */
+    int introduce_pixels_on_filled_spots; /* True  */
+    int introduce_moving_pixels;          /* True  */
+    int introduce_unmoving_pixels;        /* True  (no effect) */
+    int introduce_on_all_filled_spots;    /* False */
+    int introduce_on_all_empty_spots;     /* False */
 } tf_layer_cfg;
 
 typedef struct tf_remap tf_remap;
@@ -171,7 +189,8 @@ typedef struct tf_comp tf_comp;
 
 /* Masks are [height][width]; NULL = the reference's default (mask_src/mask_dst all
    true, mask_alpha/reset_mask all 1.0: layer.py:24, movement.py:14-15, reference.py:44).
-   data starts as (i, j, 1, 0) per pixel (reference.py:40-42). */
+   moveref/sum: data starts as (i, j, 1, 0) per pixel (reference.py:40-42); introduction: an
+   all-zero 8-channel canvas (data.py:17); static: no data, rgba alpha = 1 (static.py:11). */
 int tf_remap_create(tf_remap **out, int height, int width, const tf_layer_cfg *cfg, const uint8_t *mask_src,
                     const uint8_t *mask_dst, const float *mask_alpha, const float *reset_mask);
 void tf_remap_destroy(tf_remap *layer);
@@ -180,7 +199,11 @@ void tf_remap_destroy(tf_remap *layer);
    (uint8 [height][width] each) and writes source index s where mask s is set. */
 int tf_remap_set_sources(tf_remap *layer, int n_sources, const uint8_t *const *introduction_masks);
 
-/* MovementLayer.update + ReferenceLayer._update_reset.  `flow` float32 [H][W][2]
+/* The flow-dependent part of Layer.update.  moveref: MovementLayer.update +
+   ReferenceLayer._update_reset; sum: the accumulation (sum.py:10) + _update_reset;
+   introduction: MovementLayer.update on the 8-channel canvas and the introduction mask
+   (introduction.py:24-44) for the tf_remap_introduce calls that follow; static: nothing
+   (static.py:13 ignores the flow).  `flow` float32 [H][W][2]
    (already post-processed).  `uniform`: float64 [H][W] in [0,1) -- the field the
    reference draws with numpy.random.random (reference.py:59) -- or NULL to draw it
    on the GPU from `seed` and the handle's frame counter.  Returns TF_ERR_INDEX if a
@@ -191,10 +214,19 @@ int tf_remap_update_dev(tf_remap *layer, const void *flow_dev, const void *unifo
    the last call saw an out-of-frame vector (those updates were skipped). */
 int tf_remap_check(tf_remap *layer, int *out_of_frame);
 
-/* One iteration of ReferenceLayer._update_rgba's loop (reference.py:94-105) for
-   source `source_index`; pixmap is uint8 [H][W][channels], channels 3 or 4. */
+/* One iteration of the per-source loop for source `source_index`; pixmap is uint8
+   [H][W][channels], channels 3 or 4.  moveref/sum: ReferenceLayer._update_rgba
+   (reference.py:94-105); static: the masked copy of static.py:14-17. */
 int tf_remap_gather(tf_remap *layer, int source_index, const uint8_t *pixmap, int channels);
 int tf_remap_gather_dev(tf_remap *layer, int source_index, const void *pixmap_dev, int channels);
+
+/* Introduction layer: one iteration of introduction.py:46-63 -- every target selected by the
+   mask tf_remap_update left and by the source's introduction mask takes the record
+   (pixmap[s], [1 if RGB], source_index, i(s), j(s), frame_number) of s = target + rounded flow
+   (s = target when an introduce_on_all_* flag is set).  introduce_once is the caller's business
+   (introduction.py:21-23 returns before the sources are even asked for a frame). */
+int tf_remap_introduce(tf_remap *layer, int source_index, const uint8_t *pixmap, int channels, int frame_number);
+int tf_remap_introduce_dev(tf_remap *layer, int source_index, const void *pixmap_dev, int channels, int frame_number);
 
 /* Layer.render (layer.py:32-34) + this layer's turn in Compositor.render
    (compositor.py:36-39): alpha := uint8(mask_alpha*alpha) in place, then paint the
@@ -213,7 +245,10 @@ int tf_remap_step_dev(tf_remap *layer, tf_comp *comp, const void *flow_dev, int 
 
 /* State exchange for checkpoints (pipeline.py:225-242 pickles the compositor) and
    for extra/control.py:146-162 which reads layer.data.  data int32 [H][W][4]
-   (i, j, alpha, source), rgba uint8 [H][W][4]; either pointer may be NULL. */
+   (i, j, alpha, source) -- [H][W][8] for an introduction layer, absent for a static one;
+   rgba uint8 [H][W][4] (an introduction layer's rgba IS data[..., :4]: pass NULL).
+   Either pointer may be NULL.  tf_remap_data_depth: 4, 8 or 0. */
+int tf_remap_data_depth(tf_remap *layer, int *depth);
 int tf_remap_get_state(tf_remap *layer, int32_t *data, uint8_t *rgba);
 int tf_remap_set_state(tf_remap *layer, const int32_t *data, const uint8_t *rgba);
 

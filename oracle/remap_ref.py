@@ -170,7 +170,7 @@ def flow_to_offsets(flow: np.ndarray) -> np.ndarray:
 
 
 def move(data: np.ndarray, flow: np.ndarray, mask_src: np.ndarray,
-         mask_dst: np.ndarray, prm: LayerParams) -> np.ndarray:
+         mask_dst: np.ndarray, prm: LayerParams, alpha_index: int = INDEX_ALPHA) -> np.ndarray:
     """movement.py:25-60 as a per-target gather.  Returns the new data array.
 
     The reference indexes ``flat[shift]`` with python semantics (negative
@@ -179,15 +179,15 @@ def move(data: np.ndarray, flow: np.ndarray, mask_src: np.ndarray,
     out-of-frame source raises IndexError for both cases' superset that the
     HIP path rejects: s < 0 or s >= H*W.
     """
-    h, w, _ = data.shape
+    h, w, depth = data.shape
     n = h * w
     d = flow_to_offsets(flow).astype(np.int64)
     t = np.arange(n, dtype=np.int64)
     s = t + d
     if s.min(initial=0) < 0 or s.max(initial=0) >= n:
         raise IndexError("flow leaves the frame; run post_process first")
-    old = data.reshape(n, 4)
-    a_old = old[:, INDEX_ALPHA]
+    old = data.reshape(n, depth)
+    a_old = old[:, alpha_index]
     ms = np.asarray(mask_src, dtype=bool).ravel()[s]          # :39
     src_filled = a_old[s] != 0
     if not prm.transparent_pixels_can_move:                   # :35-38
@@ -201,12 +201,12 @@ def move(data: np.ndarray, flow: np.ndarray, mask_src: np.ndarray,
     new = old.copy()
     new[in_t] = old[s[in_t]]                                  # :51-52
     if prm.moving_pixels_leave_empty_spot:                    # :53-54
-        new[s[in_t], INDEX_ALPHA] = 0
+        new[s[in_t], alpha_index] = 0
     if prm.transparent_pixels_can_move:                       # :55-58
-        new[in_t & src_filled, INDEX_ALPHA] = 1
+        new[in_t & src_filled, alpha_index] = 1
     else:                                                     # :59-60
-        new[in_t, INDEX_ALPHA] = 1
-    return new.reshape(h, w, 4)
+        new[in_t, alpha_index] = 1
+    return new.reshape(h, w, depth)
 
 
 # --------------------------------------------------------------------------
@@ -329,3 +329,140 @@ class MoveRefLayer:
 
     def render(self):
         return layer_render(self.rgba, self.mask_alpha)
+
+
+# --------------------------------------------------------------------------
+# N2  the other layer classes (layer.py:44-56)
+# --------------------------------------------------------------------------
+class SumLayer(MoveRefLayer):
+    """compositor/layers/sum.py:7-14: a ReferenceLayer (no move) whose (i, j) accumulate
+    floor(flow) -- flow channel 0 goes to i and channel 1 to j, as written (:10) -- followed
+    by ReferenceLayer.update (reset, then the rgba gather: reference.py:107-109)."""
+
+    def update(self, flow, pixmaps=(), u=None):
+        self.data[:, :, 0:2] += np.floor(flow).astype(np.int32)    # sum.py:10
+        reset(self.data, self.prm, self.reset_mask, u, self.introduction_masks)
+        for s, pm in enumerate(pixmaps):
+            gather_rgba(self.rgba, self.data, s, pm)
+
+
+class StaticLayer:
+    """compositor/layers/static.py:7-17: alpha starts at 1 (:11); every update copies each
+    source's pixmap where its introduction mask is set (:14-17)."""
+
+    def __init__(self, h, w, mask_alpha=None, introduction_masks=()):
+        self.h, self.w = h, w
+        self.mask_alpha = np.ones((h, w), np.float32) if mask_alpha is None else np.asarray(mask_alpha, np.float32)
+        self.introduction_masks = [np.asarray(m, bool) for m in introduction_masks]
+        self.rgba = np.zeros((h, w, 4), np.uint8)
+        self.rgba[:, :, 3] = 1
+
+    def update(self, flow, pixmaps=(), u=None):
+        for m, pm in zip(self.introduction_masks, pixmaps):
+            self.rgba[:, :, :pm.shape[2]][m] = pm[m]
+
+    def render(self):
+        return layer_render(self.rgba, self.mask_alpha)
+
+
+INTRO_DEPTH = 8  # r, g, b, alpha, source, i, j, frame   (introduction.py:10-14)
+INTRO_ALPHA = 3
+
+
+class IntroParams(LayerParams):
+    """LayerParams + the introduce_* fields of LayerConfig (config.py:99-105)."""
+
+    def __init__(self, introduce_pixels_on_empty_spots=True, introduce_pixels_on_filled_spots=True,
+                 introduce_moving_pixels=True, introduce_unmoving_pixels=True, introduce_once=False,
+                 introduce_on_all_filled_spots=False, introduce_on_all_empty_spots=False, **kw):
+        LayerParams.__init__(self, **kw)
+        self.introduce_pixels_on_empty_spots = bool(introduce_pixels_on_empty_spots)
+        self.introduce_pixels_on_filled_spots = bool(introduce_pixels_on_filled_spots)
+        self.introduce_moving_pixels = bool(introduce_moving_pixels)
+        self.introduce_unmoving_pixels = bool(introduce_unmoving_pixels)
+        self.introduce_once = bool(introduce_once)
+        self.introduce_on_all_filled_spots = bool(introduce_on_all_filled_spots)
+        self.introduce_on_all_empty_spots = bool(introduce_on_all_empty_spots)
+
+
+def introduction_mask(data: np.ndarray, offsets: np.ndarray, prm: IntroParams) -> np.ndarray:
+    """introduction.py:24-44: which targets may receive an introduced pixel.
+
+    As written in the reference, `where_empty` (:27) and the unmoving selection (:37) are the
+    comparison `numpy.where(...) == 0` of a TUPLE with 0, i.e. the Python value False; indexing
+    with False selects nothing, so introduce_pixels_on_empty_spots, introduce_unmoving_pixels and
+    the mask write of introduce_on_all_empty_spots (:43) have no effect on the mask (the latter
+    still switches `consider_flow` off, :40).  Pinned by tests/golden/layer2_intro_*.npz.
+    """
+    h, w, _ = data.shape
+    filled = data[:, :, INTRO_ALPHA] != 0                          # :28
+    mask = np.ones((h, w), dtype=bool)                             # :25
+    if not prm.introduce_pixels_on_filled_spots:                   # :32-33
+        mask[filled] = False
+    if not prm.introduce_moving_pixels:                            # :34-35
+        mask[(offsets != 0).reshape(h, w)] = False
+    if prm.introduce_on_all_filled_spots:                          # :41-42
+        mask[filled] = True
+    return mask
+
+
+def introduce(data: np.ndarray, mask: np.ndarray, offsets: np.ndarray, prm: IntroParams, source_index: int,
+              pixmap: np.ndarray, intro_mask: np.ndarray, frame_number: int) -> None:
+    """One iteration of the per-source loop, introduction.py:46-63, in place: target t takes the
+    8-channel record (pixmap[s], [1 if RGB], source index, base(s), frame number) of
+    s = t + offset(t) -- or of t itself when either introduce_on_all_* flag is set (:40, :50-53)."""
+    h, w, _ = data.shape
+    n = h * w
+    sel = (mask & np.asarray(intro_mask, bool)).ravel()            # :48
+    t = np.nonzero(sel)[0]
+    consider_flow = not (prm.introduce_on_all_filled_spots or prm.introduce_on_all_empty_spots)
+    s = t + offsets.astype(np.int64)[t] if consider_flow else t
+    if s.size and (s.min() < 0 or s.max() >= n):
+        raise IndexError("flow leaves the frame; run post_process first")
+    c = pixmap.shape[2]
+    rec = np.zeros((n, INTRO_DEPTH), dtype=np.int32)
+    rec[:, :c] = pixmap.reshape(n, c)
+    if c == 3:
+        rec[:, 3] = 1                                              # :61-62
+    rec[:, 4] = source_index
+    rec[:, 5:7] = base_indices(h, w).reshape(n, 2)
+    rec[:, 7] = frame_number
+    flat = data.reshape(n, INTRO_DEPTH)
+    flat[t] = rec[s]                                               # :63
+
+
+class IntroductionLayer:
+    """compositor/layers/introduction.py:8-73 (a MovementLayer with an 8-channel canvas)."""
+
+    def __init__(self, h, w, prm: IntroParams | None = None, mask_src=None, mask_dst=None, mask_alpha=None,
+                 introduction_masks=()):
+        self.h, self.w = h, w
+        self.prm = prm or IntroParams()
+        self.mask_src = np.ones((h, w), bool) if mask_src is None else np.asarray(mask_src, bool)
+        self.mask_dst = np.ones((h, w), bool) if mask_dst is None else np.asarray(mask_dst, bool)
+        self.mask_alpha = np.ones((h, w), np.float32) if mask_alpha is None else np.asarray(mask_alpha, np.float32)
+        self.introduction_masks = list(introduction_masks)
+        self.data = np.zeros((h, w, INTRO_DEPTH), np.int32)        # data.py:17: an empty canvas
+        self.introduced_once = False
+
+    @property
+    def rgba(self):
+        return self.data[:, :, :4]                                 # :65-66: a VIEW of data (int32)
+
+    def update(self, flow, pixmaps=(), frame_numbers=None, u=None):
+        self.data = move(self.data, flow, self.mask_src, self.mask_dst, self.prm, alpha_index=INTRO_ALPHA)
+        if self.prm.introduce_once and self.introduced_once:       # :21-22 (no source.next() either)
+            return
+        self.introduced_once = True
+        offsets = flow_to_offsets(flow)
+        mask = introduction_mask(self.data, offsets, self.prm)
+        for s, pm in enumerate(pixmaps):
+            fn = 0 if frame_numbers is None else frame_numbers[s]
+            introduce(self.data, mask, offsets, self.prm, s, pm, self.introduction_masks[s], fn)
+
+    def render(self):
+        """layer.py:32-34 on the int32 view: alpha := int32(mask_alpha * alpha) written back into
+        `data` (float32 times int32 is float64 in numpy; the store truncates), result clipped to u8."""
+        a = self.mask_alpha.astype(np.float64) * self.data[:, :, INTRO_ALPHA]
+        self.data[:, :, INTRO_ALPHA] = a.astype(np.int32)
+        return np.clip(self.data[:, :, :4], 0, 255).astype(np.uint8)

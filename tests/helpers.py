@@ -60,3 +60,38 @@ def synth_pair(h, w, seed=1234, shift=(3.0, 2.0), noise=6.0):
     fa = np.clip(np.rint(tex(xx, yy) + n0), 0, 255).astype(np.uint8)
     fb = np.clip(np.rint(tex(xx - u, yy - v) + n1), 0, 255).astype(np.uint8)
     return fa, fb
+
+
+def layer2_case_files():
+    """sum / static / introduction layer recurrences (tools/capture_golden.py --layers2-only)."""
+    return sorted(glob.glob(os.path.join(GOLDEN, "layer2_*.npz")))
+
+
+INTRO_KEYS = ("introduce_pixels_on_empty_spots", "introduce_pixels_on_filled_spots", "introduce_moving_pixels",
+              "introduce_unmoving_pixels", "introduce_once", "introduce_on_all_filled_spots",
+              "introduce_on_all_empty_spots")
+
+
+def oracle_layer2(z):
+    """The oracle's layer object for one layer2_* fixture."""
+    cfg = case_cfg(z)
+    h, w, ns = int(z["h"]), int(z["w"]), int(z["nsources"])
+    intro = [z[f"intro_{s}"] for s in range(ns)]
+    cls = str(z["classname"])
+    if cls == "sum":
+        return remap_ref.SumLayer(h, w, oracle_params(cfg), mask_alpha=z["mask_alpha"], reset_mask=z["reset_mask"],
+                                  introduction_masks=intro)
+    if cls == "static":
+        return remap_ref.StaticLayer(h, w, mask_alpha=z["mask_alpha"], introduction_masks=intro)
+    if cls == "introduction":
+        prm = remap_ref.IntroParams(**{k: v for k, v in cfg.items() if k in PRM_KEYS + INTRO_KEYS})
+        return remap_ref.IntroductionLayer(h, w, prm, mask_src=z["mask_src"], mask_dst=z["mask_dst"],
+                                           mask_alpha=z["mask_alpha"], introduction_masks=intro)
+    raise ValueError(cls)
+
+
+def capture_frame_numbers(prm, t, ns):
+    """Frame numbers the capture's sources reported at frame t (FakeSource.frame_number = number of
+    next() calls - 1): one call per frame in which the layer introduced, i.e. every frame, or only
+    the first with introduce_once."""
+    return [0 if prm.introduce_once else t] * ns

@@ -1,0 +1,111 @@
+"""GPU parity of the sum / static / introduction layer classes: the reference's own
+vectors (tests/golden/layer2_*.npz) through HipCompositor, bit for bit."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.helpers import case_cfg, layer2_case_files
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeSource:
+    """PixmapSourceInterface stand-in (pixmap_source_interface.py:12-37), as the capture script's."""
+
+    def __init__(self, frames, introduction_mask):
+        self.frames, self.introduction_mask, self.counter = list(frames), introduction_mask, -1
+
+    def next(self, timeout=1):
+        self.counter += 1
+        return self.frames[self.counter % len(self.frames)]
+
+    @property
+    def frame_number(self):
+        return self.counter
+
+
+def _compositor(z):
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    h, w = int(z["h"]), int(z["w"])
+    comp = HipCompositor.from_args(h, w, [LayerConfig(0, classname=str(z["classname"]), **case_cfg(z))],
+                                   background_color="#%02x%02x%02x" % tuple(int(v) for v in z["background"]))
+    layer = comp.layers[0]
+    # the capture script installed arbitrary mask arrays on the reference layer: do the same here
+    for key in ("mask_src", "mask_dst", "mask_alpha", "reset_mask"):
+        if key in z.files:
+            setattr(layer, key, z[key])
+    ns = int(z["nsources"])
+    comp.set_sources({0: [FakeSource(z[f"pixmap_{s}"], z[f"intro_{s}"]) for s in range(ns)]})
+    return comp, layer
+
+
+@pytest.mark.parametrize("path", layer2_case_files(), ids=lambda p: os.path.basename(p)[7:-4])
+def test_layer2_matches_reference_vectors(path):
+    z = np.load(path)
+    comp, layer = _compositor(z)
+    has_data = "data_init" in z.files
+    if has_data:
+        np.testing.assert_array_equal(layer.data, z["data_init"])
+        assert layer.data.shape[2] == layer.DEPTH
+    np.testing.assert_array_equal(layer.rgba, z["rgba_init"])
+    orig = np.random.random
+    for t in range(int(z["nframes"])):
+        np.random.random = lambda size=None, _u=z[f"u_{t}"]: _u.copy()
+        try:
+            comp.update(z[f"flow_{t}"])
+        finally:
+            np.random.random = orig
+        if has_data:
+            np.testing.assert_array_equal(layer.data, z[f"data_{t}"], err_msg=f"data t={t}")
+        np.testing.assert_array_equal(layer.rgba, z[f"rgba_{t}"], err_msg=f"rgba t={t}")
+        frame = comp.render()
+        np.testing.assert_array_equal(frame, z[f"frame_{t}"], err_msg=f"frame t={t}")
+        np.testing.assert_array_equal(layer.rgba, z[f"rgba_after_render_{t}"], err_msg=f"rgba after render t={t}")
+        if has_data:
+            np.testing.assert_array_equal(layer.data, z[f"data_after_render_{t}"])
+    comp.close()
+
+
+@pytest.mark.parametrize("name", ["intro_once_leave_two_rgba", "sum_reset_random", "static_rgba_two"])
+def test_layer2_checkpoint_roundtrip(name):
+    """Pickle after two frames, continue on the copy: same frames as the uninterrupted run
+    (pipeline.py:225-242, 290-306: sources are stripped before pickling and re-installed after)."""
+    z = np.load([p for p in layer2_case_files() if name in p][0])
+    comp, layer = _compositor(z)
+    orig = np.random.random
+    try:
+        for t in range(int(z["nframes"])):
+            if t == 2:
+                sources = layer.sources
+                blob = pickle.dumps(comp)
+                comp.close()
+                comp = pickle.loads(blob)
+                layer = comp.layers[0]
+                comp.set_sources({0: sources})
+            np.random.random = lambda size=None, _u=z[f"u_{t}"]: _u.copy()
+            comp.update(z[f"flow_{t}"])
+            np.testing.assert_array_equal(comp.render(), z[f"frame_{t}"], err_msg=f"frame t={t}")
+    finally:
+        np.random.random = orig
+    comp.close()
+
+
+def test_layer2_argument_errors():
+    from transflow_amd._lib import TfError
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    from transflow_amd.remap import RemapLayer
+    with pytest.raises(ValueError):
+        HipCompositor.from_args(4, 4, [LayerConfig(0, classname="nope")])         # layer.py:56
+    intro = RemapLayer(4, 5, layer_class="introduction")
+    pm = np.zeros((4, 5, 3), np.uint8)
+    with pytest.raises((TfError, ValueError, RuntimeError)):
+        intro.gather(0, pm)            # introduction layers take pixmaps through introduce()
+    with pytest.raises((TfError, ValueError, RuntimeError)):
+        intro.introduce(0, pm, 0)      # no sources / no update yet
+    mv = RemapLayer(4, 5)
+    with pytest.raises((TfError, ValueError, RuntimeError)):
+        mv.introduce(0, pm, 0)

@@ -177,8 +177,15 @@ def test_compositor_surface_and_pickle_without_gpu():
     blob = pickle.dumps(comp)                                         # never touched the GPU
     back = pickle.loads(blob)
     assert back.layers[0].sources == [] and back.layers[0].config.reset_mode == "random"
-    with pytest.raises(NotImplementedError):
-        HipCompositor.from_args(4, 6, [LayerConfig(0, classname="sum")])
+    from transflow_amd.compositor import HipIntroductionLayer, HipStaticLayer, HipSumLayer
+    others = HipCompositor.from_args(4, 6, [LayerConfig(0, classname="sum"), LayerConfig(1, classname="static"),
+                                            LayerConfig(2, classname="introduction")])
+    assert [type(x) for x in others.layers] == [HipSumLayer, HipStaticLayer, HipIntroductionLayer]
+    intro = others.layers[2]
+    assert (intro.INDEX_I, intro.INDEX_J, intro.INDEX_ALPHA, intro.INDEX_SOURCE, intro.DEPTH) == (5, 6, 3, 4, 8)
+    assert not hasattr(others.layers[0], "mask_src") and not hasattr(others.layers[1], "reset_mask")
+    with pytest.raises(ValueError):
+        HipCompositor.from_args(4, 6, [LayerConfig(0, classname="reference")])     # layer.py:56
     with pytest.raises(ValueError):
         HipCompositor.from_args(4, 6, [LayerConfig(0, reset_mode="never")])
 

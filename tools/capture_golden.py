@@ -95,12 +95,13 @@ def smooth_mask(rng, h, w):
 
 def run_layer_case(name, h, w, cfg_kwargs, nframes, rng, sigma=2.5, rgba_pixmap=False,
                    two_sources=False, masks=None, direction=FlowSource.Direction.BACKWARD,
-                   background="#ffffff"):
-    """Runs one MoveReferenceLayer recurrence through the reference and
-    returns a dict of inputs and per-frame outputs."""
+                   background="#ffffff", classname="moveref"):
+    """Runs one layer recurrence (MoveReferenceLayer unless `classname` says otherwise) through
+    the reference and returns a dict of inputs and per-frame outputs."""
+    from transflow.compositor.layers.layer import Layer
     masks = masks or {}
-    cfg = LayerConfig(0, **cfg_kwargs)
-    layer = MoveReferenceLayer(cfg, h, w, [])
+    cfg = LayerConfig(0, classname=classname, **cfg_kwargs)
+    layer = Layer.from_args(cfg, h, w, [])
     # arbitrary mask arrays are installed on the layer object directly; the
     # reference's loaders (utils.py:51-144) are host-side parsing, not the path
     for k, v in masks.items():
@@ -120,13 +121,18 @@ def run_layer_case(name, h, w, cfg_kwargs, nframes, rng, sigma=2.5, rgba_pixmap=
     d = {
         "h": np.int32(h), "w": np.int32(w), "nframes": np.int32(nframes),
         "nsources": np.int32(len(intro)),
-        "mask_src": layer.mask_src.copy(), "mask_dst": layer.mask_dst.copy(),
-        "mask_alpha": layer.mask_alpha.copy(), "reset_mask": layer.reset_mask.copy(),
-        "data_init": layer.data.copy(),
+        "classname": np.array(classname),
+        "mask_alpha": layer.mask_alpha.copy(),
         "background": np.array(comp.background_color, dtype=np.uint8),
         "cfg_keys": np.array(sorted(cfg_kwargs.keys())),
         "cfg_vals": np.array([str(cfg_kwargs[k]) for k in sorted(cfg_kwargs.keys())]),
     }
+    for key in ("mask_src", "mask_dst", "reset_mask"):
+        if hasattr(layer, key):
+            d[key] = getattr(layer, key).copy()
+    if hasattr(layer, "data"):
+        d["data_init"] = layer.data.copy()
+    d["rgba_init"] = np.array(layer.rgba, copy=True)
     for s, (pm, im) in enumerate(zip(pixmaps, intro)):
         d[f"pixmap_{s}"] = pm
         d[f"intro_{s}"] = im
@@ -142,10 +148,13 @@ def run_layer_case(name, h, w, cfg_kwargs, nframes, rng, sigma=2.5, rgba_pixmap=
             np.random.random = orig_random
         d[f"flow_{t}"] = flow
         d[f"u_{t}"] = u
-        d[f"data_{t}"] = layer.data.copy()
-        d[f"rgba_{t}"] = layer.rgba.copy()
+        if hasattr(layer, "data"):
+            d[f"data_{t}"] = layer.data.copy()
+        d[f"rgba_{t}"] = np.array(layer.rgba, copy=True)
         d[f"frame_{t}"] = comp.render().copy()
-        d[f"rgba_after_render_{t}"] = layer.rgba.copy()
+        d[f"rgba_after_render_{t}"] = np.array(layer.rgba, copy=True)
+        if hasattr(layer, "data"):
+            d[f"data_after_render_{t}"] = layer.data.copy()
     return d
 
 
@@ -219,6 +228,53 @@ def capture_layers():
     for name, d in cases.items():
         np.savez_compressed(os.path.join(OUT, f"remap_layer_{name}.npz"), **d)
     print("layer cases:", len(cases))
+
+
+def capture_other_layers():
+    """the sum, static and introduction layer classes."""
+    rng = np.random.default_rng(303)
+    cases = {}
+    h, w = 37, 53
+    # SumLayer (sum.py:7-14): accumulates floor(flow) into (i, j), then the reference layer's reset + gather
+    cases["sum_default"] = run_layer_case("sum", h, w, {}, 4, rng, classname="sum")
+    cases["sum_reset_random"] = run_layer_case(
+        "sum_rr", h, w, dict(reset_mode="random", reset_random_factor=0.3), 4, rng, classname="sum",
+        masks={"reset_mask": smooth_mask(rng, h, w)})
+    cases["sum_reset_linear_two"] = run_layer_case(
+        "sum_rl", h, w, dict(reset_mode="linear", reset_linear_factor=0.4), 4, rng, classname="sum",
+        two_sources=True, rgba_pixmap=True, masks={"mask_alpha": smooth_mask(rng, h, w)})
+    cases["sum_reset_constant"] = run_layer_case(
+        "sum_rc", 16, 24, dict(reset_mode="constant", reset_constant_step=2.2), 5, rng, classname="sum", sigma=4.0)
+    # StaticLayer (static.py:7-17)
+    cases["static_rgb"] = run_layer_case("static", 16, 24, {}, 3, rng, classname="static")
+    cases["static_rgba_two"] = run_layer_case("static2", h, w, {}, 3, rng, classname="static", two_sources=True,
+                                              rgba_pixmap=True, masks={"mask_alpha": smooth_mask(rng, h, w)},
+                                              background="#102030")
+    cases["static_rgb_two_alpha"] = run_layer_case("static3", h, w, {}, 3, rng, classname="static", two_sources=True,
+                                                   masks={"mask_alpha": smooth_mask(rng, h, w)})
+    # IntroductionLayer (introduction.py:8-67): every introduce_* flag alone, then combinations
+    flags = ["introduce_pixels_on_empty_spots", "introduce_pixels_on_filled_spots", "introduce_moving_pixels",
+             "introduce_unmoving_pixels", "introduce_once", "introduce_on_all_filled_spots",
+             "introduce_on_all_empty_spots"]
+    defaults = dict(zip(flags, [True, True, True, True, False, False, False]))
+    cases["intro_default"] = run_layer_case("intro", h, w, {}, 4, rng, classname="introduction")
+    for f in flags:
+        kw = {f: not defaults[f]}
+        cases[f"intro_{f}"] = run_layer_case("intro_" + f, 16, 24, kw, 4, rng, classname="introduction", sigma=2.0)
+    cases["intro_once_leave_two_rgba"] = run_layer_case(
+        "intro_combo", h, w, dict(introduce_once=True, moving_pixels_leave_empty_spot=True,
+                                  transparent_pixels_can_move=True), 5, rng,
+        classname="introduction", two_sources=True, rgba_pixmap=True, sigma=3.0)
+    cases["intro_partial_masks"] = run_layer_case(
+        "intro_masks", h, w, dict(introduce_moving_pixels=False, pixels_can_move_to_filled_spot=False), 5, rng,
+        classname="introduction", two_sources=True,
+        masks={"mask_alpha": smooth_mask(rng, h, w), "mask_src": rng.random((h, w)) < 0.8})
+    cases["intro_filled_only_leave"] = run_layer_case(
+        "intro_fl", h, w, dict(introduce_pixels_on_filled_spots=False, moving_pixels_leave_empty_spot=True), 5, rng,
+        classname="introduction", sigma=3.0)
+    for name, d in cases.items():
+        np.savez_compressed(os.path.join(OUT, f"layer2_{name}.npz"), **d)
+    print("other-layer cases:", len(cases))
 
 
 def capture_known_answers():
@@ -327,6 +383,9 @@ def capture_flow_presteps():
 
 
 if __name__ == "__main__":
+    if "--layers2-only" in sys.argv:
+        capture_other_layers()
+        sys.exit(0)
     if "--presteps-only" in sys.argv:
         capture_flow_presteps()
         sys.exit(0)
@@ -338,5 +397,6 @@ if __name__ == "__main__":
     capture_layers()
     capture_known_answers()
     capture_multilayer()
+    capture_other_layers()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", total)

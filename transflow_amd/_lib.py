@@ -37,7 +37,10 @@ class TfLayerCfg(C.Structure):
                 ("pixels_can_move_to_filled_spot", C.c_int), ("moving_pixels_leave_empty_spot", C.c_int),
                 ("reset_mode", C.c_int), ("reset_random_factor", C.c_double),
                 ("reset_constant_step", C.c_double), ("reset_linear_factor", C.c_double),
-                ("reset_source", C.c_int)]
+                ("reset_source", C.c_int), ("layer_class", C.c_int),
+                ("introduce_pixels_on_empty_spots", C.c_int), ("introduce_pixels_on_filled_spots", C.c_int),
+                ("introduce_moving_pixels", C.c_int), ("introduce_unmoving_pixels", C.c_int),
+                ("introduce_on_all_filled_spots", C.c_int), ("introduce_on_all_empty_spots", C.c_int)]
 
 
 _P = C.c_void_p
@@ -94,6 +97,9 @@ PROTOTYPES = {
     "tf_remap_check": (_I, [_P, _PI]),
     "tf_remap_gather": (_I, [_P, _I, _P, _I]),
     "tf_remap_gather_dev": (_I, [_P, _I, _P, _I]),
+    "tf_remap_introduce": (_I, [_P, _I, _P, _I, _I]),
+    "tf_remap_introduce_dev": (_I, [_P, _I, _P, _I, _I]),
+    "tf_remap_data_depth": (_I, [_P, _PI]),
     "tf_remap_render": (_I, [_P, _P]),
     "tf_remap_step_dev": (_I, [_P, _P, _P, _I, _P, C.c_uint64, _P, _I]),
     "tf_remap_get_state": (_I, [_P, _P, _P]),

@@ -3,6 +3,8 @@
   HipCompositor            <- transflow/compositor/compositor.py:17-53
   HipMoveReferenceLayer    <- transflow/compositor/layers/move_reference.py:6-14 and its bases
                               (layer.py:11-55, data.py:6-17, movement.py:10-64, reference.py:31-109)
+  HipSumLayer, HipStaticLayer, HipIntroductionLayer
+                           <- layers/sum.py:7-14, static.py:7-17, introduction.py:8-73
 
 `pipeline.py` only needs: Compositor.from_args(height, width, layer_configs,
 background_color), set_sources({layer: [PixmapSourceInterface]}), update(flow),
@@ -21,12 +23,14 @@ from .config import LayerConfig
 from .masks import load_bool_mask, load_float_mask, parse_color
 
 
-class HipMoveReferenceLayer:
-    """The default `moveref` layer.  State lives in HBM; `data` / `rgba` are downloaded on
-    access (int32 [H,W,4] = (i, j, alpha, source); uint8 [H,W,4])."""
+class _HipLayer:
+    """What every layer class shares (layer.py:11-34): config, size, sources, mask_alpha, lazy device
+    state, host-only pickling.  Subclasses set LAYER_CLASS / DEPTH / INDEX_* and write `update`."""
 
+    LAYER_CLASS = "moveref"
     DEPTH = 4
-    INDEX_I, INDEX_J, INDEX_ALPHA, INDEX_SOURCE = 0, 1, 2, 3   # data.py:8-12
+    HAS_MOVE_MASKS = False   # mask_src / mask_dst (movement.py:14-15)
+    HAS_RESET = False        # reset_mask and the reset modes (reference.py:33-44)
 
     def __init__(self, config, height: int, width: int, sources, rng: str = "numpy"):
         self.config = LayerConfig.from_reference(config)
@@ -34,11 +38,13 @@ class HipMoveReferenceLayer:
         self.sources = list(sources)
         shape = (self.height, self.width)
         self.mask_alpha = load_float_mask(self.config.mask_alpha, shape, 1)            # layer.py:24
-        self.mask_src = load_bool_mask(self.config.mask_src, shape, True)              # movement.py:14
-        self.mask_dst = load_bool_mask(self.config.mask_dst, shape, True)              # movement.py:15
-        self.reset_mask = load_float_mask(self.config.reset_mask, shape, 1)            # reference.py:44
-        if self.config.reset_mode not in ("off", "random", "constant", "linear"):
-            raise ValueError(f"Unknown reset mode {self.config.reset_mode}")           # reference.py:35
+        if self.HAS_MOVE_MASKS:
+            self.mask_src = load_bool_mask(self.config.mask_src, shape, True)          # movement.py:14
+            self.mask_dst = load_bool_mask(self.config.mask_dst, shape, True)          # movement.py:15
+        if self.HAS_RESET:
+            self.reset_mask = load_float_mask(self.config.reset_mask, shape, 1)        # reference.py:44
+            if self.config.reset_mode not in ("off", "random", "constant", "linear"):
+                raise ValueError(f"Unknown reset mode {self.config.reset_mode}")       # reference.py:35
         # "numpy": draw the reset field with numpy.random.random on the host, exactly like
         # reference.py:59 (same global stream => same frames for the same numpy seed);
         # "device": counter-based generator on the GPU (no 8 B/px upload)
@@ -54,21 +60,26 @@ class HipMoveReferenceLayer:
             from .remap import RemapLayer
             c = self.config
             default = lambda a, v: None if np.all(a == v) else a  # noqa: E731  (absent mask == default)
-            self._dev = RemapLayer(
-                self.height, self.width,
-                transparent_pixels_can_move=c.transparent_pixels_can_move,
-                pixels_can_move_to_empty_spot=c.pixels_can_move_to_empty_spot,
-                pixels_can_move_to_filled_spot=c.pixels_can_move_to_filled_spot,
-                moving_pixels_leave_empty_spot=c.moving_pixels_leave_empty_spot,
-                reset_mode=c.reset_mode, reset_random_factor=c.reset_random_factor,
-                reset_constant_step=c.reset_constant_step, reset_linear_factor=c.reset_linear_factor,
-                reset_source=c.reset_source,
-                mask_src=default(self.mask_src, True), mask_dst=default(self.mask_dst, True),
-                mask_alpha=default(self.mask_alpha, 1), reset_mask=default(self.reset_mask, 1))
+            kw = dict(layer_class=self.LAYER_CLASS, mask_alpha=default(self.mask_alpha, 1))
+            if self.HAS_MOVE_MASKS:
+                kw.update(transparent_pixels_can_move=c.transparent_pixels_can_move,
+                          pixels_can_move_to_empty_spot=c.pixels_can_move_to_empty_spot,
+                          pixels_can_move_to_filled_spot=c.pixels_can_move_to_filled_spot,
+                          moving_pixels_leave_empty_spot=c.moving_pixels_leave_empty_spot,
+                          mask_src=default(self.mask_src, True), mask_dst=default(self.mask_dst, True))
+            if self.HAS_RESET:
+                kw.update(reset_mode=c.reset_mode, reset_random_factor=c.reset_random_factor,
+                          reset_constant_step=c.reset_constant_step, reset_linear_factor=c.reset_linear_factor,
+                          reset_source=c.reset_source, reset_mask=default(self.reset_mask, 1))
+            if self.LAYER_CLASS == "introduction":
+                kw.update({k: getattr(c, k) for k in (
+                    "introduce_pixels_on_empty_spots", "introduce_pixels_on_filled_spots", "introduce_moving_pixels",
+                    "introduce_unmoving_pixels", "introduce_on_all_filled_spots", "introduce_on_all_empty_spots")})
+            self._dev = RemapLayer(self.height, self.width, **kw)
             if self._pending_state is not None:          # restored from a checkpoint
                 self._dev.set_state(*self._pending_state)
                 self._pending_state = None
-            elif self.sources:                           # constructor-time sources (reference.py:42)
+            if self.sources:                             # constructor-time sources / masks to (re)install
                 self._sources_dirty = True
         if self._sources_dirty:
             self._dev.set_sources([np.asarray(s.introduction_mask, dtype=bool) for s in self.sources])
@@ -76,40 +87,34 @@ class HipMoveReferenceLayer:
         return self._dev
 
     def set_sources(self, sources):
-        """reference.py:54-56: remember the sources and write their index where their
-        introduction mask is set (also after a checkpoint restore, as the reference does:
-        pipeline.py:450-455).  Applied to the device state at its next use."""
+        """Layer.set_sources (layer.py:26-27); for the reference-layer classes also
+        reference.py:54-56: write each source's index where its introduction mask is set (also after
+        a checkpoint restore, as the reference does: pipeline.py:450-455).  Applied to the device
+        state at its next use."""
         self.sources = list(sources)
         self._sources_dirty = True
 
+    def _reset_field(self):
+        if self.HAS_RESET and self.config.reset_mode == "random" and self.rng == "numpy":
+            return np.random.random(size=(self.height, self.width))                    # reference.py:59
+        return None
+
     def update(self, flow):
-        """move_reference.py:12-14: MovementLayer.update, then ReferenceLayer.update."""
-        layer = self._layer()
-        u = None
-        if self.config.reset_mode == "random" and self.rng == "numpy":
-            u = np.random.random(size=(self.height, self.width))                       # reference.py:59
-        layer.update(flow, u, self.seed)
-        for i, source in enumerate(self.sources):                                      # reference.py:94-105
-            layer.gather(i, source.next())
+        raise NotImplementedError()                                                    # layer.py:29-30
 
     def render_into(self, comp):
         self._layer().render(comp)
 
-    @property
-    def data(self) -> np.ndarray:
+    def _state(self, which: int):
         if self._dev is None:
-            if self._pending_state is not None and self._pending_state[0] is not None:
-                return self._pending_state[0]
+            if self._pending_state is not None and self._pending_state[which] is not None:
+                return self._pending_state[which]
             self._layer()
-        return self._dev.get_state()[0]
+        return self._dev.get_state()[which]
 
     @property
     def rgba(self) -> np.ndarray:
-        if self._dev is None:
-            if self._pending_state is not None and self._pending_state[1] is not None:
-                return self._pending_state[1]
-            self._layer()
-        return self._dev.get_state()[1]
+        return self._state(1)
 
     # ---- pickling (checkpoints, pipeline.py:225-242) --------------------------------------
     def __getstate__(self):
@@ -134,7 +139,81 @@ class HipMoveReferenceLayer:
             self._dev = None
 
 
-LAYER_CLASSES = {"moveref": HipMoveReferenceLayer}
+class _HipDataLayer(_HipLayer):
+    INDEX_I, INDEX_J, INDEX_ALPHA, INDEX_SOURCE = 0, 1, 2, 3   # data.py:8-12
+
+    @property
+    def data(self) -> np.ndarray:
+        return self._state(0)
+
+
+class HipMoveReferenceLayer(_HipDataLayer):
+    """The default `moveref` layer (move_reference.py:6-14).  State lives in HBM; `data` / `rgba` are
+    downloaded on access (int32 [H,W,4] = (i, j, alpha, source); uint8 [H,W,4])."""
+
+    LAYER_CLASS = "moveref"
+    HAS_MOVE_MASKS = True
+    HAS_RESET = True
+
+    def update(self, flow):
+        """move_reference.py:12-14: MovementLayer.update, then ReferenceLayer.update."""
+        layer = self._layer()
+        layer.update(flow, self._reset_field(), self.seed)
+        for i, source in enumerate(self.sources):                                      # reference.py:94-105
+            layer.gather(i, source.next())
+
+
+class HipSumLayer(_HipDataLayer):
+    """`sum` (sum.py:7-14): a reference layer whose (i, j) accumulate floor(flow)."""
+
+    LAYER_CLASS = "sum"
+    HAS_RESET = True
+
+    def update(self, flow):
+        layer = self._layer()
+        layer.update(flow, self._reset_field(), self.seed)                             # sum.py:10 + reference.py:108
+        for i, source in enumerate(self.sources):                                      # reference.py:109
+            layer.gather(i, source.next())
+
+
+class HipStaticLayer(_HipLayer):
+    """`static` (static.py:7-17): no data; every update copies each source where it is introduced."""
+
+    LAYER_CLASS = "static"
+    DEPTH = 0
+
+    def update(self, flow):
+        layer = self._layer()
+        for i, source in enumerate(self.sources):                                      # static.py:14-17
+            layer.gather(i, source.next())
+
+
+class HipIntroductionLayer(_HipDataLayer):
+    """`introduction` (introduction.py:8-73): int32 [H,W,8] canvas (r, g, b, alpha, source, i, j,
+    frame); `rgba` is its first four channels (:65-66)."""
+
+    LAYER_CLASS = "introduction"
+    HAS_MOVE_MASKS = True
+    DEPTH = 8
+    INDEX_I, INDEX_J, INDEX_ALPHA, INDEX_SOURCE = 5, 6, 3, 4                            # introduction.py:11-14
+
+    def __init__(self, *args, **kwargs):
+        _HipLayer.__init__(self, *args, **kwargs)
+        self.introduced_once = False                                                    # :18
+
+    def update(self, flow):
+        layer = self._layer()
+        layer.update(flow)                                                              # MovementLayer.update, :69
+        if self.config.introduce_once and self.introduced_once:                         # :21-22
+            return
+        self.introduced_once = True
+        for i, source in enumerate(self.sources):                                       # :46-63
+            pixmap = source.next()
+            layer.introduce(i, pixmap, source.frame_number)
+
+
+LAYER_CLASSES = {"moveref": HipMoveReferenceLayer, "sum": HipSumLayer, "static": HipStaticLayer,
+                 "introduction": HipIntroductionLayer}                                  # layer.py:44-56
 
 
 class HipCompositor:
@@ -172,8 +251,7 @@ class HipCompositor:
         for config in layer_configs:
             classname = getattr(config, "classname", "moveref")
             if classname not in LAYER_CLASSES:
-                # static / sum / introduction layers: SURVEY.md §8(f) N2, not built yet
-                raise NotImplementedError(f"layer class {classname!r} is not implemented by transflow_amd yet")
+                raise ValueError(f"Unknown layer classname {classname}")                # layer.py:56
             layers.append(LAYER_CLASSES[classname](config, height, width, [], rng=rng))
         return cls(height, width, layers, background_color=background_color)
 

@@ -403,6 +403,190 @@ __global__ void k_comp_fill(uint8_t *image, int N, uchar4 bg)
     o[2] = bg.z;
 }
 
+
+// ---------------------------------------------------------------------------------
+// The other layer classes (layer.py:44-56)
+// ---------------------------------------------------------------------------------
+// SumLayer._update_sum (sum.py:10): (i, j) += floor(flow) -- channel 0 to i, channel 1 to j, as written
+__global__ void k_layer_sum(int4 *data, const float2 *__restrict__ flow, int N)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    float2 f = flow[t];
+    int4 d = data[t];
+    d.x += (int)floorf(f.x);
+    d.y += (int)floorf(f.y);
+    data[t] = d;
+}
+
+// StaticLayer.__init__ (static.py:11): alpha = 1
+__global__ void k_layer_static_init(uchar4 *rgba, int N)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < N)
+        rgba[t] = make_uchar4(0, 0, 0, 1);
+}
+
+// StaticLayer.update for one source (static.py:14-17): rgba[..., :C][mask] = pixmap[mask]
+template <int C>
+__global__ void k_layer_static_put(uchar4 *__restrict__ rgba, const uint8_t *__restrict__ pixmap,
+                                   const uint8_t *__restrict__ intro, int N)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N || !intro[t])
+        return;
+    if (C == 4) {
+        rgba[t] = reinterpret_cast<const uchar4 *>(pixmap)[t];
+    } else {
+        const uint8_t *p = pixmap + (size_t)t * 3;
+        uchar4 px = rgba[t];
+        px.x = p[0];
+        px.y = p[1];
+        px.z = p[2];
+        rgba[t] = px;
+    }
+}
+
+// IntroductionLayer: the canvas is two int4 per pixel, lo = (r, g, b, alpha), hi = (source, i, j, frame)
+// (introduction.py:10-14), i.e. the reference's int32 [H][W][8] as it lies in memory.
+__device__ __forceinline__ bool intro_move_target(long long t, const float2 *__restrict__ flow,
+                                                  const int4 *__restrict__ old, const uint8_t *__restrict__ msrc,
+                                                  const uint8_t *__restrict__ mdst, int N, int W, MoveFlags fl,
+                                                  int my_alpha, long long &s, int &src_alpha, bool &oob)
+{
+    long long d = flow_offset(flow[t], W);
+    oob = false;
+    if (d == 0)
+        return false;
+    s = t + d;
+    if (s < 0 || s >= N) {
+        oob = true;
+        return false;
+    }
+    src_alpha = old[2 * s].w;
+    bool ms = (msrc ? msrc[s] != 0 : true) && (fl.transparent_can_move || src_alpha != 0);
+    bool md = (mdst ? mdst[t] != 0 : true) && (fl.to_empty || my_alpha != 0) && (fl.to_filled || my_alpha == 0);
+    return ms && md;
+}
+
+// movement.py:25-60 with DEPTH = 8, INDEX_ALPHA = 3
+__global__ void k_intro_move(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4 *__restrict__ neu,
+                             const uint8_t *__restrict__ msrc, const uint8_t *__restrict__ mdst, int N, int W,
+                             MoveFlags fl, int *err)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    int4 lo = old[2 * (size_t)t], hi = old[2 * (size_t)t + 1];
+    long long s;
+    int sa;
+    bool oob;
+    if (intro_move_target(t, flow, old, msrc, mdst, N, W, fl, lo.w, s, sa, oob)) {
+        lo = old[2 * s];
+        hi = old[2 * s + 1];
+        if (!fl.transparent_can_move || sa != 0)
+            lo.w = 1;
+    }
+    if (oob)
+        atomicOr(err, 1);
+    neu[2 * (size_t)t] = lo;
+    neu[2 * (size_t)t + 1] = hi;
+}
+
+// movement.py:53-54 on the 8-channel canvas (see k_remap_leave_empty)
+__global__ void k_intro_leave_empty(const float2 *__restrict__ flow, const int4 *__restrict__ old,
+                                    int4 *__restrict__ neu, const uint8_t *__restrict__ msrc,
+                                    const uint8_t *__restrict__ mdst, int N, int W, MoveFlags fl)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    long long s, s2;
+    int sa, sa2;
+    bool oob;
+    if (!intro_move_target(t, flow, old, msrc, mdst, N, W, fl, old[2 * (size_t)t].w, s, sa, oob))
+        return;
+    bool s_is_one = intro_move_target(s, flow, old, msrc, mdst, N, W, fl, old[2 * s].w, s2, sa2, oob) &&
+                    (!fl.transparent_can_move || sa2 != 0);
+    if (!s_is_one)
+        neu[2 * s].w = 0;
+}
+
+// introduction.py:24-44: which targets may receive an introduced pixel, from the canvas after the
+// move.  on_empty_spots / unmoving_pixels / the write of on_all_empty_spots select nothing in the
+// reference (tfhip.h), so three conditions remain.
+__global__ void k_intro_mask(const int4 *__restrict__ data, const float2 *__restrict__ flow, uint8_t *__restrict__ mask,
+                             int N, int W, int on_filled, int moving, int all_filled)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    const bool filled = data[2 * (size_t)t].w != 0;
+    bool m = true;
+    if (!on_filled && filled)
+        m = false;
+    if (!moving && flow_offset(flow[t], W) != 0)
+        m = false;
+    if (all_filled && filled)
+        m = true;
+    mask[t] = m;
+}
+
+// introduction.py:46-63 for one source
+template <int C>
+__global__ void k_intro_put(int4 *__restrict__ data, const float2 *__restrict__ flow, const uint8_t *__restrict__ mask,
+                            const uint8_t *__restrict__ intro, const uint8_t *__restrict__ pixmap, int N, int W,
+                            int consider_flow, int source_index, int frame_number, int *err)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N || !mask[t] || !intro[t])
+        return;
+    long long s = t;
+    if (consider_flow) {
+        s += flow_offset(flow[t], W);
+        if (s < 0 || s >= N) {
+            atomicOr(err, 1);
+            return;
+        }
+    }
+    int4 lo;
+    if (C == 4) {
+        uchar4 px = reinterpret_cast<const uchar4 *>(pixmap)[s];
+        lo = make_int4(px.x, px.y, px.z, px.w);
+    } else {
+        const uint8_t *p = pixmap + (size_t)s * 3;
+        lo = make_int4(p[0], p[1], p[2], 1);
+    }
+    data[2 * (size_t)t] = lo;
+    data[2 * (size_t)t + 1] = make_int4(source_index, (int)(s / W), (int)(s % W), frame_number);
+}
+
+// Layer.render on the int32 view rgba = data[..., :4] (introduction.py:65-66, layer.py:32-34):
+// alpha := int32(float64(mask_alpha) * alpha) written back into the canvas, the returned image is
+// clip(rgba, 0, 255) as uint8; then Compositor.render's paint (compositor.py:36-39).
+__global__ void k_intro_render(int4 *__restrict__ data, const float *__restrict__ mask_alpha,
+                               uint8_t *__restrict__ image, int N)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    int4 lo = data[2 * (size_t)t];
+    if (mask_alpha) {
+        int a = (int)((double)mask_alpha[t] * (double)lo.w);
+        if (a != lo.w) {
+            lo.w = a;
+            data[2 * (size_t)t].w = a;
+        }
+    }
+    if (min(max(lo.w, 0), 255) != 0) {
+        uint8_t *o = image + (size_t)t * 3;
+        o[0] = (uint8_t)min(max(lo.x, 0), 255);
+        o[1] = (uint8_t)min(max(lo.y, 0), 255);
+        o[2] = (uint8_t)min(max(lo.z, 0), 255);
+    }
+}
+
 } // namespace
 
 struct tf_comp {
@@ -420,7 +604,11 @@ struct tf_remap {
     DevBuf rgba;
     DevBuf mask_src, mask_dst, mask_alpha, reset_mask;
     DevBuf intro;
+    DevBuf intro_sel;  // introduction layer: the mask of introduction.py:24-44 for the current frame
+    DevBuf last_flow;  // introduction layer: the flow of the current frame (device copy when it came from the host)
+    const float2 *flow_for_intro = nullptr;
     int n_sources = 0;
+    int depth() const { return cfg.layer_class == TF_LAYER_INTRODUCTION ? 8 : (cfg.layer_class == TF_LAYER_STATIC ? 0 : 4); }
     DevBuf err;
     DevBuf scratch_flow, scratch_u, scratch_pix;
     uint64_t frame = 0;
@@ -490,6 +678,8 @@ TF_API int tf_remap_create(tf_remap **out, int height, int width, const tf_layer
     TF_REQUIRE(height >= 0 && width >= 0 && (long long)height * width < (1ll << 31),
                "tf_remap_create: bad size %dx%d", width, height);
     TF_REQUIRE(cfg->reset_mode >= 0 && cfg->reset_mode <= 3, "tf_remap_create: unknown reset mode %d", cfg->reset_mode);
+    TF_REQUIRE(cfg->layer_class >= TF_LAYER_MOVEREF && cfg->layer_class <= TF_LAYER_INTRODUCTION,
+               "tf_remap_create: unknown layer class %d", cfg->layer_class);
     TF_TRY(ensure_init());
     tf_remap *L = new tf_remap;
     L->H = height;
@@ -504,8 +694,11 @@ TF_API int tf_remap_create(tf_remap **out, int height, int width, const tf_layer
         delete L;
         return code;
     };
-    if ((rc = L->data[0].alloc(n * 16)) || (rc = L->data[1].alloc(n * 16)) || (rc = L->rgba.alloc(n * 4)) ||
+    const size_t px_bytes = (size_t)L->depth() * 4;
+    if ((rc = L->data[0].alloc(n * px_bytes)) || (rc = L->data[1].alloc(n * px_bytes)) || (rc = L->rgba.alloc(n * 4)) ||
         (rc = L->err.alloc(4)))
+        return fail(rc);
+    if (cfg->layer_class == TF_LAYER_INTRODUCTION && (rc = L->intro_sel.alloc(n)))
         return fail(rc);
     if (mask_src && (rc = upload(L->mask_src, mask_src, n)))
         return fail(rc);
@@ -520,7 +713,19 @@ TF_API int tf_remap_create(tf_remap **out, int height, int width, const tf_layer
         return fail(set_error(TF_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)));
     if ((e = hipMemsetAsync(L->err.p, 0, 4, stream())) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)));
-    if ((rc = launch("remap_init", k_remap_init, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, L->cur_data(), L->N, L->W)))
+    switch (cfg->layer_class) {
+    case TF_LAYER_STATIC:
+        rc = launch("layer_static_init", k_layer_static_init, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, L->rgba.as<uchar4>(),
+                    L->N);
+        break;
+    case TF_LAYER_INTRODUCTION: // data.py:17: an all-zero canvas
+        if (n && (e = hipMemsetAsync(L->data[0].p, 0, n * px_bytes, stream())) != hipSuccess)
+            return fail(set_error(TF_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)));
+        break;
+    default:
+        rc = launch("remap_init", k_remap_init, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, L->cur_data(), L->N, L->W);
+    }
+    if (rc)
         return fail(rc);
     if ((e = hipStreamSynchronize(stream())) != hipSuccess) // host mask buffers are borrowed for this call only
         return fail(set_error(TF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e)));
@@ -546,8 +751,9 @@ TF_API int tf_remap_set_sources(tf_remap *L, int n_sources, const uint8_t *const
         TF_HIP(hipMemcpyAsync(L->intro.as<uint8_t>() + n * s, introduction_masks[s], n, hipMemcpyHostToDevice,
                               stream()));
     }
-    TF_TRY(launch("remap_set_sources", k_remap_set_sources, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, L->cur_data(),
-                  L->intro.as<uint8_t>(), n_sources, L->N));
+    if (L->depth() == 4) // ReferenceLayer.set_sources (reference.py:54-56); the other classes only keep the masks
+        TF_TRY(launch("remap_set_sources", k_remap_set_sources, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, L->cur_data(),
+                      L->intro.as<uint8_t>(), n_sources, L->N));
     TF_HIP(hipStreamSynchronize(stream()));
     return TF_OK;
 }
@@ -560,11 +766,28 @@ static int queue_update(tf_remap *L, const float2 *flow, const double *u, uint64
     const int4 *old = L->data[L->cur].as<int4>();
     int4 *neu = L->data[L->cur ^ 1].as<int4>();
     const uint8_t *msrc = L->mask_src.as<uint8_t>(), *mdst = L->mask_dst.as<uint8_t>();
-    TF_TRY(launch("remap_move", k_remap_move, grid, block, 0, flow, old, neu, msrc, mdst, N, L->W, L->fl,
-                  L->err.as<int>()));
-    if (L->fl.leave_empty)
-        TF_TRY(launch("remap_leave_empty", k_remap_leave_empty, grid, block, 0, flow, old, neu, msrc, mdst, N, L->W,
-                      L->fl));
+    if (L->cfg.layer_class == TF_LAYER_INTRODUCTION) {
+        TF_TRY(launch("intro_move", k_intro_move, grid, block, 0, flow, old, neu, msrc, mdst, N, L->W, L->fl,
+                      L->err.as<int>()));
+        if (L->fl.leave_empty)
+            TF_TRY(launch("intro_leave_empty", k_intro_leave_empty, grid, block, 0, flow, old, neu, msrc, mdst, N, L->W,
+                          L->fl));
+        L->flow_for_intro = flow;
+        return launch("intro_mask", k_intro_mask, grid, block, 0, (const int4 *)neu, flow, L->intro_sel.as<uint8_t>(), N,
+                      L->W, L->cfg.introduce_pixels_on_filled_spots, L->cfg.introduce_moving_pixels,
+                      L->cfg.introduce_on_all_filled_spots);
+    }
+    if (L->cfg.layer_class == TF_LAYER_SUM) {
+        // no snapshot needed: every pixel updates itself; the "new" buffer is the current one
+        neu = L->data[L->cur].as<int4>();
+        TF_TRY(launch("layer_sum", k_layer_sum, grid, block, 0, neu, flow, N));
+    } else {
+        TF_TRY(launch("remap_move", k_remap_move, grid, block, 0, flow, old, neu, msrc, mdst, N, L->W, L->fl,
+                      L->err.as<int>()));
+        if (L->fl.leave_empty)
+            TF_TRY(launch("remap_leave_empty", k_remap_leave_empty, grid, block, 0, flow, old, neu, msrc, mdst, N, L->W,
+                          L->fl));
+    }
     const float *rmask = L->reset_mask.as<float>();
     switch (L->cfg.reset_mode) {
     case 1:
@@ -590,10 +813,11 @@ TF_API int tf_remap_update_dev(tf_remap *L, const void *flow_dev, const void *un
 {
     TF_REQUIRE(L && (flow_dev || L->N == 0), "tf_remap_update_dev: null pointer");
     TF_TRY(ensure_init());
-    if (L->N == 0)
+    if (L->N == 0 || L->cfg.layer_class == TF_LAYER_STATIC) // static.py:13 ignores the flow
         return TF_OK;
     TF_TRY(queue_update(L, (const float2 *)flow_dev, (const double *)uniform_dev, seed));
-    L->cur ^= 1;
+    if (L->cfg.layer_class != TF_LAYER_SUM)
+        L->cur ^= 1;
     L->frame++;
     return TF_OK;
 }
@@ -602,7 +826,7 @@ TF_API int tf_remap_update(tf_remap *L, const float *flow, const double *uniform
 {
     TF_REQUIRE(L && (flow || L->N == 0), "tf_remap_update: null pointer");
     TF_TRY(ensure_init());
-    if (L->N == 0)
+    if (L->N == 0 || L->cfg.layer_class == TF_LAYER_STATIC)
         return TF_OK;
     size_t n = (size_t)L->N;
     TF_TRY(upload(L->scratch_flow, flow, n * 8));
@@ -620,7 +844,8 @@ TF_API int tf_remap_update(tf_remap *L, const float *flow, const double *uniform
         return set_error(TF_ERR_INDEX, "tf_remap_update: a rounded flow vector leaves the %dx%d frame "
                                        "(run post_process first); layer state unchanged",
                          L->W, L->H);
-    L->cur ^= 1;
+    if (L->cfg.layer_class != TF_LAYER_SUM)
+        L->cur ^= 1;
     L->frame++;
     return TF_OK;
 }
@@ -641,8 +866,20 @@ TF_API int tf_remap_gather_dev(tf_remap *L, int source_index, const void *pixmap
 {
     TF_REQUIRE(L && (pixmap_dev || L->N == 0), "tf_remap_gather_dev: null pointer");
     TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_gather: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_REQUIRE(L->cfg.layer_class != TF_LAYER_INTRODUCTION, "tf_remap_gather: an introduction layer takes its pixmaps "
+                                                            "through tf_remap_introduce");
     TF_TRY(ensure_init());
     dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
+    if (L->cfg.layer_class == TF_LAYER_STATIC) {
+        TF_REQUIRE(source_index >= 0 && source_index < L->n_sources, "tf_remap_gather: source %d of %d (set_sources first)",
+                   source_index, L->n_sources);
+        const uint8_t *intro = L->intro.as<uint8_t>() + (size_t)L->N * source_index;
+        if (channels == 4)
+            return launch("layer_static_put_rgba", k_layer_static_put<4>, grid, block, 0, L->rgba.as<uchar4>(),
+                          (const uint8_t *)pixmap_dev, intro, L->N);
+        return launch("layer_static_put_rgb", k_layer_static_put<3>, grid, block, 0, L->rgba.as<uchar4>(),
+                      (const uint8_t *)pixmap_dev, intro, L->N);
+    }
     if (channels == 4)
         return launch("remap_gather_rgba", k_remap_gather<4>, grid, block, 0, (const int4 *)L->cur_data(),
                       L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev, source_index, L->N, L->H, L->W);
@@ -669,8 +906,54 @@ TF_API int tf_remap_render(tf_remap *L, tf_comp *comp)
     TF_REQUIRE(L->H == comp->H && L->W == comp->W, "tf_remap_render: layer is %dx%d, compositor %dx%d", L->W, L->H,
                comp->W, comp->H);
     TF_TRY(ensure_init());
+    if (L->cfg.layer_class == TF_LAYER_INTRODUCTION)
+        return launch("intro_render", k_intro_render, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0, L->cur_data(),
+                      (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N);
     return launch("remap_render", k_remap_render, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
                   L->rgba.as<uchar4>(), (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N);
+}
+
+TF_API int tf_remap_introduce_dev(tf_remap *L, int source_index, const void *pixmap_dev, int channels, int frame_number)
+{
+    TF_REQUIRE(L && (pixmap_dev || L->N == 0), "tf_remap_introduce_dev: null pointer");
+    TF_REQUIRE(L->cfg.layer_class == TF_LAYER_INTRODUCTION, "tf_remap_introduce: not an introduction layer");
+    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_introduce: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_REQUIRE(source_index >= 0 && source_index < L->n_sources, "tf_remap_introduce: source %d of %d (set_sources first)",
+               source_index, L->n_sources);
+    TF_REQUIRE(L->flow_for_intro || L->N == 0, "tf_remap_introduce: no tf_remap_update yet");
+    TF_TRY(ensure_init());
+    if (L->N == 0)
+        return TF_OK;
+    dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
+    const int consider_flow = !(L->cfg.introduce_on_all_filled_spots || L->cfg.introduce_on_all_empty_spots);
+    const uint8_t *intro = L->intro.as<uint8_t>() + (size_t)L->N * source_index;
+    if (channels == 4)
+        return launch("intro_put_rgba", k_intro_put<4>, grid, block, 0, L->cur_data(), L->flow_for_intro,
+                      (const uint8_t *)L->intro_sel.as<uint8_t>(), intro, (const uint8_t *)pixmap_dev, L->N, L->W,
+                      consider_flow, source_index, frame_number, L->err.as<int>());
+    return launch("intro_put_rgb", k_intro_put<3>, grid, block, 0, L->cur_data(), L->flow_for_intro,
+                  (const uint8_t *)L->intro_sel.as<uint8_t>(), intro, (const uint8_t *)pixmap_dev, L->N, L->W,
+                  consider_flow, source_index, frame_number, L->err.as<int>());
+}
+
+TF_API int tf_remap_introduce(tf_remap *L, int source_index, const uint8_t *pixmap, int channels, int frame_number)
+{
+    TF_REQUIRE(L && (pixmap || L->N == 0), "tf_remap_introduce: null pointer");
+    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_introduce: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_TRY(ensure_init());
+    if (L->N == 0)
+        return TF_OK;
+    TF_TRY(upload(L->scratch_pix, pixmap, (size_t)L->N * channels));
+    TF_TRY(tf_remap_introduce_dev(L, source_index, L->scratch_pix.p, channels, frame_number));
+    TF_HIP(hipStreamSynchronize(stream())); // the host pixmap is borrowed for this call only
+    return TF_OK;
+}
+
+TF_API int tf_remap_data_depth(tf_remap *L, int *depth)
+{
+    TF_REQUIRE(L && depth, "tf_remap_data_depth: null pointer");
+    *depth = L->depth();
+    return TF_OK;
 }
 
 TF_API int tf_remap_get_state(tf_remap *L, int32_t *data, uint8_t *rgba)
@@ -678,8 +961,8 @@ TF_API int tf_remap_get_state(tf_remap *L, int32_t *data, uint8_t *rgba)
     TF_REQUIRE(L, "tf_remap_get_state: null handle");
     TF_TRY(ensure_init());
     size_t n = (size_t)L->N;
-    if (data && n)
-        TF_HIP(hipMemcpyAsync(data, L->cur_data(), n * 16, hipMemcpyDeviceToHost, stream()));
+    if (data && n && L->depth())
+        TF_HIP(hipMemcpyAsync(data, L->cur_data(), n * 4 * L->depth(), hipMemcpyDeviceToHost, stream()));
     if (rgba && n)
         TF_HIP(hipMemcpyAsync(rgba, L->rgba.p, n * 4, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
@@ -691,8 +974,8 @@ TF_API int tf_remap_set_state(tf_remap *L, const int32_t *data, const uint8_t *r
     TF_REQUIRE(L, "tf_remap_set_state: null handle");
     TF_TRY(ensure_init());
     size_t n = (size_t)L->N;
-    if (data && n)
-        TF_HIP(hipMemcpyAsync(L->cur_data(), data, n * 16, hipMemcpyHostToDevice, stream()));
+    if (data && n && L->depth())
+        TF_HIP(hipMemcpyAsync(L->cur_data(), data, n * 4 * L->depth(), hipMemcpyHostToDevice, stream()));
     if (rgba && n)
         TF_HIP(hipMemcpyAsync(L->rgba.p, rgba, n * 4, hipMemcpyHostToDevice, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
@@ -706,6 +989,7 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_step_dev: pixmap must have 3 or 4 channels, got %d", channels);
     TF_REQUIRE(L->H == comp->H && L->W == comp->W, "tf_remap_step_dev: layer is %dx%d, compositor %dx%d", L->W, L->H,
                comp->W, comp->H);
+    TF_REQUIRE(L->cfg.layer_class == TF_LAYER_MOVEREF, "tf_remap_step_dev: moveref layers only");
     TF_TRY(ensure_init());
     if (L->N == 0)
         return TF_OK;

@@ -9,6 +9,7 @@ from . import _lib
 from ._lib import TfLayerCfg, check
 
 RESET_MODES = {"off": 0, "random": 1, "constant": 2, "linear": 3}  # reference.py:16-21
+LAYER_CLASSES = {"moveref": 0, "sum": 1, "static": 2, "introduction": 3}  # layer.py:44-56
 
 
 def _ptr(a):
@@ -51,22 +52,33 @@ class CompImage:
 
 
 class RemapLayer:
-    """Device state and kernels of one moveref layer."""
+    """Device state and kernels of one compositor layer (`layer_class`: moveref, sum, static or
+    introduction -- layer.py:44-56)."""
 
-    def __init__(self, height: int, width: int, *, transparent_pixels_can_move=False,
+    def __init__(self, height: int, width: int, *, layer_class="moveref", transparent_pixels_can_move=False,
                  pixels_can_move_to_empty_spot=True, pixels_can_move_to_filled_spot=True,
                  moving_pixels_leave_empty_spot=False, reset_mode="off", reset_random_factor=1.0,
                  reset_constant_step=1.0, reset_linear_factor=0.1, reset_source=False,
+                 introduce_pixels_on_empty_spots=True, introduce_pixels_on_filled_spots=True,
+                 introduce_moving_pixels=True, introduce_unmoving_pixels=True,
+                 introduce_on_all_filled_spots=False, introduce_on_all_empty_spots=False,
                  mask_src=None, mask_dst=None, mask_alpha=None, reset_mask=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.height, self.width = int(height), int(width)
         if reset_mode not in RESET_MODES:
             raise ValueError(f"Unknown reset mode {reset_mode}")  # reference.py:35
+        if layer_class not in LAYER_CLASSES:
+            raise ValueError(f"Unknown layer classname {layer_class}")  # layer.py:56
+        self.layer_class = layer_class
+        self.depth = {"static": 0, "introduction": 8}.get(layer_class, 4)
         cfg = TfLayerCfg(int(bool(transparent_pixels_can_move)), int(bool(pixels_can_move_to_empty_spot)),
                          int(bool(pixels_can_move_to_filled_spot)), int(bool(moving_pixels_leave_empty_spot)),
                          RESET_MODES[reset_mode], float(reset_random_factor), float(reset_constant_step),
-                         float(reset_linear_factor), int(bool(reset_source)))
+                         float(reset_linear_factor), int(bool(reset_source)), LAYER_CLASSES[layer_class],
+                         int(bool(introduce_pixels_on_empty_spots)), int(bool(introduce_pixels_on_filled_spots)),
+                         int(bool(introduce_moving_pixels)), int(bool(introduce_unmoving_pixels)),
+                         int(bool(introduce_on_all_filled_spots)), int(bool(introduce_on_all_empty_spots)))
         shape = (self.height, self.width)
 
         def mask(a, dtype):
@@ -117,6 +129,13 @@ class RemapLayer:
             raise ValueError(f"pixmap shape {pm.shape} does not match the layer")
         check(self._lib.tf_remap_gather(self._h, int(source_index), _ptr(pm), int(pm.shape[2])))
 
+    def introduce(self, source_index: int, pixmap: np.ndarray, frame_number: int) -> None:
+        """Introduction layer: one iteration of introduction.py:46-63."""
+        pm = np.ascontiguousarray(pixmap, dtype=np.uint8)
+        if pm.ndim != 3 or pm.shape[:2] != (self.height, self.width):
+            raise ValueError(f"pixmap shape {pm.shape} does not match the layer")
+        check(self._lib.tf_remap_introduce(self._h, int(source_index), _ptr(pm), int(pm.shape[2]), int(frame_number)))
+
     def gather_dev(self, source_index: int, pixmap_dev: int, channels: int) -> None:
         check(self._lib.tf_remap_gather_dev(self._h, int(source_index), C.c_void_p(pixmap_dev), int(channels)))
 
@@ -131,15 +150,24 @@ class RemapLayer:
         check(self._lib.tf_remap_render(self._h, comp._h))
 
     def get_state(self):
-        data = np.empty((self.height, self.width, 4), np.int32)
+        """(data, rgba): data int32 [H,W,depth] (None for a static layer); rgba uint8 [H,W,4], or the
+        int32 view data[..., :4] for an introduction layer (introduction.py:65-66)."""
+        data = np.empty((self.height, self.width, self.depth), np.int32) if self.depth else None
+        if self.layer_class == "introduction":
+            check(self._lib.tf_remap_get_state(self._h, _ptr(data), None))
+            return data, data[:, :, :4]
         rgba = np.empty((self.height, self.width, 4), np.uint8)
         check(self._lib.tf_remap_get_state(self._h, _ptr(data), _ptr(rgba)))
         return data, rgba
 
     def set_state(self, data=None, rgba=None) -> None:
+        if self.layer_class == "introduction":
+            rgba = None  # a view of data
+        if self.depth == 0:
+            data = None
         d = None if data is None else np.ascontiguousarray(data, dtype=np.int32)
         r = None if rgba is None else np.ascontiguousarray(rgba, dtype=np.uint8)
-        if d is not None and d.shape != (self.height, self.width, 4):
+        if d is not None and d.shape != (self.height, self.width, self.depth):
             raise ValueError("data has the wrong shape")
         if r is not None and r.shape != (self.height, self.width, 4):
             raise ValueError("rgba has the wrong shape")
