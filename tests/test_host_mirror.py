@@ -208,8 +208,9 @@ def test_dropin_install_patches_reference_factories():
                                         background_color="#ff8000")
             assert isinstance(comp, HipCompositor) and comp.layers[0].config.reset_random_factor == 0.5
             assert comp.background_color == (255, 128, 0)
-            other = Compositor.from_args(4, 6, [RefLayerConfig(0, classname="sum")])
-            assert isinstance(other, Compositor)                     # not ours: the reference's own layers
+            other = Compositor.from_args(4, 6, [RefLayerConfig(0, classname="sum"),
+                                                RefLayerConfig(1, classname="introduction")])
+            assert isinstance(other, HipCompositor)                  # every layer class is served
             b = RefFlowSource.from_args("clip.mp4", direction=RefFlowSource.Direction.BACKWARD)
             assert isinstance(b, HipFlowSource.Builder) and b.direction is FlowSource.Direction.BACKWARD
             with pytest.raises(Exception):

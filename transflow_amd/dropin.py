@@ -10,8 +10,8 @@
 dispatchers that build HipFlowSource / HipCompositor when the request is one this
 backend serves -- a video path (or webcam index) with the Farnebäck method (flow mask and the
 scale/threshold/clip filters included; no convolution kernel, no polar filter), layers of
-class `moveref` -- and fall through to the reference's own factory otherwise
-(archives, motion vectors, other flow methods, other layer classes).
+any of the reference's classes (`moveref`, `sum`, `static`, `introduction`) -- and fall through to
+the reference's own factory otherwise (archives, motion vectors, other flow methods).
 INTEGRATION.md shows the three-line patch a maintainer would add instead.
 """
 from __future__ import annotations
