@@ -134,6 +134,40 @@ int tf_fb_post_process_ex(tf_fb *fb, int pair, int direction, int n_ops, const t
 int tf_fb_post_process_host_ex(tf_fb *fb, float *flow_inout, int direction, int n_ops, const tf_flow_op *ops,
                                const float *mask); /* direction -1: pre-steps only */
 
+/* ---- flow-array steps either side of the path (device pointers, no handle) ---------
+ * Flows are float32 [H][W][2] unless `wide` says float64.  All launches go to the library stream. */
+
+/* Pipeline.FLOW_MERGING_FUNCTIONS (transflow/pipeline.py:149-158; helpers transflow/utils.py:359-381):
+   n flows of n_values floats each, combined left to right in float32 as numpy does. */
+enum { TF_MERGE_FIRST = 0, TF_MERGE_SUM, TF_MERGE_AVERAGE, TF_MERGE_DIFFERENCE, TF_MERGE_PRODUCT, TF_MERGE_MASKBIN,
+       TF_MERGE_MASKLIN, TF_MERGE_ABSMAX };
+#define TF_MAX_MERGE 8
+int tf_flow_merge_dev(int kind, int n, const void *const *flows_dev, void *out_dev, size_t n_values);
+
+/* utils.upscale_array (utils.py:417-418): out [H*hf][W*wf][2] = (x*wf, y*hf) of the nearest source pixel. */
+int tf_flow_upscale_dev(const void *in_dev, void *out_dev, int width, int height, int wf, int hf);
+
+/* The convolution-kernel pre-step of post_process (source.py:344-348):
+   scipy.signal.convolve2d(channel, kernel, mode="same", boundary="fill", fillvalue=0) on both
+   channels.  wide = 1: kernel float64 [kh][kw], out float64 [H][W][2] (numpy.result_type of a float32
+   flow with a float64 or integer kernel); wide = 0: kernel and out float32. */
+int tf_flow_convolve_dev(const void *flow_dev, const void *kernel_dev, int kh, int kw, int wide, void *out_dev, int width,
+                         int height);
+
+/* source.py:349-362 on a flow of either type, in place (after a convolution the reference carries
+   on in the convolution's type).  FORWARD needs scratch_dev: 4 bytes per pixel. */
+int tf_flow_post_process_dev(void *flow_dev, int wide, int width, int height, int direction, void *scratch_dev);
+
+/* Flow visualisation, transflow/output/render.py:9-27 and :30-48: arr float32 [n] / flow float32
+   [n][2] -> rgb uint8 [n][3].  colors_rgb: 2 (render1d) or 4 (render2d) colours as float triples. */
+int tf_flow_render1d_dev(const void *arr_dev, void *rgb_dev, size_t n, float scale, const float colors_rgb[6], int binary);
+int tf_flow_render2d_dev(const void *flow_dev, void *rgb_dev, size_t n, float scale, const float colors_rgb[12]);
+
+/* Frame ingest, transflow/flow/sources/cv.py:461-466: cv2.resize(INTER_NEAREST) to (width, height)
+   then cv2.cvtColor(COLOR_BGR2GRAY), fused: bgr uint8 [src_height][src_width][3] -> grey uint8
+   [height][width].  OpenCV's arithmetic is recalled, not verifiable here (parity unpinned). */
+int tf_frame_grey_dev(const void *bgr_dev, int src_width, int src_height, void *grey_dev, int width, int height);
+
 /* Stage-level entry points (debug/parity tests): run one stage of the pyramid on
    host arrays with exactly the kernels the full path uses.  Layouts as OpenCV's:
    R and M are [H][W][5] interleaved on the host side. */

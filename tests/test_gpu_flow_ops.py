@@ -1,0 +1,127 @@
+"""GPU parity of the flow-array steps either side of the path against the
+reference's own vectors (tests/golden/flow_ops.npz) and, at full size, against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import flow_ops_ref as F
+from oracle import frames_ref
+from tests.helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+Z = np.load(os.path.join(GOLDEN, "flow_ops.npz"))
+
+
+def test_merge_golden_gpu():
+    from transflow_amd.flowops import merge_flows
+    for i in range(int(Z["merge_cases"])):
+        kind, n = str(Z[f"merge_{i}_kind"]), int(Z[f"merge_{i}_n"])
+        out = merge_flows(kind, [Z[f"merge_{i}_in{j}"] for j in range(n)])
+        np.testing.assert_array_equal(out, Z[f"merge_{i}_out"], err_msg=f"{kind} n={n}")
+    with pytest.raises(ValueError):
+        merge_flows("absmax", [Z["merge_0_in0"]] * 3)
+    with pytest.raises(KeyError):
+        merge_flows("median", [Z["merge_0_in0"]])
+
+
+def test_merge_full_size_vs_oracle():
+    from transflow_amd.flowops import MERGE_KINDS, merge_flows
+    rng = np.random.default_rng(5)
+    flows = [rng.normal(0, 2, (1080, 1920, 2)).astype(np.float32) for _ in range(3)]
+    flows[1][rng.random(flows[1].shape) < 0.3] = 0
+    flows[2][0, 0] = np.nan
+    for kind in MERGE_KINDS:
+        use = flows[:2] if kind == "absmax" else flows
+        np.testing.assert_array_equal(merge_flows(kind, use), F.merge(kind, use), err_msg=kind)
+
+
+def test_upscale_golden_gpu():
+    from transflow_amd.flowops import upscale_array
+    for i in range(int(Z["up_cases"])):
+        wf, hf = (int(v) for v in Z[f"up_{i}_f"])
+        np.testing.assert_array_equal(upscale_array(Z[f"up_{i}_in"], wf, hf), Z[f"up_{i}_out"])
+    a = np.random.default_rng(6).normal(0, 3, (540, 960, 2)).astype(np.float32)
+    np.testing.assert_array_equal(upscale_array(a, 2, 2), F.upscale(a, 2, 2))
+
+
+def test_kernel_post_process_golden_gpu():
+    from transflow_amd.flowops import convolve_post_process
+    for i in range(int(Z["conv_cases"])):
+        k, exp = Z[f"conv_{i}_kernel"], Z[f"conv_{i}_out"]
+        out = convolve_post_process(Z[f"conv_{i}_in"], k, int(Z[f"conv_{i}_dir"]))
+        assert out.dtype == exp.dtype, (i, k.dtype)
+        np.testing.assert_array_equal(out, exp, err_msg=f"case {i} kernel {k.dtype}{k.shape}")
+
+
+def test_kernel_through_the_flow_source():
+    """HipFlowSource.post_process with mask + filter + kernel, against the oracle's chain."""
+    from oracle import remap_ref as R
+    from transflow_amd.flow import FlowFilter, FlowSource
+    h, w = 45, 64
+    rng = np.random.default_rng(8)
+    kernel = rng.normal(0, 0.3, (3, 5))
+    mask = rng.random((h, w, 1)).astype(np.float32)
+    for direction in ("forward", "backward"):
+        src = FlowSource(direction, w, h, 25.0, 10, 0, 0, 10, mask=mask, kernel=kernel,
+                         flow_filters=[FlowFilter.from_string("scale=1.5")])
+        raw = rng.normal(0, 3, (h, w, 2)).astype(np.float32)
+        out = src.post_process(raw.copy())
+        pre = R.pre_steps(raw.copy(), [("scale", 1.5)], mask)
+        exp = F.post_process_with_kernel(pre, kernel, R.FORWARD if direction == "forward" else R.BACKWARD)
+        assert out.dtype == np.float64
+        np.testing.assert_array_equal(out, exp)
+        src.close()
+
+
+def test_render_golden_gpu():
+    from transflow_amd.flowops import render1d, render2d
+    for i in range(int(Z["r1_cases"])):
+        out = render1d(Z[f"r1_{i}_in"], float(Z[f"r1_{i}_scale"]), tuple(str(c) for c in Z[f"r1_{i}_colors"]),
+                       bool(Z[f"r1_{i}_binary"]))
+        np.testing.assert_array_equal(out, Z[f"r1_{i}_out"], err_msg=f"render1d {i}")
+    for i in range(int(Z["r2_cases"])):
+        out = render2d(Z[f"r2_{i}_in"], float(Z[f"r2_{i}_scale"]), tuple(str(c) for c in Z[f"r2_{i}_colors"]))
+        np.testing.assert_array_equal(out, Z[f"r2_{i}_out"], err_msg=f"render2d {i}")
+    big = np.random.default_rng(9).normal(0, 5, (1080, 1920, 2)).astype(np.float32)
+    np.testing.assert_array_equal(render2d(big, 0.1), F.render2d(big, 0.1))
+    np.testing.assert_array_equal(render1d(np.abs(big[:, :, 0]), 0.3), F.render1d(np.abs(big[:, :, 0]), 0.3))
+
+
+@pytest.mark.parametrize("size", [None, (854, 480), (333, 77), (3840, 2160)])
+def test_bgr_to_grey_vs_oracle(size):
+    from transflow_amd.flowops import bgr_to_grey
+    frame = np.random.default_rng(10).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(bgr_to_grey(frame, size), frames_ref.bgr_to_grey(frame, size))
+
+
+@pytest.mark.parametrize("rounded", [False, True])
+def test_archive_source_post_processes_on_the_gpu(tmp_path, rounded):
+    """A .flow.zip read back through ArchiveFlowSource: every frame equals the oracle's post_process of
+    the stored array (dtype kept for a rounded archive, pipeline.py:506); the archive ends with the
+    KeyError of the first missing frame, as in the reference (archive.py:45-48)."""
+    from oracle import remap_ref as R
+    from transflow_amd.archive import NumpyOutput, flow_export_meta
+    from transflow_amd.flow import HipFlowSource
+    rng = np.random.default_rng(11)
+    h, w = 40, 56
+    flows = [rng.normal(0, 4, (h, w, 2)).astype(np.float32) for _ in range(3)]
+    if rounded:
+        flows = [np.round(f).astype(int) for f in flows]
+    path = str(tmp_path / "clip.flow.zip")
+    out = NumpyOutput(path, True)
+    out.write_meta(flow_export_meta("clip.mp4", w, h, 25.0, "forward"))
+    for f in flows:
+        out.write_array(f)
+    out.close()
+    got = []
+    with HipFlowSource.from_args(path) as source:
+        assert (source.width, source.height, source.framerate, source.length) == (w, h, 25.0, None)
+        with pytest.raises(KeyError):
+            for flow in source:
+                got.append(flow)
+    assert len(got) == 3
+    for f, g in zip(flows, got):
+        exp = R.post_process(f.astype(np.float32), R.FORWARD)
+        assert g.dtype == f.dtype
+        np.testing.assert_array_equal(g, exp.astype(f.dtype))

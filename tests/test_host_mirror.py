@@ -65,7 +65,7 @@ def _builder(n_frames=51, fps=25.0, **kw):
     return HipFlowSource.Builder(ArrayFrameProvider(frames, fps), None, **kw)
 
 
-def test_builder_timing_arithmetic():
+def test_builder_timing_arithmetic(tmp_path):
     """FlowSource.Builder.build, reference source.py:151-197."""
     b = _builder()
     b.build()
@@ -89,8 +89,11 @@ def test_builder_timing_arithmetic():
     b = _builder(lock_expr="t > 1", lock_mode="skip")
     b.build()
     assert b.lock_expr_skip(1.5) and not b.lock_expr_skip(0.5)
-    with pytest.raises(NotImplementedError):
-        _builder(kernel_path="k.npy").build()
+    kpath = os.path.join(str(tmp_path), "k.npy")
+    np.save(kpath, np.full((3, 3), 1 / 9.0))
+    b = _builder(kernel_path=kpath)
+    b.build()
+    assert b.kernel.shape == (3, 3) and b.kwargs()["kernel"] is b.kernel          # source.py:131-132
     b = _builder(flow_filters="scale=2*t; threshold = 0.5")
     b.build()
     assert [f.name for f in b.flow_filters] == ["scale", "threshold"] and b.flow_filters[0].expr(1.5) == 3.0
@@ -222,3 +225,47 @@ def test_dropin_install_patches_reference_factories():
         sys.path.remove("/root/reference")
         for m in [m for m in sys.modules if m == "transflow" or m.startswith("transflow.")]:
             del sys.modules[m]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/transflow"), reason="reference tree not present")
+def test_flow_archive_format_is_the_references(tmp_path):
+    """.flow.zip written here is read by the reference's ArchiveFlowSource and vice versa
+    (output/zip.py, output/numpy.py, flow/sources/archive.py)."""
+    import sys
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from transflow.flow.sources.archive import ArchiveFlowSource as RefArchive
+    from transflow.output.numpy import NumpyOutput as RefNumpyOutput
+    from transflow_amd.archive import ArchiveFlowSource, NumpyOutput, find_unique_path, flow_export_meta
+    rng = np.random.default_rng(3)
+    flows = [rng.normal(0, 2, (6, 9, 2)).astype(np.float32) for _ in range(3)]
+    ours, theirs = str(tmp_path / "a.flow.zip"), str(tmp_path / "b.flow.zip")
+    for cls, path in ((NumpyOutput, ours), (RefNumpyOutput, theirs)):
+        out = cls(path, True)
+        out.write_meta(flow_export_meta("clip.mp4", 9, 6, 25.0, "backward"))
+        for f in flows:
+            out.write_array(f)
+        out.close()
+    # byte-identical members
+    import zipfile
+    with zipfile.ZipFile(ours) as a, zipfile.ZipFile(theirs) as b:
+        assert a.namelist() == b.namelist() == ["meta.json", "000000000.npy", "000000001.npy", "000000002.npy"]
+        for name in a.namelist():
+            assert a.read(name) == b.read(name), name
+    # cross reading: builders agree on everything they derive
+    rb, ob = RefArchive.Builder(ours), ArchiveFlowSource.Builder(theirs)
+    rb.build()
+    ob.build()
+    for attr in ("width", "height", "framerate", "base_length", "length", "start_frame", "end_frame"):
+        assert getattr(rb, attr) == getattr(ob, attr), attr
+    assert rb.direction.value == ob.direction.value == 1
+    src = ArchiveFlowSource(*ob.args(), **ob.kwargs())
+    src.validate()
+    for t in range(3):
+        np.testing.assert_array_equal(src.next(), flows[t])
+        src.input_frame_index += 1
+    with pytest.raises(KeyError):
+        src.next()                                   # how an archive ends in the reference
+    src.archive.close()
+    rb.archive.close()
+    assert find_unique_path(ours) == str(tmp_path / "a.000.flow.zip")

@@ -277,6 +277,96 @@ def capture_other_layers():
     print("other-layer cases:", len(cases))
 
 
+def capture_flow_ops():
+    """flow merging (pipeline.py:149-158 + utils.py:359-381), upscale_array
+    (utils.py:417-418), the convolution-kernel pre-step of post_process (source.py:344-348) and the
+    flow visualisation (output/render.py:9-48).  transflow.pipeline needs typing.Self (Python 3.11):
+    taken from typing_extensions for the import."""
+    import typing
+    import typing_extensions
+    if not hasattr(typing, "Self"):
+        typing.Self = typing_extensions.Self
+    from transflow.pipeline import Pipeline
+    from transflow.utils import upscale_array
+    from transflow.output.render import render1d, render2d
+    rng = np.random.default_rng(404)
+    d = {}
+    # ---- merging
+    n_case = 0
+    for (h, w) in ((12, 16), (23, 29)):
+        for n in (1, 2, 3, 5):
+            flows = [rng.normal(0, 1.5, (h, w, 2)).astype(np.float32) for _ in range(n)]
+            for f in flows[1:]:
+                f[rng.random((h, w, 2)) < 0.3] = 0          # exact zeros and small values for the masks
+                f[rng.random((h, w, 2)) < 0.1] = np.float32(0.2)
+            for kind, fn in Pipeline.FLOW_MERGING_FUNCTIONS.items():
+                if kind == "absmax" and n != 2:
+                    continue
+                ins = [f.copy() for f in flows]
+                out = np.asarray(fn(ins))
+                d[f"merge_{n_case}_kind"] = np.array(kind)
+                d[f"merge_{n_case}_n"] = np.int32(n)
+                for i, f in enumerate(flows):
+                    d[f"merge_{n_case}_in{i}"] = f
+                d[f"merge_{n_case}_out"] = out
+                n_case += 1
+    d["merge_cases"] = np.int32(n_case)
+    # ---- upscale
+    ups = [(1, 1), (2, 2), (3, 2), (1, 4)]
+    for i, (wf, hf) in enumerate(ups):
+        a = rng.normal(0, 3, (11, 17, 2)).astype(np.float32)
+        d[f"up_{i}_in"], d[f"up_{i}_f"] = a, np.array([wf, hf], np.int32)
+        d[f"up_{i}_out"] = upscale_array(a, wf, hf)
+    d["up_cases"] = np.int32(len(ups))
+    # ---- convolution kernel inside post_process
+    kernels = [
+        np.full((3, 3), 1 / 9.0),                                        # float64 box
+        rng.normal(0, 0.3, (5, 3)),                                      # float64, odd x odd, not symmetric
+        rng.normal(0, 0.3, (4, 4)),                                      # even sizes: 'same' centring
+        rng.normal(0, 0.3, (3, 3)).astype(np.float32),                   # float32 kernel: float32 result
+        np.array([[2.0]]),                                               # 1x1
+        np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], dtype=np.int64),    # integer kernel: float64 result
+        rng.normal(0, 0.2, (1, 7)),                                      # row kernel
+    ]
+    n_case = 0
+    for k in kernels:
+        for direction in (FlowSource.Direction.FORWARD, FlowSource.Direction.BACKWARD):
+            h, w = (24, 31) if n_case % 2 else (37, 53)
+            fs = make_fs(direction, h, w)
+            fs.kernel = k
+            raw = rng.normal(0, 3.0, (h, w, 2)).astype(np.float32)
+            out = np.asarray(fs.post_process(raw.copy()))
+            d[f"conv_{n_case}_kernel"] = k
+            d[f"conv_{n_case}_dir"] = np.int32(0 if direction == FlowSource.Direction.FORWARD else 1)
+            d[f"conv_{n_case}_in"] = raw
+            d[f"conv_{n_case}_out"] = out
+            n_case += 1
+    d["conv_cases"] = np.int32(n_case)
+    # ---- render1d / render2d
+    n_case = 0
+    for scale, colors, binary in ((1, None, False), (0.25, ("#102030", "#f0e0d0"), False), (0.5, None, True),
+                                  (2.0, ("#ff0000", "#00ff80"), True)):
+        arr = np.abs(rng.normal(0, 2, (19, 23))).astype(np.float32)
+        d[f"r1_{n_case}_in"] = arr
+        d[f"r1_{n_case}_scale"] = np.float64(scale)
+        d[f"r1_{n_case}_colors"] = np.array(colors if colors else ("#000000", "#ffffff"))
+        d[f"r1_{n_case}_binary"] = np.bool_(binary)
+        d[f"r1_{n_case}_out"] = render1d(arr, scale=scale, colors=colors, binary=binary)
+        n_case += 1
+    d["r1_cases"] = np.int32(n_case)
+    n_case = 0
+    for scale, colors in ((1, None), (0.2, None), (0.05, ("#ff8000", "#0080ff", "#80ff00", "#8000ff"))):
+        arr = rng.normal(0, 4, (19, 23, 2)).astype(np.float32)
+        d[f"r2_{n_case}_in"] = arr
+        d[f"r2_{n_case}_scale"] = np.float64(scale)
+        d[f"r2_{n_case}_colors"] = np.array(colors if colors else ("#ffff00", "#0000ff", "#ff00ff", "#00ff00"))
+        d[f"r2_{n_case}_out"] = render2d(arr, scale=scale, colors=colors)
+        n_case += 1
+    d["r2_cases"] = np.int32(n_case)
+    np.savez_compressed(os.path.join(OUT, "flow_ops.npz"), **d)
+    print("flow ops:", int(d["merge_cases"]), "merges,", int(d["conv_cases"]), "convolutions")
+
+
 def capture_known_answers():
     """tests/test_compositor.py:20-54 re-run, outputs stored."""
     d = {}
@@ -383,6 +473,9 @@ def capture_flow_presteps():
 
 
 if __name__ == "__main__":
+    if "--flowops-only" in sys.argv:
+        capture_flow_ops()
+        sys.exit(0)
     if "--layers2-only" in sys.argv:
         capture_other_layers()
         sys.exit(0)
@@ -398,5 +491,6 @@ if __name__ == "__main__":
     capture_known_answers()
     capture_multilayer()
     capture_other_layers()
+    capture_flow_ops()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", total)

@@ -97,6 +97,13 @@ PROTOTYPES = {
     "tf_remap_check": (_I, [_P, _PI]),
     "tf_remap_gather": (_I, [_P, _I, _P, _I]),
     "tf_remap_gather_dev": (_I, [_P, _I, _P, _I]),
+    "tf_flow_merge_dev": (_I, [_I, _I, _PP, _P, C.c_size_t]),
+    "tf_flow_upscale_dev": (_I, [_P, _P, _I, _I, _I, _I]),
+    "tf_flow_convolve_dev": (_I, [_P, _P, _I, _I, _I, _P, _I, _I]),
+    "tf_flow_post_process_dev": (_I, [_P, _I, _I, _I, _I, _P]),
+    "tf_flow_render1d_dev": (_I, [_P, _P, C.c_size_t, C.c_float, C.POINTER(C.c_float), _I]),
+    "tf_flow_render2d_dev": (_I, [_P, _P, C.c_size_t, C.c_float, C.POINTER(C.c_float)]),
+    "tf_frame_grey_dev": (_I, [_P, _I, _I, _P, _I, _I]),
     "tf_remap_introduce": (_I, [_P, _I, _P, _I, _I]),
     "tf_remap_introduce_dev": (_I, [_P, _I, _P, _I, _I]),
     "tf_remap_data_depth": (_I, [_P, _PI]),

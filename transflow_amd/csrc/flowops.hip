@@ -1,0 +1,350 @@
+// Flow-array steps either side of the hot path, on gfx950:
+//   flow merging            transflow/pipeline.py:149-158, transflow/utils.py:359-381
+//   integer upscaling       transflow/utils.py:417-418
+//   convolution kernel      transflow/flow/sources/source.py:344-348 (scipy.signal.convolve2d)
+//   post_process in the convolution's type (float64 unless the kernel is float32), :349-362
+//   flow visualisation      transflow/output/render.py:9-48
+//   BGR -> grey             transflow/flow/sources/cv.py:461-466 (cv2.cvtColor) + nearest resize
+// All element-wise or small-stencil, HBM-bound; arithmetic in the type and order numpy / scipy use.
+#include <cstring>
+
+#include "common.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct MergeArgs {
+    const float *in[TF_MAX_MERGE];
+    int n;
+};
+
+// Pipeline.FLOW_MERGING_FUNCTIONS: float32, operands combined left to right
+__global__ void k_flow_merge(MergeArgs a, float *__restrict__ out, size_t count, int kind)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= count)
+        return;
+    const float f0 = a.in[0][t];
+    float r = f0;
+    switch (kind) {
+    case TF_MERGE_FIRST:
+        break;
+    case TF_MERGE_SUM:
+    case TF_MERGE_AVERAGE:
+        for (int i = 1; i < a.n; i++)
+            r = r + a.in[i][t];
+        if (kind == TF_MERGE_AVERAGE)
+            r = r / (float)a.n;
+        break;
+    case TF_MERGE_DIFFERENCE: { // flows[0] - sum(flows[1:])
+        float s = 0.f;
+        if (a.n > 1) {
+            s = a.in[1][t];
+            for (int i = 2; i < a.n; i++)
+                s = s + a.in[i][t];
+        }
+        r = f0 - s;
+        break;
+    }
+    case TF_MERGE_PRODUCT:
+        for (int i = 1; i < a.n; i++)
+            r = r * a.in[i][t];
+        break;
+    case TF_MERGE_MASKBIN: // utils.py:367-373: |x| > 0.2 (float32) -> 1, else 0
+        for (int i = 1; i < a.n; i++)
+            r = r * (fabsf(a.in[i][t]) > 0.2f ? 1.f : 0.f);
+        break;
+    case TF_MERGE_MASKLIN:
+        for (int i = 1; i < a.n; i++)
+            r = r * fabsf(a.in[i][t]);
+        break;
+    case TF_MERGE_ABSMAX: { // utils.py:376-381: numpy.argmax keeps the first maximum; a NaN is a maximum
+        const float f1 = a.in[1][t];
+        const float a0 = fabsf(f0), a1 = fabsf(f1);
+        if (a1 > a0 || (a1 != a1 && a0 == a0))
+            r = f1;
+        break;
+    }
+    }
+    out[t] = r;
+}
+
+// utils.upscale_array: (x * wf, y * hf) repeated hf x wf times
+__global__ void k_flow_upscale(const float2 *__restrict__ in, float2 *__restrict__ out, int W, int H, int wf, int hf)
+{
+    const int Wo = W * wf;
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)Wo * H * hf)
+        return;
+    const int xo = (int)(t % Wo), yo = (int)(t / Wo);
+    float2 v = in[(size_t)(yo / hf) * W + xo / wf];
+    out[t] = make_float2(v.x * (float)wf, v.y * (float)hf);
+}
+
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+    typedef float2 type;
+};
+template <> struct Pair<double> {
+    typedef double2 type;
+};
+
+// scipy.signal.convolve2d(mode="same", boundary="fill", fillvalue=0) on both channels: kernel rows j
+// then columns k, each product and each sum rounded in T (scipy/signal/_firfilter.c)
+template <typename T>
+__global__ void k_flow_convolve(const float2 *__restrict__ flow, const T *__restrict__ kern, int kh, int kw,
+                                typename Pair<T>::type *__restrict__ out, int W, int H)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)W * H)
+        return;
+    const int n = (int)(t % W), m = (int)(t / W);
+    const int oy = (kh - 1) >> 1, ox = (kw - 1) >> 1;
+    T sx = 0, sy = 0;
+    for (int j = 0; j < kh; j++) {
+        const int y = m + oy - j;
+        const bool row_in = y >= 0 && y < H;
+        for (int k = 0; k < kw; k++) {
+            const int x = n + ox - k;
+            const T hv = kern[j * kw + k];
+            T vx = 0, vy = 0;
+            if (row_in && x >= 0 && x < W) {
+                float2 f = flow[(size_t)y * W + x];
+                vx = (T)f.x;
+                vy = (T)f.y;
+            }
+            sx = sx + hv * vx; // the fill value takes part: 0 * h
+            sy = sy + hv * vy;
+        }
+    }
+    typename Pair<T>::type r;
+    r.x = sx;
+    r.y = sy;
+    out[t] = r;
+}
+
+template <typename T> __device__ __forceinline__ T clip_nan_t(T v, T lo, T hi)
+{
+    return v != v ? v : (v < lo ? lo : (v > hi ? hi : v));
+}
+
+template <typename T2> __device__ __forceinline__ T2 clip_frame_t(T2 f, int i, int j, int W, int H)
+{
+    typedef decltype(f.x) T;
+    f.x = clip_nan_t<T>(f.x, (T)(-j), (T)(W - 1 - j));
+    f.y = clip_nan_t<T>(f.y, (T)(-i), (T)(H - 1 - i));
+    return f;
+}
+
+template <typename T2> __global__ void k_pp_clip_t(T2 *flow, int W, int H)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= W * H)
+        return;
+    flow[t] = clip_frame_t(flow[t], t / W, t % W, W, H);
+}
+
+// source.py:350-358 (see k_pp_fwd_scatter in farneback.hip)
+template <typename T2>
+__global__ void k_pp_fwd_scatter_t(const T2 *__restrict__ flow, int *__restrict__ winner, int W, int H)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int N = W * H;
+    if (t >= N)
+        return;
+    T2 f = clip_frame_t(flow[t], t / W, t % W, W, H);
+    int ix = (int)rint((double)f.x), iy = (int)rint((double)f.y);
+    int d = iy * W + ix;
+    if (d == 0)
+        return;
+    int target = min(max(t + d, 0), N - 1);
+    atomicMax(&winner[target], t);
+}
+
+template <typename T2>
+__global__ void k_pp_fwd_resolve_t(T2 *__restrict__ flow, const int *__restrict__ winner, int W, int H)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= W * H)
+        return;
+    typedef decltype(flow[0].x) T;
+    int w = winner[t];
+    int src = w >= 0 ? w : t;
+    int i = t / W, j = t % W;
+    T2 f;
+    f.x = (T)(src % W - j);
+    f.y = (T)(src / W - i);
+    flow[t] = clip_frame_t(f, i, j, W, H);
+}
+
+struct Colors {
+    float c[4][3];
+};
+
+__device__ __forceinline__ float clip01(float v) { return clip_nan(v, 0.f, 1.f); }
+__device__ __forceinline__ uint8_t to_u8(float v) { return (uint8_t)(int)clip_nan(v, 0.f, 255.f); }
+
+// output/render.py:9-27
+__global__ void k_render1d(const float *__restrict__ arr, uint8_t *__restrict__ rgb, size_t N, float scale, Colors col,
+                           int binary)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    const float sa = scale * arr[t];
+    float ka, kb;
+    if (binary) {
+        kb = clip01(rintf(sa));
+        ka = 1.f - kb;
+    } else {
+        ka = clip01(1.f - sa);
+        kb = clip01(sa);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        rgb[t * 3 + c] = to_u8(ka * col.c[0][c] + kb * col.c[1][c]);
+}
+
+// output/render.py:30-48
+__global__ void k_render2d(const float2 *__restrict__ flow, uint8_t *__restrict__ rgb, size_t N, float scale, Colors col)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    const float2 f = flow[t];
+    const float sx = scale * f.x, sy = scale * f.y;
+    const float ky = clip01(1.f + sx), kb = clip01(1.f - sx), km = clip01(1.f + sy), kg = clip01(1.f - sy);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        rgb[t * 3 + c] = to_u8(0.5f * (((ky * col.c[0][c] + kb * col.c[1][c]) + km * col.c[2][c]) + kg * col.c[3][c]));
+}
+
+// cv2.cvtColor(frame, COLOR_BGR2GRAY) for 8-bit images (cv.py:463, 466): OpenCV 4.x fixed point with
+// 15 fractional bits, Y = (B*3735 + G*19235 + R*9798 + 16384) >> 15  (imgproc color_rgb: the BT.601
+// weights 0.114, 0.587, 0.299 times 2^15, rounded; they sum to 32768).  RECALLED, cv2 is not
+// installable here: parity unpinned.
+// Fused with the nearest-neighbour resize of cv.py:461-462 / :464-465 (cv2.resize INTER_NEAREST:
+// source index = min(floor(dst * src / dst_size), src - 1)); equal sizes make it a plain conversion.
+__global__ void k_bgr_to_grey(const uint8_t *__restrict__ bgr, int Ws, int Hs, uint8_t *__restrict__ grey, int W, int H,
+                              double fx, double fy)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)W * H)
+        return;
+    const int x = (int)(t % W), y = (int)(t / W);
+    const int sx = min((int)floor(x * fx), Ws - 1), sy = min((int)floor(y * fy), Hs - 1);
+    const uint8_t *p = bgr + ((size_t)sy * Ws + sx) * 3;
+    grey[t] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + 16384) >> 15);
+}
+
+} // namespace
+
+TF_API int tf_flow_merge_dev(int kind, int n, const void *const *flows_dev, void *out_dev, size_t n_values)
+{
+    TF_REQUIRE(kind >= TF_MERGE_FIRST && kind <= TF_MERGE_ABSMAX, "tf_flow_merge: unknown kind %d", kind);
+    TF_REQUIRE(n >= 1 && n <= TF_MAX_MERGE, "tf_flow_merge: %d flows (1..%d)", n, TF_MAX_MERGE);
+    TF_REQUIRE(kind != TF_MERGE_ABSMAX || n == 2, "tf_flow_merge: absmax merges exactly two flows, got %d", n);
+    TF_REQUIRE(flows_dev && (out_dev || n_values == 0), "tf_flow_merge: null pointer");
+    TF_TRY(ensure_init());
+    MergeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    for (int i = 0; i < n; i++) {
+        TF_REQUIRE(flows_dev[i] || n_values == 0, "tf_flow_merge: flow %d is null", i);
+        a.in[i] = (const float *)flows_dev[i];
+    }
+    return launch("flow_merge", k_flow_merge, dim3(cdiv(n_values, BLOCK)), dim3(BLOCK), 0, a, (float *)out_dev, n_values,
+                  kind);
+}
+
+TF_API int tf_flow_upscale_dev(const void *in_dev, void *out_dev, int width, int height, int wf, int hf)
+{
+    TF_REQUIRE(width >= 0 && height >= 0 && wf >= 1 && hf >= 1, "tf_flow_upscale: bad size %dx%d x(%d,%d)", width, height,
+               wf, hf);
+    TF_REQUIRE((in_dev && out_dev) || (size_t)width * height == 0, "tf_flow_upscale: null pointer");
+    TF_TRY(ensure_init());
+    const size_t n = (size_t)width * wf * height * hf;
+    return launch("flow_upscale", k_flow_upscale, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const float2 *)in_dev,
+                  (float2 *)out_dev, width, height, wf, hf);
+}
+
+TF_API int tf_flow_convolve_dev(const void *flow_dev, const void *kernel_dev, int kh, int kw, int wide, void *out_dev,
+                                int width, int height)
+{
+    TF_REQUIRE(kh >= 1 && kw >= 1 && width >= 0 && height >= 0, "tf_flow_convolve: bad sizes");
+    TF_REQUIRE((flow_dev && out_dev && kernel_dev) || (size_t)width * height == 0, "tf_flow_convolve: null pointer");
+    TF_TRY(ensure_init());
+    const size_t n = (size_t)width * height;
+    if (wide)
+        return launch("flow_convolve_f64", k_flow_convolve<double>, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
+                      (const float2 *)flow_dev, (const double *)kernel_dev, kh, kw, (double2 *)out_dev, width, height);
+    return launch("flow_convolve_f32", k_flow_convolve<float>, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
+                  (const float2 *)flow_dev, (const float *)kernel_dev, kh, kw, (float2 *)out_dev, width, height);
+}
+
+template <typename T2> static int pp_any(T2 *flow, int W, int H, int direction, int *winner)
+{
+    const size_t n = (size_t)W * H;
+    dim3 grid(cdiv(n, BLOCK)), block(BLOCK);
+    if (direction == 0) {
+        TF_REQUIRE(winner || n == 0, "tf_flow_post_process: FORWARD needs the 4 B/px scratch buffer");
+        TF_HIP(hipMemsetAsync(winner, 0xFF, n * 4, stream()));
+        TF_TRY(launch("flow_pp_fwd_scatter", k_pp_fwd_scatter_t<T2>, grid, block, 0, (const T2 *)flow, winner, W, H));
+        return launch("flow_pp_fwd_resolve", k_pp_fwd_resolve_t<T2>, grid, block, 0, flow, (const int *)winner, W, H);
+    }
+    return launch("flow_pp_clip", k_pp_clip_t<T2>, grid, block, 0, flow, W, H);
+}
+
+TF_API int tf_flow_post_process_dev(void *flow_dev, int wide, int width, int height, int direction, void *scratch_dev)
+{
+    TF_REQUIRE(direction == 0 || direction == 1, "tf_flow_post_process: direction must be 0 (FORWARD) or 1 (BACKWARD)");
+    TF_REQUIRE(width >= 0 && height >= 0 && (long long)width * height < (1ll << 31), "tf_flow_post_process: bad size");
+    TF_REQUIRE(flow_dev || (size_t)width * height == 0, "tf_flow_post_process: null pointer");
+    TF_TRY(ensure_init());
+    if (wide)
+        return pp_any((double2 *)flow_dev, width, height, direction, (int *)scratch_dev);
+    return pp_any((float2 *)flow_dev, width, height, direction, (int *)scratch_dev);
+}
+
+static Colors make_colors(const float *rgb, int n)
+{
+    Colors c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            c.c[i][k] = rgb[i * 3 + k];
+    return c;
+}
+
+TF_API int tf_flow_render1d_dev(const void *arr_dev, void *rgb_dev, size_t n, float scale, const float colors_rgb[6],
+                                int binary)
+{
+    TF_REQUIRE(colors_rgb && ((arr_dev && rgb_dev) || n == 0), "tf_flow_render1d: null pointer");
+    TF_TRY(ensure_init());
+    return launch("flow_render1d", k_render1d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const float *)arr_dev,
+                  (uint8_t *)rgb_dev, n, scale, make_colors(colors_rgb, 2), binary);
+}
+
+TF_API int tf_flow_render2d_dev(const void *flow_dev, void *rgb_dev, size_t n, float scale, const float colors_rgb[12])
+{
+    TF_REQUIRE(colors_rgb && ((flow_dev && rgb_dev) || n == 0), "tf_flow_render2d: null pointer");
+    TF_TRY(ensure_init());
+    return launch("flow_render2d", k_render2d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const float2 *)flow_dev,
+                  (uint8_t *)rgb_dev, n, scale, make_colors(colors_rgb, 4));
+}
+
+TF_API int tf_frame_grey_dev(const void *bgr_dev, int src_width, int src_height, void *grey_dev, int width, int height)
+{
+    TF_REQUIRE(src_width >= 1 && src_height >= 1 && width >= 0 && height >= 0, "tf_frame_grey: bad sizes");
+    TF_REQUIRE((bgr_dev && grey_dev) || (size_t)width * height == 0, "tf_frame_grey: null pointer");
+    TF_TRY(ensure_init());
+    const size_t n = (size_t)width * height;
+    // cv2.resize with dsize only: fx = dsize.width / src.cols; the nearest-neighbour source index is
+    // floor(dst * (1 / fx))
+    const double ifx = width ? 1.0 / ((double)width / src_width) : 1.0, ify = height ? 1.0 / ((double)height / src_height) : 1.0;
+    return launch("frame_grey", k_bgr_to_grey, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const uint8_t *)bgr_dev, src_width,
+                  src_height, (uint8_t *)grey_dev, width, height, ifx, ify);
+}

@@ -9,9 +9,10 @@
 (transflow/pipeline.py:325 FlowSource.from_args, :445 Compositor.from_args) with
 dispatchers that build HipFlowSource / HipCompositor when the request is one this
 backend serves -- a video path (or webcam index) with the Farnebäck method (flow mask and the
-scale/threshold/clip filters included; no convolution kernel, no polar filter), layers of
+scale/threshold/clip filters and the convolution kernel included; no polar filter), layers of
 any of the reference's classes (`moveref`, `sum`, `static`, `introduction`) -- and fall through to
-the reference's own factory otherwise (archives, motion vectors, other flow methods).
+the reference's own factory otherwise (motion vectors, other flow methods, the polar filter).
+`.flow.zip` archives are served too (their flows are post-processed on the GPU).
 INTEGRATION.md shows the three-line patch a maintainer would add instead.
 """
 from __future__ import annotations
@@ -28,8 +29,8 @@ def _flow_from_args(original):
     def from_args(cls, flow_path, use_mvs=False, mask_path=None, kernel_path=None, cv_config=None,
                   flow_filters=None, size=None, direction=None, seek_ckpt=None, seek_time=None,
                   duration_time=None, repeat=1, lock_expr=None, lock_mode="stay"):
-        served = (isinstance(flow_path, str) and not use_mvs and not flow_path.endswith(".flow.zip")
-                  and kernel_path is None and (flow_filters is None or "polar" not in flow_filters)
+        served = (isinstance(flow_path, str) and not use_mvs
+                  and (flow_filters is None or "polar" not in flow_filters)
                   and cv_config != "window")
         if served and cv_config is not None and os.path.isfile(cv_config):
             try:

@@ -141,10 +141,8 @@ class FlowSource:
                     "lock_expr_skip": self.lock_expr_skip}
 
         def build(self):
-            if self.kernel_path is not None:
-                # the convolution kernel pre-step (source.py:344-348) is not on the GPU yet; there is
-                # deliberately no host fallback
-                raise NotImplementedError("flow convolution kernels are not implemented by transflow_amd yet")
+            if self.kernel_path is not None:                                            # source.py:131-132
+                self.kernel = np.load(self.kernel_path)
             if self.mask_path is not None:                                              # source.py:127-129
                 from .masks import load_float_mask
                 self.mask = load_float_mask(self.mask_path)
@@ -209,7 +207,10 @@ class FlowSource:
         self.end_frame = end_frame
         self.mask, self.kernel, self.flow_filters = mask, kernel, list(flow_filters)
         if self.kernel is not None:
-            raise NotImplementedError("flow convolution kernels are not implemented by transflow_amd yet")
+            from .flowops import kernel_result_type
+            if not isinstance(self.kernel, np.ndarray):
+                raise ValueError(f"Attribute kernel has incorrect type {type(self.kernel)}")   # source.py:281
+            kernel_result_type(self.kernel)   # float32 / float64 results only
         for f in self.flow_filters:
             if not isinstance(f, FlowFilter):
                 raise ValueError("flow_filters must be transflow_amd.flow.FlowFilter objects")
@@ -294,12 +295,31 @@ class FlowSource:
         field with last-write-wins, both directions clip to the frame.  In place, like the
         reference (so `prev_flow` sees the processed array, source.py:317)."""
         flow = raw
+        if (isinstance(raw, np.ndarray) and np.issubdtype(raw.dtype, np.integer) and not self.flow_filters
+                and self.mask is None and self.kernel is None):
+            # a rounded archive (pipeline.py:506 writes numpy.round(flow).astype(int)): the reference clips
+            # and inverts the integer array in place; small integers are exact in float32
+            out = self.post_process(raw.astype(np.float32))
+            raw[...] = out.astype(raw.dtype)
+            return raw
         if not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.flags.c_contiguous):
             flow = np.ascontiguousarray(raw, dtype=np.float32)
         if self._pp is None:
             from .farneback import Farneback
             self._pp = Farneback(self.width, self.height, levels=0)
         ops = [(f.name, f.expr(self.t)) for f in self.flow_filters]   # filters.py: lambdas of t, host side
+        if self.kernel is not None:
+            # source.py:339-348: filters in place, mask multiply into a new array, then the convolution
+            # of both channels (a NEW array of the convolution's type, float64 unless the kernel is
+            # float32) which the direction handling and the clip then work on
+            from .flowops import convolve_post_process
+            if ops:
+                self._pp.post_process_host_ex(flow, None, ops)
+            pre = flow
+            if self.mask is not None:
+                pre = flow.copy()
+                self._pp.post_process_host_ex(pre, None, (), self.mask)
+            return convolve_post_process(pre, self.kernel, self.direction.value)
         if self.mask is None:
             self._pp.post_process_host_ex(flow, self.direction.value, ops)
             return flow
@@ -477,9 +497,16 @@ class HipFlowSource(FlowSource):
                   flow_filters=None, size=None, direction=None, seek_ckpt=None, seek_time=None,
                   duration_time=None, repeat: int = 1, lock_expr=None, lock_mode="stay"):
         """Same signature as FlowSource.from_args (source.py:365-411); `flow_path` may also be
-        a frame provider object.  Archive and motion-vector sources are not this backend's."""
-        if use_mvs or (isinstance(flow_path, str) and flow_path.endswith(".flow.zip")):
-            raise NotImplementedError("transflow_amd replaces the cv2 Farneback source only")
+        a frame provider object.  `.flow.zip` archives go to ArchiveFlowSource (source.py:397-399);
+        motion-vector sources are not this backend's."""
+        if isinstance(flow_path, str) and flow_path.split("::")[-1].endswith(".flow.zip"):
+            from .archive import ArchiveFlowSource
+            return ArchiveFlowSource.Builder(flow_path.split("::")[-1], direction=direction, mask_path=mask_path,
+                                             kernel_path=kernel_path, flow_filters=flow_filters, seek_ckpt=seek_ckpt,
+                                             seek_time=seek_time, duration_time=duration_time, repeat=repeat,
+                                             lock_expr=lock_expr, lock_mode=lock_mode)
+        if use_mvs:
+            raise NotImplementedError("transflow_amd does not read codec motion vectors")
         if isinstance(cv_config, str):
             config = FlowConfig.from_file(cv_config) if os.path.isfile(cv_config) else FlowConfig()
         else:
