@@ -125,3 +125,19 @@ def test_archive_source_post_processes_on_the_gpu(tmp_path, rounded):
         exp = R.post_process(f.astype(np.float32), R.FORWARD)
         assert g.dtype == f.dtype
         np.testing.assert_array_equal(g, exp.astype(f.dtype))
+
+
+@pytest.mark.parametrize("shape,kshape", [((64, 80), (3, 3)), ((45, 150), (9, 4)), ((24, 31), (70, 70)),
+                                           ((130, 67), (1, 33)), ((17, 64), (16, 1))])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_convolution_tiled_and_fallback_vs_oracle(shape, kshape, dtype):
+    """Both convolution kernels (LDS-tiled; per-pixel fallback for kernels whose tile exceeds 64 KB)
+    against the oracle's scipy-ordered sum, bit for bit, on tile-edge-unfriendly sizes."""
+    from transflow_amd.flowops import convolve_post_process
+    rng = np.random.default_rng(12)
+    flow = rng.normal(0, 3, (*shape, 2)).astype(np.float32)
+    kernel = rng.normal(0, 0.3, kshape).astype(dtype)
+    out = convolve_post_process(flow, kernel, None)
+    exp = np.stack([F.convolve_same(flow[:, :, 0], kernel), F.convolve_same(flow[:, :, 1], kernel)], axis=-1)
+    assert out.dtype == exp.dtype == dtype
+    np.testing.assert_array_equal(out, exp)

@@ -6,6 +6,7 @@
 //   flow visualisation      transflow/output/render.py:9-48
 //   BGR -> grey             transflow/flow/sources/cv.py:461-466 (cv2.cvtColor) + nearest resize
 // All element-wise or small-stencil, HBM-bound; arithmetic in the type and order numpy / scipy use.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -126,6 +127,62 @@ __global__ void k_flow_convolve(const float2 *__restrict__ flow, const T *__rest
     out[t] = r;
 }
 
+// The same sums from an LDS tile: a block of 64x4 threads produces 64x16 outputs (four rows per
+// thread); the tile holds the inputs those need, zero outside the image (the fill value), and the
+// kernel values sit behind it.  Same j-then-k order per output, so the results are bit-identical to
+// k_flow_convolve; used when tile + kernel fit 64 KB.
+constexpr int CV_TW = 64, CV_TH = 16;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_flow_convolve_tiled(const float2 *__restrict__ flow, const T *__restrict__ kern, int kh, int kw,
+                      typename Pair<T>::type *__restrict__ out, int W, int H)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_cv[];
+    const int LW = CV_TW + kw - 1, LH = CV_TH + kh - 1;
+    float2 *tile = reinterpret_cast<float2 *>(s_cv);
+    T *sk = reinterpret_cast<T *>(s_cv + (((size_t)LW * LH * sizeof(float2) + 15) & ~(size_t)15));
+    const int x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
+    const int oy = (kh - 1) >> 1, ox = (kw - 1) >> 1;
+    // tile (ry, rx) <-> image (y0 + oy - (kh-1) + ry, x0 + ox - (kw-1) + rx)
+    const int ty0 = y0 + oy - (kh - 1), tx0 = x0 + ox - (kw - 1);
+    for (int idx = threadIdx.x; idx < LW * LH; idx += 256) {
+        const int ry = idx / LW, rx = idx - ry * LW;
+        const int y = ty0 + ry, x = tx0 + rx;
+        tile[idx] = (y >= 0 && y < H && x >= 0 && x < W) ? flow[(size_t)y * W + x] : make_float2(0.f, 0.f);
+    }
+    for (int idx = threadIdx.x; idx < kh * kw; idx += 256)
+        sk[idx] = kern[idx];
+    __syncthreads();
+    const int tx = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    T sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
+    for (int j = 0; j < kh; j++) {
+        for (int k = 0; k < kw; k++) {
+            const T hv = sk[j * kw + k];
+            const float2 *p = tile + (tq + (kh - 1) - j) * LW + tx + (kw - 1) - k;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float2 f = p[4 * q * LW];
+                sx[q] = sx[q] + hv * (T)f.x;
+                sy[q] = sy[q] + hv * (T)f.y;
+            }
+        }
+    }
+    const int x = x0 + tx;
+    if (x < W) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int y = y0 + tq + 4 * q;
+            if (y < H) {
+                typename Pair<T>::type r;
+                r.x = sx[q];
+                r.y = sy[q];
+                out[(size_t)y * W + x] = r;
+            }
+        }
+    }
+}
+
 template <typename T> __device__ __forceinline__ T clip_nan_t(T v, T lo, T hi)
 {
     return v != v ? v : (v < lo ? lo : (v > hi ? hi : v));
@@ -187,39 +244,72 @@ struct Colors {
 __device__ __forceinline__ float clip01(float v) { return clip_nan(v, 0.f, 1.f); }
 __device__ __forceinline__ uint8_t to_u8(float v) { return (uint8_t)(int)clip_nan(v, 0.f, 255.f); }
 
+// Four pixels per thread: their 12 output bytes leave as three dwords.
+__device__ __forceinline__ void store_rgb4(uint8_t *__restrict__ rgb, size_t t4, size_t N, const uint8_t (&px)[12])
+{
+    if (t4 + 4 <= N) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(rgb + t4 * 3); // t4 is a multiple of 4: 12-byte groups stay 4-aligned
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+            o[d] = px[4 * d] | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | ((uint32_t)px[4 * d + 3] << 24);
+    } else {
+        for (size_t i = 0; t4 + i < N; i++)
+            for (int c = 0; c < 3; c++)
+                rgb[(t4 + i) * 3 + c] = px[3 * i + c];
+    }
+}
+
 // output/render.py:9-27
 __global__ void k_render1d(const float *__restrict__ arr, uint8_t *__restrict__ rgb, size_t N, float scale, Colors col,
                            int binary)
 {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= N)
+    const size_t t4 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * 4;
+    if (t4 >= N)
         return;
-    const float sa = scale * arr[t];
-    float ka, kb;
-    if (binary) {
-        kb = clip01(rintf(sa));
-        ka = 1.f - kb;
+    uint8_t px[12];
+    float a4[4];
+    if (t4 + 4 <= N) {
+        const float4 v = *reinterpret_cast<const float4 *>(arr + t4);
+        a4[0] = v.x, a4[1] = v.y, a4[2] = v.z, a4[3] = v.w;
     } else {
-        ka = clip01(1.f - sa);
-        kb = clip01(sa);
+        for (int i = 0; i < 4; i++)
+            a4[i] = arr[min(t4 + i, N - 1)];
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-        rgb[t * 3 + c] = to_u8(ka * col.c[0][c] + kb * col.c[1][c]);
+    for (int i = 0; i < 4; i++) {
+        const float sa = scale * a4[i];
+        float ka, kb;
+        if (binary) {
+            kb = clip01(rintf(sa));
+            ka = 1.f - kb;
+        } else {
+            ka = clip01(1.f - sa);
+            kb = clip01(sa);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            px[3 * i + c] = to_u8(ka * col.c[0][c] + kb * col.c[1][c]);
+    }
+    store_rgb4(rgb, t4, N, px);
 }
 
 // output/render.py:30-48
 __global__ void k_render2d(const float2 *__restrict__ flow, uint8_t *__restrict__ rgb, size_t N, float scale, Colors col)
 {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= N)
+    const size_t t4 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * 4;
+    if (t4 >= N)
         return;
-    const float2 f = flow[t];
-    const float sx = scale * f.x, sy = scale * f.y;
-    const float ky = clip01(1.f + sx), kb = clip01(1.f - sx), km = clip01(1.f + sy), kg = clip01(1.f - sy);
+    uint8_t px[12];
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-        rgb[t * 3 + c] = to_u8(0.5f * (((ky * col.c[0][c] + kb * col.c[1][c]) + km * col.c[2][c]) + kg * col.c[3][c]));
+    for (int i = 0; i < 4; i++) {
+        const float2 f = flow[min(t4 + i, N - 1)];
+        const float sx = scale * f.x, sy = scale * f.y;
+        const float ky = clip01(1.f + sx), kb = clip01(1.f - sx), km = clip01(1.f + sy), kg = clip01(1.f - sy);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            px[3 * i + c] = to_u8(0.5f * (((ky * col.c[0][c] + kb * col.c[1][c]) + km * col.c[2][c]) + kg * col.c[3][c]));
+    }
+    store_rgb4(rgb, t4, N, px);
 }
 
 // cv2.cvtColor(frame, COLOR_BGR2GRAY) for 8-bit images (cv.py:463, 466): OpenCV 4.x fixed point with
@@ -238,6 +328,23 @@ __global__ void k_bgr_to_grey(const uint8_t *__restrict__ bgr, int Ws, int Hs, u
     const int sx = min((int)floor(x * fx), Ws - 1), sy = min((int)floor(y * fy), Hs - 1);
     const uint8_t *p = bgr + ((size_t)sy * Ws + sx) * 3;
     grey[t] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + 16384) >> 15);
+}
+
+// equal sizes: four pixels per thread, 12 bytes in as three dwords, one dword out
+__global__ void k_bgr_to_grey4(const uint32_t *__restrict__ bgr, uint32_t *__restrict__ grey, size_t n4)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n4)
+        return;
+    const uint32_t a = bgr[3 * t], b = bgr[3 * t + 1], c = bgr[3 * t + 2];
+    const uint8_t p[12] = {(uint8_t)a, (uint8_t)(a >> 8), (uint8_t)(a >> 16), (uint8_t)(a >> 24),
+                           (uint8_t)b, (uint8_t)(b >> 8), (uint8_t)(b >> 16), (uint8_t)(b >> 24),
+                           (uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        o |= (uint32_t)((p[3 * i] * 3735 + p[3 * i + 1] * 19235 + p[3 * i + 2] * 9798 + 16384) >> 15) << (8 * i);
+    grey[t] = o;
 }
 
 } // namespace
@@ -278,6 +385,17 @@ TF_API int tf_flow_convolve_dev(const void *flow_dev, const void *kernel_dev, in
     TF_REQUIRE((flow_dev && out_dev && kernel_dev) || (size_t)width * height == 0, "tf_flow_convolve: null pointer");
     TF_TRY(ensure_init());
     const size_t n = (size_t)width * height;
+    const size_t tile_bytes = (((size_t)(CV_TW + kw - 1) * (CV_TH + kh - 1) * sizeof(float2) + 15) & ~(size_t)15) +
+                              (size_t)kh * kw * (wide ? 8 : 4);
+    static const bool no_tiles = getenv("TF_CONV_NO_TILES") && atoi(getenv("TF_CONV_NO_TILES")) != 0;
+    if (tile_bytes <= 64 * 1024 && !no_tiles && n) {
+        dim3 grid(cdiv(width, CV_TW), cdiv(height, CV_TH));
+        if (wide)
+            return launch("flow_convolve_f64", k_flow_convolve_tiled<double>, grid, dim3(256), tile_bytes,
+                          (const float2 *)flow_dev, (const double *)kernel_dev, kh, kw, (double2 *)out_dev, width, height);
+        return launch("flow_convolve_f32", k_flow_convolve_tiled<float>, grid, dim3(256), tile_bytes,
+                      (const float2 *)flow_dev, (const float *)kernel_dev, kh, kw, (float2 *)out_dev, width, height);
+    }
     if (wide)
         return launch("flow_convolve_f64", k_flow_convolve<double>, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
                       (const float2 *)flow_dev, (const double *)kernel_dev, kh, kw, (double2 *)out_dev, width, height);
@@ -324,7 +442,7 @@ TF_API int tf_flow_render1d_dev(const void *arr_dev, void *rgb_dev, size_t n, fl
 {
     TF_REQUIRE(colors_rgb && ((arr_dev && rgb_dev) || n == 0), "tf_flow_render1d: null pointer");
     TF_TRY(ensure_init());
-    return launch("flow_render1d", k_render1d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const float *)arr_dev,
+    return launch("flow_render1d", k_render1d, dim3(cdiv((n + 3) / 4, BLOCK)), dim3(BLOCK), 0, (const float *)arr_dev,
                   (uint8_t *)rgb_dev, n, scale, make_colors(colors_rgb, 2), binary);
 }
 
@@ -332,7 +450,7 @@ TF_API int tf_flow_render2d_dev(const void *flow_dev, void *rgb_dev, size_t n, f
 {
     TF_REQUIRE(colors_rgb && ((flow_dev && rgb_dev) || n == 0), "tf_flow_render2d: null pointer");
     TF_TRY(ensure_init());
-    return launch("flow_render2d", k_render2d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const float2 *)flow_dev,
+    return launch("flow_render2d", k_render2d, dim3(cdiv((n + 3) / 4, BLOCK)), dim3(BLOCK), 0, (const float2 *)flow_dev,
                   (uint8_t *)rgb_dev, n, scale, make_colors(colors_rgb, 4));
 }
 
@@ -345,6 +463,10 @@ TF_API int tf_frame_grey_dev(const void *bgr_dev, int src_width, int src_height,
     // cv2.resize with dsize only: fx = dsize.width / src.cols; the nearest-neighbour source index is
     // floor(dst * (1 / fx))
     const double ifx = width ? 1.0 / ((double)width / src_width) : 1.0, ify = height ? 1.0 / ((double)height / src_height) : 1.0;
+    if (width == src_width && height == src_height && (n & 3) == 0 && ((uintptr_t)bgr_dev & 3) == 0 &&
+        ((uintptr_t)grey_dev & 3) == 0)
+        return launch("frame_grey", k_bgr_to_grey4, dim3(cdiv(n / 4, BLOCK)), dim3(BLOCK), 0, (const uint32_t *)bgr_dev,
+                      (uint32_t *)grey_dev, n / 4);
     return launch("frame_grey", k_bgr_to_grey, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const uint8_t *)bgr_dev, src_width,
                   src_height, (uint8_t *)grey_dev, width, height, ifx, ify);
 }
