@@ -158,6 +158,22 @@ int tf_flow_convolve_dev(const void *flow_dev, const void *kernel_dev, int kh, i
    on in the convolution's type).  FORWARD needs scratch_dev: 4 bytes per pixel. */
 int tf_flow_post_process_dev(void *flow_dev, int wide, int width, int height, int direction, void *scratch_dev);
 
+/* The `polar` flow filter, transflow/flow/filters.py:75-87, in place on a float32 flow: r = |v|,
+   a = atan2(vy, vx), then v = (R cos A, R sin A) with R and A the filter's two user expressions of
+   (t, r, a).  The expressions arrive as postfix programs (transflow_amd/exprs.py compiles them; parts
+   that are not arrays are evaluated on the host per frame and arrive as constants); a step computes in
+   float32 unless `wide`, as numpy types the same expression.  wide_trig: sin/cos of A in float64;
+   wide_product: the products in float64 (then cast to the float32 flow). */
+typedef struct tf_polar_step {
+    int op;      /* enum PolarOp of flowops.hip == index into transflow_amd/exprs.py OPS */
+    int wide;
+    double imm;  /* push_const only */
+} tf_polar_step;
+#define TF_MAX_POLAR_STEPS 48
+#define TF_MAX_POLAR_STACK 12
+int tf_flow_polar_dev(void *flow_dev, size_t n_pixels, int n_radius, const tf_polar_step *radius, int n_theta,
+                      const tf_polar_step *theta, int wide_trig, int wide_product);
+
 /* Flow visualisation, transflow/output/render.py:9-27 and :30-48: arr float32 [n] / flow float32
    [n][2] -> rgb uint8 [n][3].  colors_rgb: 2 (render1d) or 4 (render2d) colours as float triples. */
 int tf_flow_render1d_dev(const void *arr_dev, void *rgb_dev, size_t n, float scale, const float colors_rgb[6], int binary);

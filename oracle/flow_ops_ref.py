@@ -146,3 +146,22 @@ def render2d(arr: np.ndarray, scale=1, colors=("#ffff00", "#0000ff", "#ff00ff", 
     k_g = np.clip(one - s * a[:, :, 1], 0, 1)[..., None]
     frame = np.float32(0.5) * (((k_y * cy + k_b * cb) + k_m * cm) + k_g * cg)   # :43-47, left to right
     return np.clip(frame, 0, 255).astype(np.uint8)
+
+
+def polar(flow: np.ndarray, expr_radius: str, expr_theta: str, t: float) -> np.ndarray:
+    """PolarFlowFilter.apply, flow/filters.py:81-88, in place: the two user expressions are evaluated by
+    Python on numpy arrays exactly as the reference does (utils.parse_lambda_expression, utils.py:409-414;
+    `math`, `numpy`, `random`, `re`, `os` in scope)."""
+    import math
+    import os
+    import random
+    import re
+    scope = {"math": math, "numpy": np, "random": random, "re": re, "os": os}
+    h, w, _ = flow.shape
+    radius = np.sqrt(flow[:, :, 0] * flow[:, :, 0] + flow[:, :, 1] * flow[:, :, 1])   # :83, float32 pair norm
+    theta = np.arctan2(flow[:, :, 1], flow[:, :, 0])                                  # :84
+    new_radius = eval("lambda t, r, a: " + expr_radius, scope)(t, radius, theta)
+    new_theta = eval("lambda t, r, a: " + expr_theta, scope)(t, radius, theta)
+    flow[:, :, 1] = new_radius * np.sin(new_theta)                                    # :87
+    flow[:, :, 0] = new_radius * np.cos(new_theta)                                    # :88
+    return flow

@@ -141,3 +141,44 @@ def test_convolution_tiled_and_fallback_vs_oracle(shape, kshape, dtype):
     exp = np.stack([F.convolve_same(flow[:, :, 0], kernel), F.convolve_same(flow[:, :, 1], kernel)], axis=-1)
     assert out.dtype == exp.dtype == dtype
     np.testing.assert_array_equal(out, exp)
+
+
+ZP = np.load(os.path.join(GOLDEN, "flow_polar.npz"))
+
+
+def _close(out, exp):
+    """Device sin/cos/atan2/sqrt/pow differ from numpy's by a few ulp; the flow tolerance of the path
+    is 1e-4 relative (BASELINE north_star): ask for 20x better."""
+    scale = max(1.0, float(np.nanmax(np.abs(exp))))
+    assert np.isnan(out).sum() == np.isnan(exp).sum()
+    np.testing.assert_allclose(np.nan_to_num(out), np.nan_to_num(exp), rtol=0, atol=5e-6 * scale)
+
+
+@pytest.mark.parametrize("i", range(int(ZP["cases"])))
+def test_polar_filter_golden_gpu(i):
+    from transflow_amd.exprs import PolarFilter
+    from transflow_amd.flowops import polar_filter
+    flow = ZP[f"in_{i}"].copy()
+    out = polar_filter(flow, PolarFilter(str(ZP[f"er_{i}"]), str(ZP[f"ea_{i}"])), float(ZP["t"]))
+    assert out is flow
+    _close(out, ZP[f"out_{i}"])
+
+
+def test_polar_inside_post_process_chain():
+    """scale -> polar -> clip -> BACKWARD clip, as the reference chained them (source.py:339-341)."""
+    from transflow_amd.flow import FlowFilter, FlowSource
+    src = FlowSource("backward", 34, 21, 30.0, 100, 0, 0, 100,
+                     flow_filters=[FlowFilter.from_string("scale=1.5"), FlowFilter.from_string("polar=r+1:a*2"),
+                                   FlowFilter.from_string("clip=4")])
+    src.output_frame_index = 21
+    out = src.post_process(ZP["chain_in"].copy())
+    _close(out, ZP["chain_out"])
+    src.close()
+
+
+def test_polar_full_size_vs_oracle():
+    from transflow_amd.exprs import PolarFilter
+    from transflow_amd.flowops import polar_filter
+    flow = np.random.default_rng(13).normal(0, 3, (1080, 1920, 2)).astype(np.float32)
+    exp = F.polar(flow.copy(), "numpy.sqrt(r)*(1+t)", "a+numpy.sin(r)", 0.25)
+    _close(polar_filter(flow, PolarFilter("numpy.sqrt(r)*(1+t)", "a+numpy.sin(r)"), 0.25), exp)

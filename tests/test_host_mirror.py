@@ -97,8 +97,13 @@ def test_builder_timing_arithmetic(tmp_path):
     b = _builder(flow_filters="scale=2*t; threshold = 0.5")
     b.build()
     assert [f.name for f in b.flow_filters] == ["scale", "threshold"] and b.flow_filters[0].expr(1.5) == 3.0
+    b = _builder(flow_filters="polar=r*2:a+t")
+    b.build()
+    assert b.flow_filters[0].name == "polar" and not b.flow_filters[0].polar.radius.scalar_only
     with pytest.raises(NotImplementedError):
-        _builder(flow_filters="polar=r:a").build()
+        _builder(flow_filters="polar=r.cumsum():a").build()              # not expressible per pixel
+    with pytest.raises(ValueError):
+        _builder(flow_filters="polar=r").build()                          # filters.py:29-30
     with pytest.raises(ValueError):
         _builder(flow_filters="blur=3").build()
 

@@ -367,6 +367,38 @@ def capture_flow_ops():
     print("flow ops:", int(d["merge_cases"]), "merges,", int(d["conv_cases"]), "convolutions")
 
 
+POLAR_CASES = [
+    ("r", "a"), ("r*2", "a+t"), ("numpy.sqrt(r)+1", "-a"), ("numpy.where(r>2, r, 0)", "a"), ("r", "t"), ("3", "a"),
+    ("r**2/10", "numpy.float64(0.5)*a"), ("numpy.minimum(r, 3)", "a + math.pi/4"),
+    ("numpy.clip(r,1,4)*numpy.cos(a)", "numpy.arctan2(numpy.sin(a), numpy.cos(a)*2)"), ("r % 1.5", "a // 0.5 * 0.5"),
+    ("abs(r-2)**0.5", "numpy.maximum(a, -1) * (t + 1)"), ("2*t", "math.pi*t"),
+]
+
+
+def capture_polar():
+    """The polar flow filter (filters.py:75-87) applied by the reference; t = 0.7."""
+    from transflow.flow.filters import FlowFilter as RefFilter
+    rng = np.random.default_rng(505)
+    d = {"cases": np.int32(len(POLAR_CASES)), "t": np.float64(0.7)}
+    for i, (er, ea) in enumerate(POLAR_CASES):
+        flow = rng.normal(0, 2.5, (21, 34, 2)).astype(np.float32)
+        flow[0, 0] = 0
+        d[f"in_{i}"] = flow.copy()
+        RefFilter.from_args("polar", (er, ea)).apply(flow, 0.7)
+        d[f"out_{i}"] = flow
+        d[f"er_{i}"], d[f"ea_{i}"] = np.array(er), np.array(ea)
+    # through post_process, between two other filters
+    fs = make_fs(FlowSource.Direction.BACKWARD, 21, 34)
+    fs.flow_filters = [RefFilter.from_args("scale", ("1.5",)), RefFilter.from_args("polar", ("r+1", "a*2")),
+                       RefFilter.from_args("clip", ("4",))]
+    fs.output_frame_index = 21          # t = 21 / 30
+    raw = rng.normal(0, 2.5, (21, 34, 2)).astype(np.float32)
+    d["chain_in"] = raw.copy()
+    d["chain_out"] = np.asarray(fs.post_process(raw))
+    np.savez_compressed(os.path.join(OUT, "flow_polar.npz"), **d)
+    print("polar cases:", len(POLAR_CASES))
+
+
 def capture_known_answers():
     """tests/test_compositor.py:20-54 re-run, outputs stored."""
     d = {}
@@ -473,6 +505,9 @@ def capture_flow_presteps():
 
 
 if __name__ == "__main__":
+    if "--polar-only" in sys.argv:
+        capture_polar()
+        sys.exit(0)
     if "--flowops-only" in sys.argv:
         capture_flow_ops()
         sys.exit(0)
@@ -492,5 +527,6 @@ if __name__ == "__main__":
     capture_multilayer()
     capture_other_layers()
     capture_flow_ops()
+    capture_polar()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", total)

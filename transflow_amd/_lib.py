@@ -28,6 +28,10 @@ class TfFbParams(C.Structure):
                 ("flags", C.c_int)]
 
 
+class TfPolarStep(C.Structure):
+    _fields_ = [("op", C.c_int), ("wide", C.c_int), ("imm", C.c_double)]
+
+
 class TfFlowOp(C.Structure):
     _fields_ = [("kind", C.c_int), ("wide", C.c_int), ("value", C.c_double)]
 
@@ -101,6 +105,7 @@ PROTOTYPES = {
     "tf_flow_upscale_dev": (_I, [_P, _P, _I, _I, _I, _I]),
     "tf_flow_convolve_dev": (_I, [_P, _P, _I, _I, _I, _P, _I, _I]),
     "tf_flow_post_process_dev": (_I, [_P, _I, _I, _I, _I, _P]),
+    "tf_flow_polar_dev": (_I, [_P, C.c_size_t, _I, _P, _I, _P, _I, _I]),
     "tf_flow_render1d_dev": (_I, [_P, _P, C.c_size_t, C.c_float, C.POINTER(C.c_float), _I]),
     "tf_flow_render2d_dev": (_I, [_P, _P, C.c_size_t, C.c_float, C.POINTER(C.c_float)]),
     "tf_frame_grey_dev": (_I, [_P, _I, _I, _P, _I, _I]),

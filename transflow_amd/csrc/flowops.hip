@@ -347,6 +347,155 @@ __global__ void k_bgr_to_grey4(const uint32_t *__restrict__ bgr, uint32_t *__res
     grey[t] = o;
 }
 
+
+// ---------------------------------------------------------------------------------
+// The `polar` flow filter (transflow/flow/filters.py:75-87): radius and angle of every vector,
+// two user expressions of (t, r, a) compiled to postfix programs by transflow_amd/exprs.py (the
+// parts that are not arrays are evaluated on the host and arrive as constants), then
+// flow = (R cos A, R sin A).  A step computes in float32 unless its `wide` flag says float64, which
+// is how numpy types the same expression; values ride on a stack of doubles (every float is one).
+// ---------------------------------------------------------------------------------
+enum PolarOp { P_PUSH_R, P_PUSH_A, P_PUSH_CONST, P_ADD, P_SUB, P_MUL, P_DIV, P_POW, P_MOD, P_FLOORDIV, P_NEG, P_SIN, P_COS,
+               P_TAN, P_ASIN, P_ACOS, P_ATAN, P_ATAN2, P_SQRT, P_ABS, P_EXP, P_LOG, P_LOG2, P_LOG10, P_MIN, P_MAX,
+               P_FLOOR, P_CEIL, P_RINT, P_SIGN, P_SQUARE, P_HYPOT, P_LT, P_LE, P_GT, P_GE, P_EQ, P_NE, P_WHERE, P_CLIP,
+               P_RECIP, P_NOT, P_COUNT };
+
+struct PolarProg {
+    int n;
+    unsigned char op[TF_MAX_POLAR_STEPS];
+    unsigned char wide[TF_MAX_POLAR_STEPS];
+    double imm[TF_MAX_POLAR_STEPS];
+};
+
+template <typename T> __device__ __forceinline__ T pmod(T a, T b)
+{ // numpy.mod: the result takes the divisor's sign
+    T r = sizeof(T) == 4 ? (T)fmodf((float)a, (float)b) : (T)fmod((double)a, (double)b);
+    if (r != 0 && ((r < 0) != (b < 0)))
+        r += b;
+    return r;
+}
+
+template <typename T> __device__ __forceinline__ T pnanmin(T a, T b) { return (a != a || b != b) ? (a != a ? a : b) : (a < b ? a : b); }
+template <typename T> __device__ __forceinline__ T pnanmax(T a, T b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); }
+
+template <typename T> __device__ __forceinline__ double polar_unary(int op, T x)
+{
+    const bool f = sizeof(T) == 4;
+    switch (op) {
+    case P_NEG: return -x;
+    case P_SIN: return f ? sinf(x) : sin((double)x);
+    case P_COS: return f ? cosf(x) : cos((double)x);
+    case P_TAN: return f ? tanf(x) : tan((double)x);
+    case P_ASIN: return f ? asinf(x) : asin((double)x);
+    case P_ACOS: return f ? acosf(x) : acos((double)x);
+    case P_ATAN: return f ? atanf(x) : atan((double)x);
+    case P_SQRT: return f ? sqrtf(x) : sqrt((double)x);
+    case P_ABS: return f ? fabsf(x) : fabs((double)x);
+    case P_EXP: return f ? expf(x) : exp((double)x);
+    case P_LOG: return f ? logf(x) : log((double)x);
+    case P_LOG2: return f ? log2f(x) : log2((double)x);
+    case P_LOG10: return f ? log10f(x) : log10((double)x);
+    case P_FLOOR: return f ? floorf(x) : floor((double)x);
+    case P_CEIL: return f ? ceilf(x) : ceil((double)x);
+    case P_RINT: return f ? rintf(x) : rint((double)x);
+    case P_SIGN: return x != x ? x : (T)((x > 0) - (x < 0));
+    case P_SQUARE: return x * x;
+    case P_RECIP: return (T)1 / x;
+    default: return x;
+    }
+}
+
+template <typename T> __device__ __forceinline__ double polar_binary(int op, T a, T b)
+{
+    const bool f = sizeof(T) == 4;
+    switch (op) {
+    case P_ADD: return a + b;
+    case P_SUB: return a - b;
+    case P_MUL: return a * b;
+    case P_DIV: return a / b;
+    case P_POW: return f ? powf(a, b) : pow((double)a, (double)b);
+    case P_MOD: return pmod<T>(a, b);
+    case P_FLOORDIV: return f ? floorf(a / b) : floor((double)a / (double)b);
+    case P_ATAN2: return f ? atan2f(a, b) : atan2((double)a, (double)b);
+    case P_MIN: return pnanmin<T>(a, b);
+    case P_MAX: return pnanmax<T>(a, b);
+    case P_HYPOT: return f ? hypotf(a, b) : hypot((double)a, (double)b);
+    case P_LT: return a < b;
+    case P_LE: return a <= b;
+    case P_GT: return a > b;
+    case P_GE: return a >= b;
+    case P_EQ: return a == b;
+    case P_NE: return a != b;
+    default: return a;
+    }
+}
+
+__device__ double polar_eval(const PolarProg &p, float r, float a)
+{
+    double st[TF_MAX_POLAR_STACK];
+    int sp = 0;
+    for (int i = 0; i < p.n; i++) {
+        const int op = p.op[i];
+        const bool wide = p.wide[i] != 0;
+        if (op == P_PUSH_R) {
+            st[sp++] = r;
+        } else if (op == P_PUSH_A) {
+            st[sp++] = a;
+        } else if (op == P_PUSH_CONST) {
+            st[sp++] = p.imm[i];
+        } else if (op == P_WHERE) {
+            const double y = st[--sp], x = st[--sp], c = st[--sp];
+            const double v = c != 0 ? x : y;
+            st[sp++] = wide ? v : (double)(float)v;
+        } else if (op == P_CLIP) {
+            const double hi = st[--sp], lo = st[--sp], x = st[--sp];
+            st[sp++] = wide ? pnanmin<double>(pnanmax<double>(x, lo), hi)
+                            : (double)pnanmin<float>(pnanmax<float>((float)x, (float)lo), (float)hi);
+        } else if (op == P_NOT) {
+            st[sp - 1] = st[sp - 1] == 0;
+        } else if (op == P_ADD || op == P_SUB || op == P_MUL || op == P_DIV || op == P_POW || op == P_MOD ||
+                   op == P_FLOORDIV || op == P_ATAN2 || op == P_MIN || op == P_MAX || op == P_HYPOT ||
+                   (op >= P_LT && op <= P_NE)) {
+            const double b = st[--sp], x = st[--sp];
+            st[sp++] = wide ? polar_binary<double>(op, x, b) : polar_binary<float>(op, (float)x, (float)b);
+        } else {
+            const double x = st[sp - 1];
+            st[sp - 1] = wide ? polar_unary<double>(op, x) : polar_unary<float>(op, (float)x);
+        }
+    }
+    return st[0];
+}
+
+// wide_out: bit 0 = sin/cos in float64 (the angle expression is float64 or a bare Python scalar: numpy.sin of
+// one is a float64), bit 1 = the product in float64
+__global__ void k_pp_polar(float2 *__restrict__ flow, size_t N, PolarProg pr, PolarProg pa, int wide_out)
+{
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N)
+        return;
+    const float2 f = flow[t];
+    const float r = sqrtf(f.x * f.x + f.y * f.y); // numpy.linalg.norm of a float32 pair (filters.py:83)
+    const float a = atan2f(f.y, f.x);              // :84
+    const double R = polar_eval(pr, r, a), A = polar_eval(pa, r, a);
+    double s, c;
+    if (wide_out & 1) {
+        s = sin(A);
+        c = cos(A);
+    } else {
+        s = sinf((float)A);
+        c = cosf((float)A);
+    }
+    float2 o;
+    if (wide_out & 2) {
+        o.y = (float)(R * s); // :87 then :88
+        o.x = (float)(R * c);
+    } else {
+        o.y = (float)R * (float)s;
+        o.x = (float)R * (float)c;
+    }
+    flow[t] = o;
+}
+
 } // namespace
 
 TF_API int tf_flow_merge_dev(int kind, int n, const void *const *flows_dev, void *out_dev, size_t n_values)
@@ -469,4 +618,47 @@ TF_API int tf_frame_grey_dev(const void *bgr_dev, int src_width, int src_height,
                       (uint32_t *)grey_dev, n / 4);
     return launch("frame_grey", k_bgr_to_grey, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, (const uint8_t *)bgr_dev, src_width,
                   src_height, (uint8_t *)grey_dev, width, height, ifx, ify);
+}
+
+static int load_prog(PolarProg &p, int n, const tf_polar_step *steps, const char *what)
+{
+    TF_REQUIRE(n >= 1 && n <= TF_MAX_POLAR_STEPS && steps, "tf_flow_polar: %s program has %d steps (1..%d)", what, n,
+               TF_MAX_POLAR_STEPS);
+    memset(&p, 0, sizeof(p));
+    p.n = n;
+    int depth = 0;
+    for (int i = 0; i < n; i++) {
+        const int op = steps[i].op;
+        TF_REQUIRE(op >= 0 && op < P_COUNT, "tf_flow_polar: %s step %d: unknown opcode %d", what, i, op);
+        int pops = 1, pushes = 1;
+        if (op == P_PUSH_R || op == P_PUSH_A || op == P_PUSH_CONST)
+            pops = 0;
+        else if (op == P_WHERE || op == P_CLIP)
+            pops = 3;
+        else if (op == P_ADD || op == P_SUB || op == P_MUL || op == P_DIV || op == P_POW || op == P_MOD ||
+                 op == P_FLOORDIV || op == P_ATAN2 || op == P_MIN || op == P_MAX || op == P_HYPOT ||
+                 (op >= P_LT && op <= P_NE))
+            pops = 2;
+        TF_REQUIRE(depth >= pops, "tf_flow_polar: %s step %d pops an empty stack", what, i);
+        depth += pushes - pops;
+        TF_REQUIRE(depth <= TF_MAX_POLAR_STACK, "tf_flow_polar: %s program needs more than %d stack slots", what,
+                   TF_MAX_POLAR_STACK);
+        p.op[i] = (unsigned char)op;
+        p.wide[i] = steps[i].wide != 0;
+        p.imm[i] = steps[i].imm;
+    }
+    TF_REQUIRE(depth == 1, "tf_flow_polar: %s program leaves %d values", what, depth);
+    return TF_OK;
+}
+
+TF_API int tf_flow_polar_dev(void *flow_dev, size_t n_pixels, int n_radius, const tf_polar_step *radius, int n_theta,
+                             const tf_polar_step *theta, int wide_trig, int wide_product)
+{
+    TF_REQUIRE(flow_dev || n_pixels == 0, "tf_flow_polar: null pointer");
+    PolarProg pr, pa;
+    TF_TRY(load_prog(pr, n_radius, radius, "radius"));
+    TF_TRY(load_prog(pa, n_theta, theta, "theta"));
+    TF_TRY(ensure_init());
+    return launch("flow_polar", k_pp_polar, dim3(cdiv(n_pixels, BLOCK)), dim3(BLOCK), 0, (float2 *)flow_dev, n_pixels, pr,
+                  pa, (wide_trig ? 1 : 0) | (wide_product ? 2 : 0));
 }

@@ -9,9 +9,10 @@
 (transflow/pipeline.py:325 FlowSource.from_args, :445 Compositor.from_args) with
 dispatchers that build HipFlowSource / HipCompositor when the request is one this
 backend serves -- a video path (or webcam index) with the Farnebäck method (flow mask and the
-scale/threshold/clip filters and the convolution kernel included; no polar filter), layers of
+scale/threshold/clip filters, the convolution kernel and per-pixel polar expressions included), layers of
 any of the reference's classes (`moveref`, `sum`, `static`, `introduction`) -- and fall through to
-the reference's own factory otherwise (motion vectors, other flow methods, the polar filter).
+the reference's own factory otherwise (motion vectors, other flow methods, polar expressions that are
+not per-pixel formulas).
 `.flow.zip` archives are served too (their flows are post-processed on the GPU).
 INTEGRATION.md shows the three-line patch a maintainer would add instead.
 """
@@ -29,9 +30,14 @@ def _flow_from_args(original):
     def from_args(cls, flow_path, use_mvs=False, mask_path=None, kernel_path=None, cv_config=None,
                   flow_filters=None, size=None, direction=None, seek_ckpt=None, seek_time=None,
                   duration_time=None, repeat=1, lock_expr=None, lock_mode="stay"):
-        served = (isinstance(flow_path, str) and not use_mvs
-                  and (flow_filters is None or "polar" not in flow_filters)
-                  and cv_config != "window")
+        served = isinstance(flow_path, str) and not use_mvs and cv_config != "window"
+        if served and flow_filters is not None and "polar" in flow_filters:
+            try:                                   # polar expressions the device cannot run stay the reference's
+                from .flow import FlowFilter
+                for part in flow_filters.strip().split(";"):
+                    FlowFilter.from_string(part)
+            except NotImplementedError:
+                served = False
         if served and cv_config is not None and os.path.isfile(cv_config):
             try:
                 FlowConfig.from_file(cv_config)

@@ -26,20 +26,26 @@ logger = logging.getLogger(__name__)
 
 
 class FlowFilter:
-    """A flow filter of the reference (transflow/flow/filters.py): `name=expr` where expr is a
-    Python expression of t evaluated on the host for every frame; the arithmetic on the flow runs
-    on the GPU.  `polar` (array-valued user expressions) is not available on the device."""
+    """A flow filter of the reference (transflow/flow/filters.py): `name=expr`.  scale / threshold /
+    clip: expr is a Python expression of t evaluated on the host for every frame, the arithmetic on
+    the flow runs on the GPU.  polar: `polar=expr_radius:expr_theta`, expressions of (t, r, a)
+    compiled for the device (transflow_amd/exprs.py)."""
 
-    NAMES = ("scale", "threshold", "clip")
+    NAMES = ("scale", "threshold", "clip", "polar")
 
     def __init__(self, name: str, expr_string: str):
-        if name == "polar":
-            raise NotImplementedError("the 'polar' flow filter evaluates user expressions on arrays; "
-                                      "transflow_amd has no device form of it")
         if name not in self.NAMES:
             raise ValueError(f"Unknown filter name '{name}'")                     # filters.py:33
         self.name = name
         self.expr_string = expr_string
+        if name == "polar":
+            from .exprs import PolarFilter
+            parts = expr_string.split(":")
+            if len(parts) != 2:
+                raise ValueError(f"Invalid number of arguments: {name} {tuple(parts)}")   # filters.py:29-30
+            self.polar = PolarFilter(parts[0], parts[1])
+            self.expr = None
+            return
         import math
         import random
         import re
@@ -307,6 +313,26 @@ class FlowSource:
         if self._pp is None:
             from .farneback import Farneback
             self._pp = Farneback(self.width, self.height, levels=0)
+        if any(f.name == "polar" for f in self.flow_filters):
+            # filters apply in order (source.py:339-341): runs of scale/threshold/clip go to the device as
+            # one launch each, every polar filter as its own; the rest of post_process follows unfiltered
+            from .flowops import polar_filter
+            run = []
+            for f in list(self.flow_filters) + [None]:
+                if f is not None and f.name != "polar":
+                    run.append((f.name, f.expr(self.t)))
+                    continue
+                if run:
+                    self._pp.post_process_host_ex(flow, None, run)
+                    run = []
+                if f is not None:
+                    polar_filter(flow, f.polar, self.t)
+            filters, self.flow_filters = self.flow_filters, []
+            try:
+                out = self.post_process(flow)
+            finally:
+                self.flow_filters = filters
+            return out
         ops = [(f.name, f.expr(self.t)) for f in self.flow_filters]   # filters.py: lambdas of t, host side
         if self.kernel is not None:
             # source.py:339-348: filters in place, mask multiply into a new array, then the convolution

@@ -101,6 +101,25 @@ def convolve_post_process(flow, kernel, direction: int | None) -> np.ndarray:
     return res
 
 
+def polar_filter(flow, polar, t: float) -> np.ndarray:
+    """PolarFlowFilter.apply (filters.py:81-88), in place on a C-contiguous float32 flow; `polar` is a
+    transflow_amd.exprs.PolarFilter."""
+    from ._lib import TfPolarStep
+    if not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.flags.c_contiguous
+            and flow.ndim == 3 and flow.shape[2] == 2):
+        raise ValueError("the polar filter works in place on a C-contiguous float32 (H, W, 2) array")
+    sr, st, wide_trig, wide_product = polar.programs(t)
+    ar = (TfPolarStep * len(sr))(*[TfPolarStep(o, w, v) for o, w, v in sr])
+    at = (TfPolarStep * len(st))(*[TfPolarStep(o, w, v) for o, w, v in st])
+    lib = _lib.load()
+    buf = DevBuffer.from_array(flow)
+    check(lib.tf_flow_polar_dev(C.c_void_p(buf.ptr), flow.shape[0] * flow.shape[1], len(sr), ar, len(st), at,
+                                int(wide_trig), int(wide_product)))
+    flow[...] = buf.download(flow.shape, np.float32)
+    buf.close()
+    return flow
+
+
 def _colors(colors, n):
     arr = np.array([parse_color(c) for c in colors], dtype=np.float32)   # render.py:17 / :37
     if arr.shape != (n, 3):
