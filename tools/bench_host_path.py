@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""The drop-in (host-array) path end to end: what a transflow pipeline sees per frame when flows and
+frames cross PCIe as numpy arrays -- HipFlowSource.next + post_process, HipCompositor.update + render.
+This is the PCIe-inclusive rate DESIGN.md section 5 quotes; it is never bench.py's `value`.
+Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from transflow_amd.compositor import HipCompositor  # noqa: E402
+from transflow_amd.config import LayerConfig  # noqa: E402
+from transflow_amd.flow import ArrayFrameProvider, HipFlowSource  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "1080p"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+w, h = {"1080p": (1920, 1080), "4k": (3840, 2160)}[name]
+frames = bench.synth_frames(h, w, n + 1, 2000)
+pix = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+class Src:
+    introduction_mask = np.ones((h, w), bool)
+
+    def next(self, timeout=1):
+        return pix
+
+
+comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
+comp.set_sources({0: [Src()]})
+t_flow = t_comp = 0.0
+with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backward") as source:
+    it = iter(source)
+    flow = next(it)                      # warm-up: handle creation, first launches
+    comp.update(flow)
+    comp.render()
+    k = 0
+    while True:
+        t0 = time.perf_counter()
+        try:
+            flow = next(it)
+        except StopIteration:
+            break
+        t1 = time.perf_counter()
+        comp.update(flow)
+        img = comp.render()
+        t2 = time.perf_counter()
+        t_flow += t1 - t0
+        t_comp += t2 - t1
+        k += 1
+print(f"{name}: {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
+      f"{k / (t_flow + t_comp):.1f} frames/s end to end through host arrays (one process)")
