@@ -1740,6 +1740,8 @@ struct tf_fb {
     int2 *pairs_host = nullptr;                // pinned staging of the slot pairs
     hipEvent_t pairs_copied = nullptr;
     bool pairs_pending = false;
+    hipEvent_t fine_start = nullptr;           // the previous call's chain has reached its full-resolution level
+    bool fine_pending = false;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
     // A3+A4 as one kernel per iteration (k_flow_iter1: M never stored).  Correct (same parity tests) and
@@ -1760,6 +1762,8 @@ struct tf_fb {
                 (void)hipEventDestroy(e);
         if (pairs_copied)
             (void)hipEventDestroy(pairs_copied);
+        if (fine_start)
+            (void)hipEventDestroy(fine_start);
         if (pairs_host)
             (void)hipHostFree(pairs_host);
         if (prep_stream)
@@ -2123,6 +2127,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
     if (hipEventCreateWithFlags(&fb->chain_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->chain_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->pairs_copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&fb->fine_start, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&fb->pairs_host, P * sizeof(int2), hipHostMallocDefault) != hipSuccess ||
         hipStreamCreateWithPriority(&fb->prep_stream, hipStreamNonBlocking, least) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "creating the preparation stream failed"));
@@ -2198,6 +2203,12 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         // frame in place; a caller writing frames on the device orders that itself (tfhip.h).
         if (overlap && fb->chain_pending[set])
             TF_HIP(hipStreamWaitEvent(ps, fb->chain_done[set], 0));
+        // ... and this call's expansion starts when the previous call's chain enters its full-resolution
+        // level: the coarse levels' small launches are not starved by the expansion's big grids, and
+        // the expansion (VALU-bound) then hides under the longest HBM-bound stretch of the chain
+        static const bool defer = !(getenv("TF_FB_NO_DEFER") && atoi(getenv("TF_FB_NO_DEFER")) != 0);
+        if (overlap && defer && fb->fine_pending)
+            TF_HIP(hipStreamWaitEvent(ps, fb->fine_start, 0));
         TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, ps));
         TF_HIP(hipEventRecord(fb->pairs_copied, ps));
         fb->pairs_pending = true;
@@ -2219,6 +2230,10 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         Level &L = *fb->lv[k];
         if (overlap)
             TF_HIP(hipStreamWaitEvent(main_stream(), L.ready, 0));
+        if (overlap && k == 0) {
+            TF_HIP(hipEventRecord(fb->fine_start, main_stream()));
+            fb->fine_pending = true;
+        }
         FlowInit fi;
         memset(&fi, 0, sizeof(fi));
         if (k < fb->K) {
