@@ -1952,9 +1952,13 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
     const unsigned strips = cdiv(w, OUTC);
-    // ~16 waves per CU in flight; each segment re-sums its first window (2M+1 rows)
-    long segs_wanted = std::max(1l, 4096 / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(256, std::max<long>(8, (h + segs_wanted - 1) / segs_wanted));
+    // each segment re-sums its first window (2M+1 rows), so segments should be tall; but the launch
+    // should hold a few waves per resident slot (12 per CU) or its tail runs on a half-empty chip
+    // (measured at 4K x 16: 4096 / 8192 / 12288 / 16384 waves -> 5.03 / 4.92 / 4.88 / 4.86 ms for all levels)
+    static const long waves_wanted = getenv("TF_BLUR_WAVES") ? atol(getenv("TF_BLUR_WAVES")) : 12288;
+    const long seg_min = 8;
+    long segs_wanted = std::max(1l, waves_wanted / std::max(1l, (long)strips * n_pairs));
+    int seg = (int)std::min<long>(256, std::max<long>(seg_min, (h + segs_wanted - 1) / segs_wanted));
     if (getenv("TF_BLUR_SEG"))
         seg = std::max(8, atoi(getenv("TF_BLUR_SEG")));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
