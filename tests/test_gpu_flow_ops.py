@@ -182,3 +182,69 @@ def test_polar_full_size_vs_oracle():
     flow = np.random.default_rng(13).normal(0, 3, (1080, 1920, 2)).astype(np.float32)
     exp = F.polar(flow.copy(), "numpy.sqrt(r)*(1+t)", "a+numpy.sin(r)", 0.25)
     _close(polar_filter(flow, PolarFilter("numpy.sqrt(r)*(1+t)", "a+numpy.sin(r)"), 0.25), exp)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (9, 1), (3, 5), (0, 4)])
+def test_tiny_and_empty_inputs(shape):
+    """One pixel, one row, one column, and the empty frame through every flow-array entry point."""
+    from transflow_amd.exprs import PolarFilter
+    from transflow_amd.flowops import (bgr_to_grey, convolve_post_process, merge_flows, polar_filter, render1d,
+                                       render2d, upscale_array)
+    h, w = shape
+    rng = np.random.default_rng(14)
+    f0 = rng.normal(0, 2, (h, w, 2)).astype(np.float32)
+    f1 = rng.normal(0, 2, (h, w, 2)).astype(np.float32)
+    np.testing.assert_array_equal(merge_flows("difference", [f0, f1]), F.merge("difference", [f0, f1]))
+    np.testing.assert_array_equal(merge_flows("absmax", [f0, f1]), F.merge("absmax", [f0, f1]))
+    np.testing.assert_array_equal(upscale_array(f0, 3, 2), F.upscale(f0, 3, 2))
+    np.testing.assert_array_equal(render2d(f0, 0.4), F.render2d(f0, 0.4))
+    np.testing.assert_array_equal(render1d(np.abs(f0[:, :, 0]), 0.4), F.render1d(np.abs(f0[:, :, 0]), 0.4))
+    if h * w:
+        k = rng.normal(0, 0.4, (3, 2))
+        for d in (0, 1):
+            np.testing.assert_array_equal(convolve_post_process(f0, k, d), F.post_process_with_kernel(f0, k, d))
+        exp = F.polar(f0.copy(), "r+1", "a*2", 0.0)
+        np.testing.assert_allclose(polar_filter(f0.copy(), PolarFilter("r+1", "a*2"), 0.0), exp, rtol=0, atol=2e-5)
+        frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(bgr_to_grey(frame), frames_ref.bgr_to_grey(frame))
+        np.testing.assert_array_equal(bgr_to_grey(frame, (2 * w + 1, h + 2)), frames_ref.bgr_to_grey(frame, (2 * w + 1, h + 2)))
+
+
+@pytest.mark.parametrize("cls", ["sum", "static", "introduction"])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 6), (5, 1)])
+def test_layer_classes_on_degenerate_frames(cls, shape):
+    """The other layer classes on one-pixel / one-row / one-column frames against the oracle."""
+    from oracle import remap_ref as R
+    from transflow_amd.remap import CompImage, RemapLayer
+    h, w = shape
+    rng = np.random.default_rng(15)
+    intro = [rng.random((h, w)) < 0.8]
+    layer = RemapLayer(h, w, layer_class=cls)
+    layer.set_sources(intro)
+    comp = CompImage(h, w, (9, 8, 7))
+    if cls == "sum":
+        ref = R.SumLayer(h, w, introduction_masks=intro)
+    elif cls == "static":
+        ref = R.StaticLayer(h, w, introduction_masks=intro)
+    else:
+        ref = R.IntroductionLayer(h, w, introduction_masks=intro)
+    for t in range(3):
+        flow = R.post_process(rng.normal(0, 1.5, (h, w, 2)).astype(np.float32), R.BACKWARD)
+        pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        layer.update(flow)
+        if cls == "introduction":
+            layer.introduce(0, pm, t)
+            ref.update(flow, [pm], frame_numbers=[t])
+        else:
+            layer.gather(0, pm)
+            ref.update(flow, [pm])
+        comp.begin()
+        layer.render(comp)
+        img = ref.render()
+        exp = R.composite(np.broadcast_to(np.array([9, 8, 7], np.uint8), (h, w, 3)), [img])
+        np.testing.assert_array_equal(comp.download(), exp)
+        data, rgba = layer.get_state()
+        if data is not None:
+            np.testing.assert_array_equal(data, ref.data)
+        np.testing.assert_array_equal(rgba, np.asarray(ref.rgba))
+    layer.close()
