@@ -137,3 +137,38 @@ def test_against_cv2_when_available():
         got = F.calc(a, b, levels=levels)
         tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
         assert np.abs(got - ref).max() <= tol
+
+
+def test_blur_matches_an_independent_separable_filter():
+    """GaussianBlur(REFLECT_101) against scipy.ndimage's correlate1d(mode='mirror') with the same taps:
+    an independent implementation of the same definition (float64 there, float32 taps/sums here)."""
+    from scipy import ndimage
+    img = _texture(60, 75)
+    for ksz, sigma in [(3, 0.0), (9, 1.5), (19, 3.5), (39, 7.5)]:
+        k = F.gaussian_kernel(ksz, sigma).astype(np.float64)
+        ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0,
+                                  mode="mirror")
+        np.testing.assert_allclose(F.gaussian_blur_u8(img, ksz, sigma), ref, rtol=0, atol=2e-3)
+
+
+def test_polyexp_is_the_weighted_least_squares_fit():
+    """Farnebäck's expansion is, by definition, the Gaussian-weighted least-squares fit of
+    c + bx x + by y + axx x^2 + ayy y^2 + axy xy over the (2n+1)^2 neighbourhood: solved here with
+    numpy.linalg.lstsq per pixel and compared with the oracle's separable closed form on a
+    non-polynomial image (so the weights matter).  Store order R = (by, bx, ayy, axx, axy), SURVEY A.3."""
+    n, sigma = 5, 1.2
+    img = (_texture(40, 44).astype(np.float32) / 8).astype(np.float32)
+    r = F.polyexp(img, n, sigma).astype(np.float64)
+    d = np.arange(-n, n + 1, dtype=np.float64)
+    g = np.exp(-d * d / (2 * sigma * sigma))
+    g /= g.sum()
+    dy, dx = np.meshgrid(d, d, indexing="ij")
+    wgt = np.sqrt(np.outer(g, g)).ravel()
+    basis = np.stack([np.ones_like(dx), dx, dy, dx * dx, dy * dy, dx * dy], axis=-1).reshape(-1, 6)
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        i, j = int(rng.integers(n, 40 - n)), int(rng.integers(n, 44 - n))
+        patch = img[i - n:i + n + 1, j - n:j + n + 1].astype(np.float64).ravel()
+        coef = np.linalg.lstsq(basis * wgt[:, None], patch * wgt, rcond=None)[0]
+        np.testing.assert_allclose(r[i, j], [coef[2], coef[1], coef[4], coef[3], coef[5]], rtol=0, atol=2e-4,
+                                   err_msg=f"pixel ({i}, {j})")
