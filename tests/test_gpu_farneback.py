@@ -171,6 +171,36 @@ def test_batch_equals_single(FB):
     fb.close()
 
 
+def test_pipelined_calls_equal_single_calls(FB):
+    """tf_fb_calc_slots only enqueues: six calls issued back to back without a host synchronisation
+    (the next call's frame expansion runs on the second stream beside the previous call's
+    iterations, R double-buffered) give bit for bit the flows of the same pairs run one at a time."""
+    import ctypes as C
+    from transflow_amd import _lib
+    from transflow_amd._lib import check
+    from transflow_amd.device import DevBuffer
+    h, w = 360, 640
+    frames = [synth_pair(h, w, seed=70 + i)[i % 2] for i in range(8)]
+    single = FB(w, h, levels=4)
+    calls = [([0, 1], [1, 2]), ([2, 3], [3, 4]), ([5, 4], [4, 3]), ([6, 7], [7, 6]), ([0, 7], [7, 0]), ([3, 1], [2, 5])]
+    exp = [[single.calc(frames[a], frames[b]) for a, b in zip(*c)] for c in calls]
+    single.close()
+    fb = FB(w, h, levels=4, frame_slots=8, max_pairs=2)
+    for i, f in enumerate(frames):
+        fb.set_frame(i, f)
+    lib = _lib.load()
+    keep = [[DevBuffer(h * w * 8) for _ in range(2)] for _ in calls]
+    for c, bufs in zip(calls, keep):
+        fb.calc_slots(*c)                       # no synchronisation between the calls
+        for i, buf in enumerate(bufs):          # the flow buffers are reused by the next call: copy, in stream order
+            check(lib.tf_dev_copy(C.c_void_p(buf.ptr), C.c_void_p(fb.flow_ptr(i)), h * w * 8))
+    for e, bufs in zip(exp, keep):
+        for i, buf in enumerate(bufs):
+            np.testing.assert_array_equal(buf.download((h, w, 2), np.float32), e[i])
+            buf.close()
+    fb.close()
+
+
 def test_strided_input_and_errors(FB):
     h, w = 64, 96
     a, b = synth_pair(h, w + 8, seed=60)
