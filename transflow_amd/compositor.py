@@ -226,6 +226,7 @@ class HipCompositor:
         self.background[:, :] = self.background_color
         self.layers = list(layers)
         self._comp = None
+        self._frame_pool = None
 
     def _image(self):
         if self._comp is None:
@@ -243,7 +244,10 @@ class HipCompositor:
         comp.begin()
         for layer in self.layers:
             layer.render_into(comp)
-        return comp.download()
+        if self._frame_pool is None:
+            from .device import ArrayPool
+            self._frame_pool = ArrayPool((self.height, self.width, 3), np.uint8)
+        return comp.download(self._frame_pool.take())
 
     @classmethod
     def from_args(cls, height: int, width: int, layer_configs, background_color: str = "#ffffff", rng: str = "numpy"):
@@ -260,11 +264,12 @@ class HipCompositor:
             layer.set_sources(pixmap_interfaces.get(i, []))
 
     def __getstate__(self):
-        return {k: v for k, v in self.__dict__.items() if k != "_comp"}
+        return {k: v for k, v in self.__dict__.items() if k not in ("_comp", "_frame_pool")}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._comp = None
+        self._frame_pool = None
 
     def close(self):
         for layer in self.layers:

@@ -51,5 +51,25 @@ class DevBuffer:
             pass
 
 
+class ArrayPool:
+    """Host arrays handed out again once nobody else holds them.  A fresh 66 MB numpy array costs
+    ~5 ms of page faults at 4K -- four times the copy that fills it -- so per-frame outputs (flows,
+    rendered frames) come from a small pool; an array the caller still references is never reused."""
+
+    def __init__(self, shape, dtype, limit: int = 4):
+        self.shape, self.dtype, self.limit = tuple(shape), np.dtype(dtype), int(limit)
+        self._arrays: list = []
+
+    def take(self) -> np.ndarray:
+        import sys
+        for a in self._arrays:
+            if sys.getrefcount(a) == 3:      # the list, the loop variable, getrefcount's argument
+                return a
+        a = np.empty(self.shape, self.dtype)
+        if len(self._arrays) < self.limit:
+            self._arrays.append(a)
+        return a
+
+
 def sync() -> None:
     check(_lib.load().tf_sync())

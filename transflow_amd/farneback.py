@@ -85,6 +85,12 @@ class Farneback:
         check(self._lib.tf_fb_get_flow(self._h, int(pair), _ptr(flow)))
         return flow
 
+    def get_flow_into(self, pair: int, out: np.ndarray) -> np.ndarray:
+        if out.dtype != np.float32 or not out.flags.c_contiguous or out.shape != (self.height, self.width, 2):
+            raise ValueError("get_flow_into needs a C-contiguous float32 array of shape (H, W, 2)")
+        check(self._lib.tf_fb_get_flow(self._h, int(pair), _ptr(out)))
+        return out
+
     def flow_ptr(self, pair: int = 0) -> int:
         p = C.c_void_p()
         check(self._lib.tf_fb_flow_ptr(self._h, int(pair), C.byref(p)))

@@ -467,6 +467,10 @@ class HipFlowSource(FlowSource):
         self.device = device
         self.prev_gray = None
         self._fb = None
+        self._prev_slot = None   # frame slot holding prev_gray on the device (resident path)
+        self._pending = None     # array handed out by read_next_flow whose flow is still on the device
+        self._mask_dev = None
+        self._flow_pool = None
         FlowSource.__init__(self, *args, **kwargs)
 
     def validate(self):
@@ -492,6 +496,64 @@ class HipFlowSource(FlowSource):
                 raise RuntimeError(f"An error occurred while reading frame at index {i}")
         self.prev_gray = to_grey(frame)
         self.prev_flow = None
+        self._prev_slot = None
+
+    # ---- resident form of one iteration -------------------------------------------------------
+    # __next__ (source.py:293-321) calls read_next_flow() and hands its result straight to
+    # post_process().  When nothing can look at the raw flow in between (no lock expressions: they are
+    # what reads prev_flow) the flow stays on the device from the Farnebäck call through the filters,
+    # the mask and the direction handling, only the new frame goes up and only the final flow comes
+    # down -- one transfer each instead of two frames up and the flow down, up and down again.  The
+    # public next() / post_process() pair keeps working on host arrays for any other caller.
+    def _resident_ok(self) -> bool:
+        return (self.lock_expr_stay is None and self.lock_expr_skip is None and self.kernel is None
+                and not any(f.name == "polar" for f in self.flow_filters))
+
+    def read_next_flow(self):
+        if not self._resident_ok():
+            return FlowSource.read_next_flow(self)
+        if self.input_frame_index == self.end_frame:
+            self.rewind()
+        frame = self.provider.read()
+        if frame is None:
+            raise StopIteration
+        gray = to_grey(frame)
+        if self.prev_gray is None:
+            raise ValueError("Missing reference frames")
+        fb = self._handle()
+        if self._prev_slot is None:                  # first frame, or after a rewind
+            fb.set_frame(0, self.prev_gray)
+            self._prev_slot = 0
+        new_slot = self._prev_slot ^ 1
+        fb.set_frame(new_slot, gray)
+        if self.direction == FlowSource.Direction.FORWARD:      # cv.py:467-472
+            fb.calc_slots([self._prev_slot], [new_slot])
+        else:
+            fb.calc_slots([new_slot], [self._prev_slot])
+        self._prev_slot, self.prev_gray = new_slot, gray
+        self.input_frame_index += 1
+        if self._flow_pool is None:
+            from .device import ArrayPool
+            self._flow_pool = ArrayPool((self.height, self.width, 2), np.float32)
+        self._pending = self._flow_pool.take()       # filled by post_process
+        return self._pending
+
+    def post_process(self, raw):
+        if self._pending is None or raw is not self._pending:
+            return FlowSource.post_process(self, raw)
+        self._pending = None
+        fb = self._fb
+        ops = [(f.name, f.expr(self.t)) for f in self.flow_filters]
+        mask_dev = None
+        if self.mask is not None:
+            if self._mask_dev is None:
+                from .device import DevBuffer
+                self._mask_dev = DevBuffer.from_array(
+                    np.ascontiguousarray(self.mask, dtype=np.float32).reshape(self.height, self.width))
+            mask_dev = self._mask_dev.ptr
+        fb.post_process_ex(0, self.direction.value, ops, mask_dev)
+        fb.get_flow_into(0, raw)
+        return raw
 
     def next(self):
         """cv.py:460-490: (prev, next) ordered by direction, one Farnebäck call."""
@@ -507,9 +569,13 @@ class HipFlowSource(FlowSource):
             raise ValueError("Missing reference frames")
         flow = self._handle().calc(left, right)
         self.prev_gray = gray
+        self._prev_slot = None       # calc() used both frame slots
         return flow
 
     def close(self):
+        if self._mask_dev is not None:
+            self._mask_dev.close()
+            self._mask_dev = None
         if self._fb is not None:
             self._fb.close()
             self._fb = None

@@ -29,8 +29,9 @@ class CompImage:
     def begin(self):
         check(self._lib.tf_comp_begin(self._h))
 
-    def download(self) -> np.ndarray:
-        out = np.empty((self.height, self.width, 3), np.uint8)
+    def download(self, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None:
+            out = np.empty((self.height, self.width, 3), np.uint8)
         check(self._lib.tf_comp_download(self._h, _ptr(out)))
         return out
 
