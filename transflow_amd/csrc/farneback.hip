@@ -1732,9 +1732,13 @@ struct tf_fb {
     std::vector<Level *> lv;
     // R exists twice when the preparation stream is in use: call i+1 expands its frames into one set
     // while the flow chain of call i still reads the other (`cur` = the set of the call being issued)
-    DevBuf frames, img, R[2], M[2], lflow[3], pairs, winner, scratch;
+    DevBuf frames, img, R[2], M[2], lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
     int nsets = 1, cur = 0;
     hipStream_t prep_stream = nullptr;         // A1+A2 of every level run here, ahead of and beside the flow chain
+    hipStream_t chain_stream = nullptr;        // the flow chain; the library stream only waits for its end, so what the
+                                               // caller queues after a call (its remap) runs beside the NEXT call's chain
+    hipEvent_t entry[2] = {nullptr, nullptr};  // position of the library stream when call (parity) was issued
+    bool entry_pending[2] = {false, false};
     hipEvent_t chain_done[2] = {nullptr, nullptr}; // the chain has finished with R set s
     bool chain_pending[2] = {false, false};
     int2 *pairs_host = nullptr;                // pinned staging of the slot pairs
@@ -1766,8 +1770,10 @@ struct tf_fb {
             (void)hipEventDestroy(fine_start);
         if (pairs_host)
             (void)hipHostFree(pairs_host);
-        if (prep_stream)
-            (void)hipStreamDestroy(prep_stream);
+        for (auto e : entry)
+            if (e)
+                (void)hipEventDestroy(e);
+        // prep_stream / chain_stream are the library's side streams (runtime.hip), not ours to destroy
     }
 };
 
@@ -2114,6 +2120,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
+        (fb->nsets > 1 && ((rc = fb->lflow[3].alloc(P * N0 * 8)) || (rc = fb->lflow[4].alloc(P * N0 * 8)))) ||
         (rc = fb->pairs.alloc(P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
         return fail(rc);
     for (int k = 1; k <= fb->K; k++) {
@@ -2126,15 +2133,15 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
     for (int k = 0; k <= fb->K; k++)
         if (hipEventCreateWithFlags(&fb->lv[k]->ready, hipEventDisableTiming) != hipSuccess)
             return fail(set_error(TF_ERR_HIP, "hipEventCreate failed"));
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipEventCreateWithFlags(&fb->chain_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->chain_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->pairs_copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->fine_start, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void **)&fb->pairs_host, P * sizeof(int2), hipHostMallocDefault) != hipSuccess ||
-        hipStreamCreateWithPriority(&fb->prep_stream, hipStreamNonBlocking, least) != hipSuccess)
-        return fail(set_error(TF_ERR_HIP, "creating the preparation stream failed"));
+        hipEventCreateWithFlags(&fb->entry[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&fb->entry[1], hipEventDisableTiming) != hipSuccess ||
+        side_stream(1, &fb->chain_stream) != TF_OK || side_stream(0, &fb->prep_stream) != TF_OK ||
+        hipHostMalloc((void **)&fb->pairs_host, P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
+        return fail(set_error(TF_ERR_HIP, "creating the handle's events and staging buffer failed"));
     *out = fb;
     return TF_OK;
 }
@@ -2201,6 +2208,20 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     // full-resolution iterations (HBM-bound) instead of in front of its own chain.
     const bool overlap = fb->nsets > 1;
     const int set = fb->cur;
+    // The chain has a stream of its own as well.  The library stream -- where the caller's work on the
+    // result goes (post_process, the remap of each pair) -- waits for the chain's end, and the chain of
+    // the NEXT call does not wait for that work: the result lands in one of two buffers by call
+    // parity, and this call's chain only waits for what the library stream had been given when the
+    // PREVIOUS call was issued (all that could still read this parity's buffer).  So the remap of call
+    // i (HBM-bound, full-size) runs beside the coarse levels of call i+1 (small launches, mostly idle chip).
+    static const bool own_chain_stream = !(getenv("TF_FB_NO_CHAIN_STREAM") && atoi(getenv("TF_FB_NO_CHAIN_STREAM")) != 0);
+    hipStream_t cs = (overlap && own_chain_stream) ? fb->chain_stream : main_stream();
+    if (overlap && own_chain_stream) {
+        TF_HIP(hipEventRecord(fb->entry[set], main_stream()));
+        fb->entry_pending[set] = true;
+        if (fb->entry_pending[set ^ 1])
+            TF_HIP(hipStreamWaitEvent(cs, fb->entry[set ^ 1], 0));
+    }
     {
         hipStream_t ps = overlap ? fb->prep_stream : main_stream();
         // R set `set` was last read by the chain two calls ago.  Frames: tf_fb_set_frame returns with the
@@ -2230,12 +2251,13 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         }
     }
     int coarse = -1; // lflow buffer holding the coarser level's result
+    StreamScope chain_scope(cs);
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
         if (overlap)
-            TF_HIP(hipStreamWaitEvent(main_stream(), L.ready, 0));
+            TF_HIP(hipStreamWaitEvent(cs, L.ready, 0));
         if (overlap && k == 0) {
-            TF_HIP(hipEventRecord(fb->fine_start, main_stream()));
+            TF_HIP(hipEventRecord(fb->fine_start, cs));
             fb->fine_pending = true;
         }
         FlowInit fi;
@@ -2258,6 +2280,9 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             a = 0;
             b = 1;
         }
+        const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
+        if (k == 0 && overlap && !(fused && L.W >= 2 && L.H >= 2))
+            a = out_buf;
         int result;
         if (fused && L.W >= 2 && L.H >= 2) {
             const float2 *src = nullptr; // zero flow at the coarsest scale (flags == 0)
@@ -2290,12 +2315,19 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             }
             result = a;
         }
+        if (k == 0 && overlap && result != out_buf) { // the opt-in fused iterations ping-pong: move their result
+            TF_HIP(hipMemcpyAsync(fb->lflow[out_buf].p, fb->lflow[result].p, (size_t)n_pairs * L.W * L.H * 8,
+                                  hipMemcpyDeviceToDevice, cs));
+            result = out_buf;
+        }
         coarse = result;
         fb->final_buf = result;
     }
     if (overlap) {
-        TF_HIP(hipEventRecord(fb->chain_done[set], main_stream()));
+        TF_HIP(hipEventRecord(fb->chain_done[set], cs));
         fb->chain_pending[set] = true;
+        if (cs != main_stream())
+            TF_HIP(hipStreamWaitEvent(main_stream(), fb->chain_done[set], 0));
     }
     fb->cur = (set + 1) % fb->nsets;
     fb->last_pairs = n_pairs;
