@@ -167,6 +167,29 @@ def measured_traffic(name, wl, batch, launches_per_step, iterations=3):
     return total / max(1.0, launches_per_step)
 
 
+def copy_ceiling(lib, check, nbytes=1 << 30, reps=8):
+    """Measured rate (read + write bytes per second) of a 16-byte-per-lane copy kernel over 1 GiB, HIP
+    events on the library stream: the practical HBM ceiling the 8 TB/s spec figure is quoted next to
+    (SURVEY 8d)."""
+    src, dst, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(lib.tf_dev_alloc(C.byref(src), nbytes))
+    check(lib.tf_dev_alloc(C.byref(dst), nbytes))
+    check(lib.tf_event_create(C.byref(e0)))
+    check(lib.tf_event_create(C.byref(e1)))
+    check(lib.tf_dev_stream_copy(dst, src, nbytes))
+    check(lib.tf_event_record(e0))
+    for _ in range(reps):
+        check(lib.tf_dev_stream_copy(dst, src, nbytes))
+    check(lib.tf_event_record(e1))
+    ms = C.c_float()
+    check(lib.tf_event_elapsed_ms(e0, e1, C.byref(ms)))
+    lib.tf_event_destroy(e0)
+    lib.tf_event_destroy(e1)
+    check(lib.tf_dev_free(src))
+    check(lib.tf_dev_free(dst))
+    return 2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9
+
+
 def cpu_baseline(wl):
     """The oracle (a scalar C port of OpenCV's CPU path + the numpy remap), timed on
     this host on ONE frame pair of the same workload.  Checker code, used here only
@@ -321,6 +344,7 @@ def main():
         j.prof(False)
         cnt, ms = j.prof_report()[dominant]
         ach = kernel_alg_bytes(dominant, wl, args.batch) * n / (ms * 1e-3) / 1e9
+        out["roofline"]["measured_copy_ceiling_GBs"] = copy_ceiling(job.lib, job.check)
         out["roofline"]["exclusive"] = {"what": "same kernel, same workload, preparation stream disabled (nothing runs beside it); untimed region",
                                         "launches": cnt, "avg_launch_ms": ms / max(1, cnt), "achieved": ach,
                                         "frac": ach / rf.HBM_PEAK_GBS}

@@ -71,6 +71,8 @@ int tf_dev_free(void *dev);
 int tf_dev_upload(void *dev, const void *host, size_t bytes);
 int tf_dev_download(void *host, const void *dev, size_t bytes);
 int tf_dev_copy(void *dst_dev, const void *src_dev, size_t bytes); /* device to device, on the library stream */
+/* The same as one kernel, 16 bytes per lane: bench.py measures the practical HBM ceiling with it. */
+int tf_dev_stream_copy(void *dst_dev, const void *src_dev, size_t bytes);
 
 /* ---- Farnebäck dense optical flow ----------------------------------------------
  * Replaces cv2.calcOpticalFlowFarneback as called at

@@ -317,6 +317,23 @@ TF_API int tf_dev_download(void *host, const void *dev, size_t bytes)
     return TF_OK;
 }
 
+// 16 bytes per lane, one pass: the streaming copy the HBM ceiling is quoted from (MI355X_MICROARCH.md)
+__global__ void k_stream_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] = src[i];
+}
+
+TF_API int tf_dev_stream_copy(void *dst_dev, const void *src_dev, size_t bytes)
+{
+    TF_REQUIRE(dst_dev && src_dev && (bytes & 15) == 0, "tf_dev_stream_copy: null pointer or size not a multiple of 16");
+    TF_TRY(ensure_init());
+    const size_t n = bytes / 16;
+    return tf::launch("stream_copy", k_stream_copy, dim3(tf::cdiv(n, 256)), dim3(256), 0, (const float4 *)src_dev,
+                      (float4 *)dst_dev, n);
+}
+
 TF_API int tf_dev_copy(void *dst_dev, const void *src_dev, size_t bytes)
 {
     TF_REQUIRE(dst_dev && src_dev, "tf_dev_copy: null pointer");
