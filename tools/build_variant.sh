@@ -5,7 +5,7 @@ name=$1; shift
 cd "$(dirname "$0")/../transflow_amd/csrc"
 out=../../build_abl
 mkdir -p $out/$name
-for f in runtime remap farneback; do
+for f in runtime remap farneback flowops; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result "$@" -c $f.hip -o $out/$name/$f.o &
 done
 wait

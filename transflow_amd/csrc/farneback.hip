@@ -74,6 +74,32 @@ __device__ __forceinline__ void xcd_tile(unsigned &bx, unsigned &by)
     by = t / gridDim.x;
 }
 
+// Barriers that order LDS traffic only.  __syncthreads() also carries a release fence on GLOBAL memory,
+// i.e. `s_waitcnt vmcnt(0)`: in a marching loop that drains every prefetched load at every row.
+// lds_barrier(): all waves of the workgroup; lds_wave_sync(): the lanes of one wave (single-wave exchange).
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// 1/d for a positive, normal double: hardware estimate + two Newton steps (relative error ~1e-16, not
+// correctly rounded; a true division is ~25 instructions).  For determinants that carry +1e-3.
+__device__ __forceinline__ double fast_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ void lds_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // REFLECT_101 when the overshoot is known to be smaller than the image (one reflection suffices)
 __device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
 
@@ -1182,7 +1208,7 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
             s_o[c][lane] = vs[c][1];
             s_p[c][lane] = vs[c][0] + vs[c][1];
         }
-        __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
+        lds_wave_sync(); // single-wave workgroup: orders the LDS writes before the reads, leaves the loads in flight
         if (is_out) {
             double g0[5], g1[5];
 #pragma unroll
@@ -1218,7 +1244,7 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
             if (c0 + 1 < Wk)
                 o[1] = f1;
         }
-        __syncthreads(); // the next row's writes must not overtake this row's reads
+        lds_wave_sync(); // the next row's writes must not overtake this row's reads
       }
     }
 }
@@ -1271,11 +1297,9 @@ __global__ void k_flow_upsample(float2 *__restrict__ dst, int Wk, int Hk, FlowIn
 }
 
 // ---------------------------------------------------------------------------------
-// A3+A4 fused, ONE column per lane: the window ring is 19 KB per wave (15 x 5 x 64 floats for
-// m = 7), so seven waves share a CU instead of three.  A wave marches a 64-column strip
-// (64 - 2m outputs); adjacent strips meet in one XCD's L2 (xcd_tile), which absorbs the halo
-// columns.  PF rows of gathers are kept in flight (branch-free, clamped rows).  The window sum
-// uses pair sums p[l] = v[l] + v[l+1] (one wave shuffle): m+1 LDS reads and m adds per channel.
+// One pixel of A3 split into "issue the loads" and "finish the arithmetic" (one column per lane),
+// so a marching wave can keep the gathers of later rows in flight: used by the producers of
+// k_flow_iter_pc below.  Same statements as update_matrix_px.
 // ---------------------------------------------------------------------------------
 struct Gather1 {
     float r0[5];
@@ -1347,96 +1371,129 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk,
     m[4] = r6 * r2 + r5 * r3;
 }
 
+// ---------------------------------------------------------------------------------
+// A3+A4 fused, roles split inside the workgroup (the default on large levels).  Three waves march a strip
+// of 128 columns together: waves 0-1 are PRODUCERS (one column per lane: they compute row e of M
+// from R0, R1 and the flow -- gather1_issue / gather1_finish, two rows in flight -- and put it in an LDS
+// ring of 2M+3 rows), wave 2 is the CONSUMER (two columns per lane: it slides the vertical window
+// sums over the ring, exchanges them across lanes, solves and writes the flow: k_blur_solve_wave's
+// body).  One workgroup barrier per row: in step s the producers write row s while the consumer
+// works on row s-1, whose leaving row (s-1-(2M+1)) sits in a slot nobody writes before the next
+// barrier -- which is why the ring has 2M+3 slots, not 2M+1.  M is never stored: the window costs
+// 43 KB of LDS per 112 output columns (3 workgroups = 9 waves per CU).
+// ---------------------------------------------------------------------------------
 template <int M, bool HAVE_FLOW>
-__global__ void __launch_bounds__(64)
-k_flow_iter1(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
-             int Hk, double scale, int seg)
+__global__ void __launch_bounds__(192)
+k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
+               int Hk, double scale, int seg)
 {
     static_assert(M & 1, "the pair-sum window needs an odd half-width");
-    constexpr int HALO = M, OUTC = 64 - 2 * HALO, WIN = 2 * M + 1, PF = 2;
-    __shared__ float ring[WIN][5][64];
-    __shared__ double s_v[5][64], s_p[5][64];
-    const int lane = threadIdx.x;
+#ifndef TF_PC_PF
+#define TF_PC_PF 2
+#endif
+    constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1, NS = WIN + 2, PF = TF_PC_PF;
+    __shared__ float ring[NS][5][128];
+    __shared__ double s_e[5][64], s_o[5][64], s_p[5][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
     xcd_tile(bx, by);
-    const int c0 = (int)bx * OUTC - HALO + lane;
-    const int x = clampi(c0, 0, Wk - 1); // replicated border columns
     const int pair = blockIdx.z;
     const size_t Nk = (size_t)Wk * Hk;
-    const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
-    const float2 *fin = HAVE_FLOW ? flow_in + (size_t)pair * Nk : nullptr;
     const int r0 = by * seg, r1 = min(r0 + seg, Hk);
-
-    auto load_flow = [&](int row) {
-        return HAVE_FLOW ? fin[(size_t)min(row, Hk - 1) * Wk + x] : make_float2(0.f, 0.f);
-    };
-
-    double vs[5] = {0, 0, 0, 0, 0};
-    float mlast[5];
-    // ---- the first window: rows r0-M .. r0+M-1 (a clamped row repeats the edge row's matrices)
-    int last_row = -1, slot = 0;
-    for (int e = r0 - M; e < r0 + M; e++) {
-        const int row = clampi(e, 0, Hk - 1);
-        if (row != last_row) {
-            Gather1 g;
-            gather1_issue(g, R0, R1, Nk, Wk, Hk, x, row, load_flow(row));
-            gather1_finish(g, Wk, Hk, x, row, mlast);
-            last_row = row;
+    // step s: producers make entering row e = r0 - M + s (s < n_rows); the consumer handles row s - 1
+    const int n_rows = (r1 - r0) + 2 * M, nsteps = n_rows + 1;
+    for (int i = threadIdx.x; i < NS * 5 * 128; i += 192)
+        (&ring[0][0][0])[i] = 0.f; // rows "above" the first window count as zero: the warm-up subtracts them
+    __syncthreads();
+    if (wave < 2) {
+        const int col = wave * 64 + lane;
+        const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
+        const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
+        const float2 *fin = HAVE_FLOW ? flow_in + (size_t)pair * Nk : nullptr;
+        auto load_flow = [&](int row) {
+            return HAVE_FLOW ? fin[(size_t)clampi(row, 0, Hk - 1) * Wk + x] : make_float2(0.f, 0.f);
+        };
+        Gather1 G[PF];
+#pragma unroll
+        for (int t = 0; t < PF; t++) {
+            const int row = clampi(r0 - M + t, 0, Hk - 1);
+            gather1_issue(G[t], R0, R1, Nk, Wk, Hk, x, row, load_flow(row));
         }
+        float2 F = load_flow(r0 - M + PF);
+        int slot = 0;
+        for (int sb = 0; sb < nsteps; sb += PF) {
 #pragma unroll
-        for (int c = 0; c < 5; c++) {
-            ring[slot][c][lane] = mlast[c];
-            vs[c] += (double)mlast[c];
-        }
-        slot = slot + 1 == WIN ? 0 : slot + 1;
-    }
+            for (int h = 0; h < PF; h++) {
+                const int s = sb + h;
+                if (s >= nsteps)
+                    break;
+                if (s < n_rows) {
+                    const int e = r0 - M + s;
+                    float m[5];
+                    gather1_finish(G[h], Wk, Hk, x, clampi(e, 0, Hk - 1), m);
+                    gather1_issue(G[h], R0, R1, Nk, Wk, Hk, x, clampi(e + PF, 0, Hk - 1), F);
+                    F = load_flow(e + PF + 1);
 #pragma unroll
-    for (int c = 0; c < 5; c++)
-        ring[slot][c][lane] = 0.f; // the slot the first entering row replaces
-    // ---- software pipeline: G[t] holds the gathers of entering row r0+M+t (slot t % PF), F the
-    // flow of the row after those
-    Gather1 G[PF];
-    float2 F;
-#pragma unroll
-    for (int t = 0; t < PF; t++)
-        gather1_issue(G[t], R0, R1, Nk, Wk, Hk, x, min(r0 + M + t, Hk - 1), load_flow(r0 + M + t));
-    F = load_flow(r0 + M + PF);
-    const bool is_out = lane >= HALO && lane < 64 - HALO && c0 < Wk;
-    for (int yb = r0; yb < r1; yb += PF) {
-#pragma unroll
-        for (int h = 0; h < PF; h++) {
-            const int y = yb + h;
-            if (y >= r1)
-                break;
-            gather1_finish(G[h], Wk, Hk, x, min(y + M, Hk - 1), mlast);
-            gather1_issue(G[h], R0, R1, Nk, Wk, Hk, x, min(y + M + PF, Hk - 1), F); // row entering PF steps later
-            F = load_flow(y + M + PF + 1);
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const float old = ring[slot][c][lane];
-                ring[slot][c][lane] = mlast[c];
-                vs[c] += (double)mlast[c] - (double)old;
-                s_v[c][lane] = vs[c];
-                s_p[c][lane] = vs[c] + __shfl_down(vs[c], 1); // lane 63 pairs with itself: never read
+                    for (int c = 0; c < 5; c++)
+                        ring[slot][c][col] = m[c];
+                    slot = slot + 1 == NS ? 0 : slot + 1;
+                }
+                lds_barrier();
             }
-            slot = slot + 1 == WIN ? 0 : slot + 1;
-            __syncthreads(); // single-wave workgroup: orders the LDS writes before the reads
-            if (is_out) {
-                double g[5];
+        }
+    } else {
+        const int c0 = (int)bx * OUTC - HALO + 2 * lane;
+        const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
+        double vs[5][2];
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            vs[c][0] = vs[c][1] = 0.0;
+        int slot_new = 0, slot_old = 2 % NS; // row s-1 and row s-1-WIN  ((s - 1 - WIN) mod NS == (s + 1) mod NS)
+        for (int s = 0; s < nsteps; s++) {
+            if (s >= 1) {
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    // columns l-M .. l+M = v[l-M] + pairs starting at l-M+1, l-M+3, ..., l+M-1
-                    double a = s_v[c][lane - M];
-#pragma unroll
-                    for (int j = -M + 1; j <= M - 1; j += 2)
-                        a += s_p[c][lane + j];
-                    g[c] = a * scale;
+                    const float2 nw = *reinterpret_cast<const float2 *>(&ring[slot_new][c][2 * lane]);
+                    const float2 od = *reinterpret_cast<const float2 *>(&ring[slot_old][c][2 * lane]);
+                    vs[c][0] += (double)nw.x - (double)od.x;
+                    vs[c][1] += (double)nw.y - (double)od.y;
                 }
-                const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
-                flow_out[(size_t)pair * Nk + (size_t)y * Wk + c0] =
-                    make_float2((float)((g[0] * g[4] - g[1] * g[3]) * idet), (float)((g[2] * g[3] - g[1] * g[4]) * idet));
+                slot_new = slot_new + 1 == NS ? 0 : slot_new + 1;
+                slot_old = slot_old + 1 == NS ? 0 : slot_old + 1;
+                const int y = r0 + (s - 1) - 2 * M; // the row whose window is now complete
+                if (y >= r0) {                      // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        s_e[c][lane] = vs[c][0];
+                        s_o[c][lane] = vs[c][1];
+                        s_p[c][lane] = vs[c][0] + vs[c][1];
+                    }
+                    lds_wave_sync(); // one wave writes and reads these rows: no workgroup barrier
+                    if (is_out) {
+                        double g0[5], g1[5];
+#pragma unroll
+                        for (int c = 0; c < 5; c++) {
+                            constexpr int hh = (M - 1) / 2, kk = (M + 1) / 2;
+                            double common = s_p[c][lane - hh];
+#pragma unroll
+                            for (int j = -hh + 1; j <= hh; j++)
+                                common += s_p[c][lane + j];
+                            g0[c] = (s_o[c][lane - kk] + common) * scale;
+                            g1[c] = (common + s_e[c][lane + kk]) * scale;
+                        }
+                        const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
+                        const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
+                        float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
+                        o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
+                                           (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
+                        if (c0 + 1 < Wk)
+                            o[1] = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
+                                               (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+                    }
+                    lds_wave_sync();
+                }
             }
-            __syncthreads(); // the next row's writes must not overtake this row's reads
+            lds_barrier();
         }
     }
 }
@@ -1748,10 +1805,10 @@ struct tf_fb {
     bool fine_pending = false;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
-    // A3+A4 as one kernel per iteration (k_flow_iter1: M never stored).  Correct (same parity tests) and
-    // within 5 % of the two-kernel form on MI355X, not faster: what it saves in M traffic it spends on
-    // halo columns.  Opt-in with TF_FB_FUSED=1.
-    bool fused = getenv("TF_FB_FUSED") && atoi(getenv("TF_FB_FUSED")) != 0;
+    // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
+    // the chip with its 3-wave workgroups, as two kernels (k_update_matrices, k_blur_solve_wave)
+    // otherwise.  TF_FB_FUSED=0 / 1 forces never / always.
+    int fused = getenv("TF_FB_FUSED") ? atoi(getenv("TF_FB_FUSED")) : -1;
     float *Rk(int k) { return (k <= 0 ? R[cur] : lv[k]->R[cur]).as<float>(); }
     float *imgk(int k) { return (k <= 0 ? img : lv[k]->img).as<float>(); }
     ~tf_fb()
@@ -2004,16 +2061,21 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
 {
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     const float *R = fb->Rk(k);
-    constexpr int OUTC = 64 - 2 * M;
+    constexpr int OUTC = 128 - 2 * ((M + 1) & ~1);
     const unsigned strips = cdiv(w, OUTC);
-    // the 19-24 KB of LDS per wave admit ~6 waves per CU: aim at a few rounds of them
-    long segs_wanted = std::max(1l, (7 * 256 * 3) / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(h, std::max<long>(2 * (2 * M + 1), (h + segs_wanted - 1) / segs_wanted));
+    // 3 workgroups per CU are resident; a few rounds of them, fewer on smaller levels where each
+    // segment's 2M warm-up rows weigh more (measured at 4K x 16: 3072 / 1536 / 768 workgroups best
+    // at levels 0 / 1 / 2)
+    static const long forced = getenv("TF_PC_BLOCKS") ? atol(getenv("TF_PC_BLOCKS")) : 0;
+    const long px = (long)w * h * n_pairs;
+    const long blocks_wanted = forced ? forced : std::min(3072l, std::max(768l, px / 21600));
+    long segs = std::max(1l, blocks_wanted / std::max(1l, (long)strips * n_pairs));
+    int seg = (int)std::min<long>(h, std::max<long>(4 * (2 * M + 1), (h + segs - 1) / segs));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter1<M, true>, grid, dim3(64), 0, R, flow_in, flow_out, w, h,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, true>, grid, dim3(192), 0, R, flow_in, flow_out, w, h,
                       scale, seg);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter1<M, false>, grid, dim3(64), 0, R, flow_in, flow_out, w, h,
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, false>, grid, dim3(192), 0, R, flow_in, flow_out, w, h,
                   scale, seg);
 }
 
@@ -2200,7 +2262,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     for (int i = 0; i < n_pairs; i++)
         fb->pairs_host[i] = make_int2(prev_slots[i], next_slots[i]);
     const int m = fb->prm.winsize / 2;
-    const bool fused = fb->fused && (m == 3 || m == 5 || m == 7);
+    const bool fusable = m == 3 || m == 5 || m == 7; // the pair-sum window of the fused kernel
     // A1+A2 of every level depend on the frames only: they run on the preparation stream, coarse
     // level first, while the flow chain (which needs the coarser level's result) follows on the
     // library stream as each level's coefficients become ready.  The call returns without waiting,
@@ -2281,27 +2343,32 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             b = 1;
         }
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
-        if (k == 0 && overlap && !(fused && L.W >= 2 && L.H >= 2))
+        const bool fused_here = fusable && L.W >= 2 && L.H >= 2 &&
+                                (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= (4l << 20)));
+        if (k == 0 && overlap && !fused_here)
             a = out_buf;
         int result;
-        if (fused && L.W >= 2 && L.H >= 2) {
+        // one kernel per iteration where the level fills the chip (>= 4M pixels over the batch), two otherwise
+        if (fused_here) {
+            // the iterations ping-pong between two buffers, ordered so that the LAST one writes p: the
+            // call's result buffer at full resolution, otherwise any buffer the coarser level is not in
+            const int I = fb->prm.iterations;
+            const int p = (k == 0 && overlap) ? out_buf : a, q = (k == 0 && overlap) ? a : b;
+            auto buf_of = [&](int i) { return ((I - i) & 1) ? q : p; }; // i = 0: the upsampled start, i >= 1: iteration i
             const float2 *src = nullptr; // zero flow at the coarsest scale (flags == 0)
             if (k < fb->K) {
                 dim3 g(cdiv(L.W, 64), cdiv(L.H, 4), n_pairs);
-                TF_TRY(launch(lvl_name("fb_flow_upsample", k), k_flow_upsample, g, dim3(256), 0, fb->lflow[a].as<float2>(),
-                              L.W, L.H, fi));
-                src = fb->lflow[a].as<float2>();
-                std::swap(a, b); // first iteration reads a, writes b
+                TF_TRY(launch(lvl_name("fb_flow_upsample", k), k_flow_upsample, g, dim3(256), 0,
+                              fb->lflow[buf_of(0)].as<float2>(), L.W, L.H, fi));
+                src = fb->lflow[buf_of(0)].as<float2>();
             }
-            int dst = a;
-            for (int i = 0; i < fb->prm.iterations; i++) {
+            for (int i = 1; i <= I; i++) {
                 int rc = TF_OK;
-                fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[dst].as<float2>(), k, rc);
+                fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[buf_of(i)].as<float2>(), k, rc);
                 TF_TRY(rc);
-                src = fb->lflow[dst].as<float2>();
-                result = dst;
-                dst = (dst == a) ? b : a; // the next iteration reads what this one wrote
+                src = fb->lflow[buf_of(i)].as<float2>();
             }
+            result = p;
         } else {
             TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0, k));
             FlowInit fl;
@@ -2314,11 +2381,6 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
                     TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0, k));
             }
             result = a;
-        }
-        if (k == 0 && overlap && result != out_buf) { // the opt-in fused iterations ping-pong: move their result
-            TF_HIP(hipMemcpyAsync(fb->lflow[out_buf].p, fb->lflow[result].p, (size_t)n_pairs * L.W * L.H * 8,
-                                  hipMemcpyDeviceToDevice, cs));
-            result = out_buf;
         }
         coarse = result;
         fb->final_buf = result;
