@@ -1308,13 +1308,28 @@ struct Gather1 {
     bool inb;
 };
 
-__device__ __forceinline__ void gather1_issue(Gather1 &g, const float *__restrict__ R0, const float *__restrict__ R1,
-                                              size_t Nk, int Wk, int Hk, int x, int y, float2 fl)
+// The wave-uniform plane bases (R0 + c*Nk, R1 + c*Nk) stay in SGPRs and every load is base + one 32-bit
+// byte offset per lane, so the five planes share the lane's address arithmetic.
+struct PlaneBases {
+    const float *r0[5];
+    const float *r1[5];
+};
+
+__device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
 {
-    const size_t o = (size_t)y * Wk + x;
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ float2u ld_f32x2(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float2u *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+__device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, int Wk, int Hk, int x, int y, float2 fl)
+{
+    const unsigned o = ((unsigned)y * Wk + x) * 4u;
 #pragma unroll
     for (int c = 0; c < 5; c++)
-        g.r0[c] = R0[c * Nk + o];
+        g.r0[c] = ld_f32(pb.r0[c], o);
     float fx = x + fl.x, fy = y + fl.y;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     g.dx = fl.x;
@@ -1322,11 +1337,11 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const float *__restric
     g.fx = fx - x1;
     g.fy = fy - y1;
     g.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
-    const float *rp = R1 + (size_t)clampi(y1, 0, Hk - 2) * Wk + clampi(x1, 0, Wk - 2);
+    const unsigned ot = ((unsigned)clampi(y1, 0, Hk - 2) * Wk + clampi(x1, 0, Wk - 2)) * 4u, ob = ot + (unsigned)Wk * 4u;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        float2u tv = *reinterpret_cast<const float2u *>(rp + c * Nk);
-        float2u bv = *reinterpret_cast<const float2u *>(rp + c * Nk + Wk);
+        float2u tv = ld_f32x2(pb.r1[c], ot);
+        float2u bv = ld_f32x2(pb.r1[c], ob);
         g.t[c] = make_float2(tv.x, tv.y);
         g.b[c] = make_float2(bv.x, bv.y);
     }
@@ -1408,16 +1423,24 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     if (wave < 2) {
         const int col = wave * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
-        const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
+        PlaneBases pb;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            pb.r0[c] = R + (size_t)pair * 10 * Nk + (size_t)c * Nk;
+            pb.r1[c] = pb.r0[c] + 5 * Nk;
+        }
         const float2 *fin = HAVE_FLOW ? flow_in + (size_t)pair * Nk : nullptr;
         auto load_flow = [&](int row) {
-            return HAVE_FLOW ? fin[(size_t)clampi(row, 0, Hk - 1) * Wk + x] : make_float2(0.f, 0.f);
+            if (!HAVE_FLOW)
+                return make_float2(0.f, 0.f);
+            const unsigned off = ((unsigned)clampi(row, 0, Hk - 1) * Wk + x) * 8u;
+            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
         };
         Gather1 G[PF];
 #pragma unroll
         for (int t = 0; t < PF; t++) {
             const int row = clampi(r0 - M + t, 0, Hk - 1);
-            gather1_issue(G[t], R0, R1, Nk, Wk, Hk, x, row, load_flow(row));
+            gather1_issue(G[t], pb, Wk, Hk, x, row, load_flow(row));
         }
         float2 F = load_flow(r0 - M + PF);
         int slot = 0;
@@ -1431,7 +1454,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                     const int e = r0 - M + s;
                     float m[5];
                     gather1_finish(G[h], Wk, Hk, x, clampi(e, 0, Hk - 1), m);
-                    gather1_issue(G[h], R0, R1, Nk, Wk, Hk, x, clampi(e + PF, 0, Hk - 1), F);
+                    gather1_issue(G[h], pb, Wk, Hk, x, clampi(e + PF, 0, Hk - 1), F);
                     F = load_flow(e + PF + 1);
 #pragma unroll
                     for (int c = 0; c < 5; c++)
@@ -2063,14 +2086,27 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     const float *R = fb->Rk(k);
     constexpr int OUTC = 128 - 2 * ((M + 1) & ~1);
     const unsigned strips = cdiv(w, OUTC);
-    // 3 workgroups per CU are resident; a few rounds of them, fewer on smaller levels where each
-    // segment's 2M warm-up rows weigh more (measured at 4K x 16: 3072 / 1536 / 768 workgroups best
-    // at levels 0 / 1 / 2)
+    // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
+    // rounds of 768, each as long as a segment plus its 2M+1 warm-up / drain steps.  Pick the segment
+    // count that minimises rounds x steps (4K x 16: 4 segments = 2240 workgroups, 2.9 -> 3 rounds).
     static const long forced = getenv("TF_PC_BLOCKS") ? atol(getenv("TF_PC_BLOCKS")) : 0;
-    const long px = (long)w * h * n_pairs;
-    const long blocks_wanted = forced ? forced : std::min(3072l, std::max(768l, px / 21600));
-    long segs = std::max(1l, blocks_wanted / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(h, std::max<long>(4 * (2 * M + 1), (h + segs - 1) / segs));
+    const long per_seg = (long)strips * n_pairs, slots = 768;
+    long best_segs = 1;
+    double best_cost = 1e300;
+    for (long sg = 1; sg <= 64 && sg <= h; sg++) {
+        const long rows = (h + sg - 1) / sg;
+        if (rows < 2 * (2 * M + 1) && sg > 1)
+            break;
+        const long rounds = (per_seg * sg + slots - 1) / slots;
+        const double cost = (double)rounds * (double)(rows + 2 * M + 1);
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best_segs = sg;
+        }
+    }
+    if (forced)
+        best_segs = std::max(1l, forced / std::max(1l, per_seg));
+    const int seg = (int)((h + best_segs - 1) / best_segs);
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     if (flow_in)
         return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, true>, grid, dim3(192), 0, R, flow_in, flow_out, w, h,
