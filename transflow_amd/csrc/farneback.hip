@@ -1877,11 +1877,11 @@ static const char *lvl_name(const char *base, int k)
 
 // Extra dynamic LDS per preparation-kernel workgroup (bytes): caps how many of them a CU hosts, which
 // leaves wave slots to the HBM-bound flow chain running beside them on the library stream.  Measured
-// at 4K batch 16: 14 KB on the expansion kernels (4 workgroups per CU instead
-// of 7) and 8 KB on the level-image kernel give +5 % frames/s; more starves the preparation.
+// at 4K batch 16: 8 KB on the expansion kernels (5 workgroups per CU instead
+// of 7) and 8 KB on the level-image kernel give +3-5 % frames/s; more starves the preparation.
 static size_t prep_pad(const tf_fb *fb, bool image_kernel = false)
 {
-    static const long pad = getenv("TF_PREP_PAD_KB") ? atol(getenv("TF_PREP_PAD_KB")) : 14;
+    static const long pad = getenv("TF_PREP_PAD_KB") ? atol(getenv("TF_PREP_PAD_KB")) : 8;
     static const long pad_img = getenv("TF_PREP_PAD_IMG_KB") ? atol(getenv("TF_PREP_PAD_IMG_KB")) : 8;
     if (fb->nsets < 2) // no second stream, nothing to leave room for
         return 0;
