@@ -161,7 +161,10 @@ def measured_traffic(name, wl, batch, launches_per_step, iterations=3):
     if name not in table:
         return None
     n = [a * b for a, b in rf.level_sizes(wl["w"], wl["h"], 0.5, wl["levels"])]
-    per_level_launches = {"fb_update_matrices": iterations, "fb_blur_solve": iterations}.get(name, 1)
+    per_level_launches = {"fb_update_matrices": iterations, "fb_blur_solve": iterations,
+                          "fb_flow_iter": iterations}.get(name, 1)
+    if name == "fb_flow_iter":          # runs on the levels of >= 4M pixels over the batch only
+        n = [v for v in n if v * batch >= (4 << 20)]
     images = 2 if name in ("fb_polyexp", "fb_level_image") else 1
     total = table[name]["bytes_per_px"] * sum(n) * batch * images * per_level_launches
     return total / max(1.0, launches_per_step)

@@ -23,7 +23,13 @@ fb = Farneback(w, h, levels=0, frame_slots=2, max_pairs=1)
 a = np.zeros((h, w), np.uint8)
 fb.set_frame(0, a)
 fb.set_frame(1, a)
-fb.calc_slots([0], [1])
+fb.calc_slots([0], [1])                   # the fused iteration kernel (8.3M pixels >= its threshold)
+os.environ["TF_FB_FUSED"] = "0"
+fb2 = Farneback(w, h, levels=0, frame_slots=2, max_pairs=1)   # the same as two kernels per iteration
+fb2.set_frame(0, a)
+fb2.set_frame(1, a)
+fb2.calc_slots([0], [1])
+del os.environ["TF_FB_FUSED"]
 for _ in range(5):
     fb.post_process(0, BACKWARD)          # k_pp_clip: N*8 read, N*8 written
 layer = RemapLayer(h, w)                   # k_remap_init: N*16 written

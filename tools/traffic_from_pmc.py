@@ -11,7 +11,8 @@ import json
 import sys
 
 PIXELS = 3840 * 2160
-KERNELS = {"fb_update_matrices": ("k_update_matrices", 1), "fb_blur_solve": ("k_blur_solve_wave", 1),
+KERNELS = {"fb_flow_iter": ("k_flow_iter_pc", 1), "fb_update_matrices": ("k_update_matrices", 1),
+           "fb_blur_solve": ("k_blur_solve_wave", 1),
            "fb_level_polyexp": ("k_level0_polyexp_t", 2), "pp_clip": ("k_pp_clip", 1)}
 
 

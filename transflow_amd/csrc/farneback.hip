@@ -1266,37 +1266,6 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
 }
 
 // ---------------------------------------------------------------------------------
-// A5 as its own (cheap) kernel for the fused iteration below: level flow =
-// resize(coarser flow, INTER_LINEAR) * 1/pyr_scale.
-// ---------------------------------------------------------------------------------
-__global__ void k_flow_upsample(float2 *__restrict__ dst, int Wk, int Hk, FlowInit fi)
-{
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= Wk || y >= Hk)
-        return;
-    const int pair = blockIdx.z;
-    const float2 *c = fi.src + (size_t)pair * fi.Wc * fi.Hc;
-    int sx = fi.xofs[x], sy = fi.yofs[y];
-    float fx = fi.xfrac[x], fy = fi.yfrac[y];
-    int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
-    float2 h0, h1;
-    if (sx >= fi.Wc - 1) {
-        h0 = c[(size_t)sy0 * fi.Wc + sx];
-        h1 = c[(size_t)sy1 * fi.Wc + sx];
-    } else {
-        float2 a = c[(size_t)sy0 * fi.Wc + sx], b = c[(size_t)sy0 * fi.Wc + sx + 1];
-        float2 d = c[(size_t)sy1 * fi.Wc + sx], e = c[(size_t)sy1 * fi.Wc + sx + 1];
-        float a0 = 1.f - fx;
-        h0 = make_float2(a.x * a0 + b.x * fx, a.y * a0 + b.y * fx);
-        h1 = make_float2(d.x * a0 + e.x * fx, d.y * a0 + e.y * fx);
-    }
-    float b0 = 1.f - fy;
-    dst[(size_t)pair * Wk * Hk + (size_t)y * Wk + x] =
-        make_float2((h0.x * b0 + h1.x * fy) * fi.mul, (h0.y * b0 + h1.y * fy) * fi.mul);
-}
-
-// ---------------------------------------------------------------------------------
 // One pixel of A3 split into "issue the loads" and "finish the arithmetic" (one column per lane),
 // so a marching wave can keep the gathers of later rows in flight: used by the producers of
 // k_flow_iter_pc below.  Same statements as update_matrix_px.
@@ -1389,35 +1358,40 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk,
 // ---------------------------------------------------------------------------------
 // A3+A4 fused, roles split inside the workgroup (the default on large levels).  Three waves march a strip
 // of 128 columns together: waves 0-1 are PRODUCERS (one column per lane: they compute row e of M
-// from R0, R1 and the flow -- gather1_issue / gather1_finish, two rows in flight -- and put it in an LDS
-// ring of 2M+3 rows), wave 2 is the CONSUMER (two columns per lane: it slides the vertical window
-// sums over the ring, exchanges them across lanes, solves and writes the flow: k_blur_solve_wave's
-// body).  One workgroup barrier per row: in step s the producers write row s while the consumer
-// works on row s-1, whose leaving row (s-1-(2M+1)) sits in a slot nobody writes before the next
-// barrier -- which is why the ring has 2M+3 slots, not 2M+1.  M is never stored: the window costs
-// 43 KB of LDS per 112 output columns (3 workgroups = 9 waves per CU).
+// from R0, R1 and the flow -- gather1_issue / gather1_finish, two rows in flight --, keep the window's
+// 2M+1 rows of their column in an LDS ring, slide the vertical window sum over it in double and
+// publish that sum), wave 2 is the CONSUMER (two columns per lane: it adds the sums across columns
+// -- pair sums through LDS, as k_blur_solve_wave --, solves and writes the flow).  One workgroup
+// barrier per row: in step s the producers publish row s while the consumer works on the sums of
+// step s-1 (double-buffered).  M is never stored: the window costs 38 KB of LDS per 112 output
+// columns, 50 KB per workgroup, 3 workgroups = 9 waves per CU.
 // ---------------------------------------------------------------------------------
-template <int M, bool HAVE_FLOW>
+// FLOW: where the iteration's input flow comes from -- 0: zero (coarsest scale), 1: flow_in, 2: A5 on the
+// fly, resize(coarser flow, INTER_LINEAR) * 1/pyr_scale through `fi` (the statements of k_flow_upsample;
+// the column's table entries are loaded once per lane, the row's are the same address for all lanes).
+template <int M, int FLOW>
 __global__ void __launch_bounds__(192)
 k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
-               int Hk, double scale, int seg)
+               int Hk, double scale, int seg, FlowInit fi)
 {
     static_assert(M & 1, "the pair-sum window needs an odd half-width");
 #ifndef TF_PC_PF
 #define TF_PC_PF 2
 #endif
-    constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1, NS = WIN + 2, PF = TF_PC_PF;
-    __shared__ float ring[NS][5][128];
-    __shared__ double s_e[5][64], s_o[5][64], s_p[5][64];
+    constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1, PF = TF_PC_PF;
+    __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
+    __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
+    __shared__ double s_p[5][64];         // the consumer's pair sums
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
     xcd_tile(bx, by);
     const int pair = blockIdx.z;
     const size_t Nk = (size_t)Wk * Hk;
     const int r0 = by * seg, r1 = min(r0 + seg, Hk);
-    // step s: producers make entering row e = r0 - M + s (s < n_rows); the consumer handles row s - 1
+    // step s: producers make entering row e = r0 - M + s (s < n_rows) and its window sums; the consumer
+    // turns the sums of step s - 1 into the flow of row r0 + (s - 1) - 2M
     const int n_rows = (r1 - r0) + 2 * M, nsteps = n_rows + 1;
-    for (int i = threadIdx.x; i < NS * 5 * 128; i += 192)
+    for (int i = threadIdx.x; i < WIN * 5 * 128; i += 192)
         (&ring[0][0][0])[i] = 0.f; // rows "above" the first window count as zero: the warm-up subtracts them
     __syncthreads();
     if (wave < 2) {
@@ -1429,12 +1403,39 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             pb.r0[c] = R + (size_t)pair * 10 * Nk + (size_t)c * Nk;
             pb.r1[c] = pb.r0[c] + 5 * Nk;
         }
-        const float2 *fin = HAVE_FLOW ? flow_in + (size_t)pair * Nk : nullptr;
+        const float2 *fin = FLOW == 1 ? flow_in + (size_t)pair * Nk : nullptr;
+        const float2 *coarse = FLOW == 2 ? fi.src + (size_t)pair * fi.Wc * fi.Hc : nullptr;
+        int up_sx = 0, up_sx1 = 0;
+        float up_fx = 0.f;
+        bool up_edge = false;
+        if (FLOW == 2) {
+            up_sx = fi.xofs[x];
+            up_fx = fi.xfrac[x];
+            up_edge = up_sx >= fi.Wc - 1; // resize.cpp: dx >= xmax copies S[sx]
+            up_sx1 = min(up_sx + 1, fi.Wc - 1);
+        }
         auto load_flow = [&](int row) {
-            if (!HAVE_FLOW)
+            if (FLOW == 0)
                 return make_float2(0.f, 0.f);
-            const unsigned off = ((unsigned)clampi(row, 0, Hk - 1) * Wk + x) * 8u;
-            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
+            row = clampi(row, 0, Hk - 1);
+            if (FLOW == 1) {
+                const unsigned off = ((unsigned)row * Wk + x) * 8u;
+                return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
+            }
+            const int sy = fi.yofs[row];
+            const float fy = fi.yfrac[row];
+            const int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
+            const float2 a = coarse[sy0 * fi.Wc + up_sx], b = coarse[sy0 * fi.Wc + up_sx1];
+            const float2 d = coarse[sy1 * fi.Wc + up_sx], e2 = coarse[sy1 * fi.Wc + up_sx1];
+            const float a0 = 1.f - up_fx;
+            float2 h0 = make_float2(a.x * a0 + b.x * up_fx, a.y * a0 + b.y * up_fx);
+            float2 h1 = make_float2(d.x * a0 + e2.x * up_fx, d.y * a0 + e2.y * up_fx);
+            if (up_edge) {
+                h0 = a;
+                h1 = d;
+            }
+            const float b0 = 1.f - fy;
+            return make_float2((h0.x * b0 + h1.x * fy) * fi.mul, (h0.y * b0 + h1.y * fy) * fi.mul);
         };
         Gather1 G[PF];
 #pragma unroll
@@ -1443,6 +1444,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             gather1_issue(G[t], pb, Wk, Hk, x, row, load_flow(row));
         }
         float2 F = load_flow(r0 - M + PF);
+        double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
         for (int sb = 0; sb < nsteps; sb += PF) {
 #pragma unroll
@@ -1456,10 +1458,16 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                     gather1_finish(G[h], Wk, Hk, x, clampi(e, 0, Hk - 1), m);
                     gather1_issue(G[h], pb, Wk, Hk, x, clampi(e + PF, 0, Hk - 1), F);
                     F = load_flow(e + PF + 1);
+                    // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
+                    // only this lane ever touches its column of the ring
 #pragma unroll
-                    for (int c = 0; c < 5; c++)
+                    for (int c = 0; c < 5; c++) {
+                        const float old = ring[slot][c][col];
                         ring[slot][c][col] = m[c];
-                    slot = slot + 1 == NS ? 0 : slot + 1;
+                        vs[c] += (double)m[c] - (double)old;
+                        s_v[s & 1][c][col] = vs[c];
+                    }
+                    slot = slot + 1 == WIN ? 0 : slot + 1;
                 }
                 lds_barrier();
             }
@@ -1467,54 +1475,37 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     } else {
         const int c0 = (int)bx * OUTC - HALO + 2 * lane;
         const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
-        double vs[5][2];
-#pragma unroll
-        for (int c = 0; c < 5; c++)
-            vs[c][0] = vs[c][1] = 0.0;
-        int slot_new = 0, slot_old = 2 % NS; // row s-1 and row s-1-WIN  ((s - 1 - WIN) mod NS == (s + 1) mod NS)
         for (int s = 0; s < nsteps; s++) {
-            if (s >= 1) {
+            const int y = r0 + (s - 1) - 2 * M; // the row whose window the producers completed in step s - 1
+            if (y >= r0) {                      // wave-uniform
+                const double(*sv)[128] = s_v[(s - 1) & 1];
 #pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const float2 nw = *reinterpret_cast<const float2 *>(&ring[slot_new][c][2 * lane]);
-                    const float2 od = *reinterpret_cast<const float2 *>(&ring[slot_old][c][2 * lane]);
-                    vs[c][0] += (double)nw.x - (double)od.x;
-                    vs[c][1] += (double)nw.y - (double)od.y;
-                }
-                slot_new = slot_new + 1 == NS ? 0 : slot_new + 1;
-                slot_old = slot_old + 1 == NS ? 0 : slot_old + 1;
-                const int y = r0 + (s - 1) - 2 * M; // the row whose window is now complete
-                if (y >= r0) {                      // wave-uniform
+                for (int c = 0; c < 5; c++)
+                    s_p[c][lane] = sv[c][2 * lane] + sv[c][2 * lane + 1];
+                lds_wave_sync(); // one wave writes and reads s_p: no workgroup barrier
+                if (is_out) {
+                    double g0[5], g1[5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        s_e[c][lane] = vs[c][0];
-                        s_o[c][lane] = vs[c][1];
-                        s_p[c][lane] = vs[c][0] + vs[c][1];
-                    }
-                    lds_wave_sync(); // one wave writes and reads these rows: no workgroup barrier
-                    if (is_out) {
-                        double g0[5], g1[5];
+                        // windows of columns 2l and 2l+1 as M whole pairs plus one single column at each end
+                        constexpr int hh = (M - 1) / 2, kk = (M + 1) / 2;
+                        double common = s_p[c][lane - hh];
 #pragma unroll
-                        for (int c = 0; c < 5; c++) {
-                            constexpr int hh = (M - 1) / 2, kk = (M + 1) / 2;
-                            double common = s_p[c][lane - hh];
-#pragma unroll
-                            for (int j = -hh + 1; j <= hh; j++)
-                                common += s_p[c][lane + j];
-                            g0[c] = (s_o[c][lane - kk] + common) * scale;
-                            g1[c] = (common + s_e[c][lane + kk]) * scale;
-                        }
-                        const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
-                        const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
-                        float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
-                        o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
-                                           (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
-                        if (c0 + 1 < Wk)
-                            o[1] = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
-                                               (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+                        for (int j = -hh + 1; j <= hh; j++)
+                            common += s_p[c][lane + j];
+                        g0[c] = (sv[c][2 * (lane - kk) + 1] + common) * scale;
+                        g1[c] = (common + sv[c][2 * (lane + kk)]) * scale;
                     }
-                    lds_wave_sync();
+                    const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
+                    const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
+                    float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
+                    o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
+                                       (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
+                    if (c0 + 1 < Wk)
+                        o[1] = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
+                                           (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
                 }
+                lds_wave_sync();
             }
             lds_barrier();
         }
@@ -2079,8 +2070,10 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, floa
                   (const float *)fb->Rk(0), w, h, m, scale, seg);
 }
 
+// `up`: the first iteration of a level below the coarsest takes its flow from the coarser level (A5 fused)
 template <int M>
-static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k)
+static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k,
+                            const FlowInit *up)
 {
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     const float *R = fb->Rk(k);
@@ -2108,22 +2101,28 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
         best_segs = std::max(1l, forced / std::max(1l, per_seg));
     const int seg = (int)((h + best_segs - 1) / best_segs);
     dim3 grid(strips, cdiv(h, seg), n_pairs);
+    FlowInit none;
+    memset(&none, 0, sizeof(none));
+    if (up)
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
+                      seg, *up);
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, true>, grid, dim3(192), 0, R, flow_in, flow_out, w, h,
-                      scale, seg);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, false>, grid, dim3(192), 0, R, flow_in, flow_out, w, h,
-                  scale, seg);
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
+                      seg, none);
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
+                  seg, none);
 }
 
 // true if the fused iteration kernel exists for this window; launches it
-static bool fb_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k, int &rc)
+static bool fb_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k, int &rc,
+                         const FlowInit *up = nullptr)
 {
     if (w < 2 || h < 2)
         return false;
     switch (fb->prm.winsize / 2) { // odd half-widths: the pair-sum window
-    case 3: rc = launch_flow_iter<3>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
-    case 5: rc = launch_flow_iter<5>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
-    case 7: rc = launch_flow_iter<7>(fb, w, h, n_pairs, flow_in, flow_out, k); return true;
+    case 3: rc = launch_flow_iter<3>(fb, w, h, n_pairs, flow_in, flow_out, k, up); return true;
+    case 5: rc = launch_flow_iter<5>(fb, w, h, n_pairs, flow_in, flow_out, k, up); return true;
+    case 7: rc = launch_flow_iter<7>(fb, w, h, n_pairs, flow_in, flow_out, k, up); return true;
     default: return false;
     }
 }
@@ -2390,17 +2389,13 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             // call's result buffer at full resolution, otherwise any buffer the coarser level is not in
             const int I = fb->prm.iterations;
             const int p = (k == 0 && overlap) ? out_buf : a, q = (k == 0 && overlap) ? a : b;
-            auto buf_of = [&](int i) { return ((I - i) & 1) ? q : p; }; // i = 0: the upsampled start, i >= 1: iteration i
+            auto buf_of = [&](int i) { return ((I - i) & 1) ? q : p; }; // what iteration i (1..I) writes
             const float2 *src = nullptr; // zero flow at the coarsest scale (flags == 0)
-            if (k < fb->K) {
-                dim3 g(cdiv(L.W, 64), cdiv(L.H, 4), n_pairs);
-                TF_TRY(launch(lvl_name("fb_flow_upsample", k), k_flow_upsample, g, dim3(256), 0,
-                              fb->lflow[buf_of(0)].as<float2>(), L.W, L.H, fi));
-                src = fb->lflow[buf_of(0)].as<float2>();
-            }
             for (int i = 1; i <= I; i++) {
                 int rc = TF_OK;
-                fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[buf_of(i)].as<float2>(), k, rc);
+                // the first iteration below the coarsest scale upsamples the coarser level's flow itself
+                fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[buf_of(i)].as<float2>(), k, rc,
+                             (i == 1 && k < fb->K) ? &fi : nullptr);
                 TF_TRY(rc);
                 src = fb->lflow[buf_of(i)].as<float2>();
             }
