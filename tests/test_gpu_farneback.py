@@ -201,6 +201,33 @@ def test_pipelined_calls_equal_single_calls(FB):
     fb.close()
 
 
+def test_fused_and_two_kernel_iterations_agree(FB, monkeypatch):
+    """The same pyramid with the iteration as one kernel on every level (TF_FB_FUSED=1), as two kernels on
+    every level (=0) and with the default per-level choice: identical algorithm, different summation
+    order in the window sums and a different reciprocal -- far inside the path's 1e-4 tolerance, and
+    each within tolerance of the oracle."""
+    h, w = 540, 960
+    a, b = synth_pair(h, w, seed=80, shift=(2.5, 1.5))
+    ref = O.calc(a, b, levels=3)
+    out = {}
+    for mode in ("1", "0", None):
+        if mode is None:
+            monkeypatch.delenv("TF_FB_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("TF_FB_FUSED", mode)      # read when the handle is created
+        fb = FB(w, h, levels=3, max_pairs=12, frame_slots=2)   # 12 pairs: level 0 crosses the 4M-pixel threshold
+        fb.set_frame(0, a)
+        fb.set_frame(1, b)
+        fb.calc_slots([0] * 12, [1] * 12)
+        out[mode] = fb.get_flow(5)
+        np.testing.assert_array_equal(out[mode], fb.get_flow(11))      # every pair of the batch alike
+        assert np.abs(out[mode] - ref).max() <= flow_tol(ref)
+        fb.close()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out["1"] - out["0"]).max() <= 2e-5 * scale
+    assert np.abs(out[None] - out["0"]).max() <= 2e-5 * scale
+
+
 def test_strided_input_and_errors(FB):
     h, w = 64, 96
     a, b = synth_pair(h, w + 8, seed=60)
