@@ -629,6 +629,86 @@ k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk
     }
 }
 
+// The two passes of FarnebackPolyExp over a blurred level tile held in LDS (sI, indexed by real level
+// coordinates relative to (xr0, yr0); virtual coordinates outside the level clamp, as OpenCV
+// replicates edge rows/columns of the level image): shared by the fused level-0 and level-1 kernels.
+// W, H: the LEVEL's size.  Call with sI complete and the workgroup synchronised.
+template <int N, int TW, int TH>
+__device__ __forceinline__ void tile_expansion(const float *sI, float (*sT)[TH][TW + 2 * N], int x0, int y0, int xr0,
+                                               int yr0, int W, int H, const PolyConst &pc, float *dst, size_t Nk)
+{
+    constexpr int LW = TW + 2 * N;
+    // polynomial expansion, vertical pass: virtual row y0-N+j reads real row clamp(...) - yr0
+    // (an interior tile reads rows/columns 4g+j / cx directly; a border tile clamps them)
+    const bool interior = x0 - N >= 0 && x0 + TW - 1 + N <= W - 1 && y0 - N >= 0 && y0 + TH - 1 + N <= H - 1;
+    for (int idx = threadIdx.x; idx < (TH / 4) * (LW / 2); idx += 256) {
+        const int g = idx / (LW / 2), cx = 2 * (idx - g * (LW / 2));
+        f32x2 v[4 + 2 * N];
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * N; j++)
+                v[j] = *reinterpret_cast<const f32x2 *>(&sI[(4 * g + j) * LW + cx]);
+        } else {
+            const int xa = clampi(x0 - N + cx, 0, W - 1) - xr0, xb = clampi(x0 - N + cx + 1, 0, W - 1) - xr0;
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * N; j++) {
+                const float *row = sI + (clampi(y0 - N + 4 * g + j, 0, H - 1) - yr0) * LW;
+                v[j] = f32x2{row[xa], row[xb]};
+            }
+        }
+        polyexp_vertical4<N>(v, pc, &sT[0][4 * g][cx], &sT[1][4 * g][cx], &sT[2][4 * g][cx], LW);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TH * (TW / 2); idx += 256) {
+        const int ty = idx / (TW / 2), cp = idx - ty * (TW / 2);
+        const int x = x0 + 2 * cp, y = y0 + ty;
+        if (x >= W || y >= H)
+            continue;
+        float w0[2 + 2 * N], w1[2 + 2 * N], w2[2 + 2 * N];
+#pragma unroll
+        for (int j = 0; j < 2 + 2 * N; j++) {
+            w0[j] = sT[0][ty][2 * cp + j];
+            w1[j] = sT[1][ty][2 * cp + j];
+            w2[j] = sT[2][ty][2 * cp + j];
+        }
+        float out[2][5];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float *T0 = w0 + q + N, *T1 = w1 + q + N, *T2 = w2 + q + N;
+            float g0 = pc.g[0];
+            double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                double tg = T0[k] + T0[-k];
+                g0 = pc.g[k];
+                b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+                b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
+                b2 += (T0[k] - T0[-k]) * pc.xg[k];
+                b3 += (T1[k] + T1[-k]) * g0;
+                b6 += (T1[k] - T1[-k]) * pc.xg[k];
+                b5 += (T2[k] + T2[-k]) * g0;
+            }
+            out[q][0] = (float)(b3 * pc.ig11);
+            out[q][1] = (float)(b2 * pc.ig11);
+            out[q][2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            out[q][3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            out[q][4] = (float)(b6 * pc.ig55);
+        }
+        const size_t o = (size_t)y * W + x;
+        if (x + 1 < W) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                float2w v2 = {out[0][c], out[1][c]};
+                *reinterpret_cast<float2w *>(dst + c * Nk + o) = v2;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                dst[c * Nk + o] = out[0][c];
+        }
+    }
+}
+
 // A1+A2 fused for the full-resolution level (resize is a copy, the blur has 3 taps): the level
 // image never leaves the CU.  Stages the u8 region by REAL image coordinates (REFLECT_101 ring of
 // one pixel), blurs it into LDS exactly as k_level_image does (row pass, then column pass), then
@@ -726,76 +806,109 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
         }
     }
     __syncthreads();
-    // polynomial expansion, vertical pass: virtual row y0-N+j reads real row clamp(...) - yr0
-    // (an interior tile reads rows/columns 4g+j / cx directly; a border tile clamps them)
-    const bool interior = x0 - N >= 0 && x0 + TW - 1 + N <= W - 1 && y0 - N >= 0 && y0 + TH - 1 + N <= H - 1;
-    for (int idx = threadIdx.x; idx < (TH / 4) * (LW / 2); idx += 256) {
-        const int g = idx / (LW / 2), cx = 2 * (idx - g * (LW / 2));
-        f32x2 v[4 + 2 * N];
-        if (interior) {
+    tile_expansion<N, TW, TH>(sI, sT, x0, y0, xr0, yr0, W, H, pc, R + (size_t)pi * 5 * Nk, Nk);
+}
+
+// A1+A2 fused for a level that is exactly half the frame in both directions with the 3-tap blur
+// (level 1 of a pyr_scale = 0.5 pyramid over even frame sizes).  resize.cpp's coordinates are then
+// (2X, 2Y) with both fractions exactly 0.5, so a level pixel is the lerp of the blurred frame at a 2x2
+// block, each of those a 3x3 separable blur: computed per level pixel from its 4x4 bytes with
+// k_level_image's statements (row pass, column pass centre-then-pair, horizontal lerp, vertical
+// lerp); the level image never leaves the CU.  Then the expansion passes shared with level 0.
+template <int N>
+__global__ void __launch_bounds__(256)
+k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ R, int W,
+                   int H, float kc, float k1, PolyConst pc)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 2 * N, LH = TH + 2 * N;
+    constexpr int SW = ((2 * LW + 2 + 3 + 3) + 3) & ~3, SH = 2 * LH + 2; // staged bytes: 2 per level pixel + 1 all round
+    constexpr int BYTES_A = SH * SW, BYTES_T = 3 * TH * LW * 4;
+    constexpr int BYTES_U = ((BYTES_A > BYTES_T ? BYTES_A : BYTES_T) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) uint8_t s_u[BYTES_U];
+    __shared__ float sI[LH * LW];
+    uint8_t *sS = s_u;
+    float(*sT)[TH][LW] = reinterpret_cast<float(*)[TH][LW]>(s_u);
+    const int Wk = W >> 1, Hk = H >> 1;
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const size_t Nk = (size_t)Wk * Hk;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xr0 = max(x0 - N, 0), xr1 = min(x0 + TW - 1 + N, Wk - 1);
+    const int yr0 = max(y0 - N, 0), yr1 = min(y0 + TH - 1 + N, Hk - 1);
+    const int nx = xr1 - xr0 + 1, ny = yr1 - yr0 + 1;
+    // frame bytes: columns 2*xr0-1 .. 2*xr1+2, rows 2*yr0-1 .. 2*yr1+2 (REFLECT_101 outside the frame)
+    const int cfirst = 2 * xr0 - 1, rfirst = 2 * yr0 - 1, nrows = 2 * ny + 2;
+    const int xs = cfirst >= 0 ? (cfirst & ~3) : cfirst, off = cfirst - xs;
+    const int ncols = 2 * xr1 + 2 - xs + 1;
+    const bool dwords = (W & 3) == 0 && xs >= 0 && (xs & 3) == 0 && xs + ((ncols + 3) & ~3) <= W;
+    constexpr int U = 8;
+    if (dwords) {
+        const int nq = (ncols + 3) >> 2;
+        for (int c = lane; c < nq; c += 64) {
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint32_t v[U];
 #pragma unroll
-            for (int j = 0; j < 4 + 2 * N; j++)
-                v[j] = *reinterpret_cast<const f32x2 *>(&sI[(4 * g + j) * LW + cx]);
-        } else {
-            const int xa = clampi(x0 - N + cx, 0, W - 1) - xr0, xb = clampi(x0 - N + cx + 1, 0, W - 1) - xr0;
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101(rfirst + ry, H) * W + xs + 4 * c);
+                }
 #pragma unroll
-            for (int j = 0; j < 4 + 2 * N; j++) {
-                const float *row = sI + (clampi(y0 - N + 4 * g + j, 0, H - 1) - yr0) * LW;
-                v[j] = f32x2{row[xa], row[xb]};
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        *reinterpret_cast<uint32_t *>(sS + ry * SW + 4 * c) = v[u];
+                }
             }
         }
-        polyexp_vertical4<N>(v, pc, &sT[0][4 * g][cx], &sT[1][4 * g][cx], &sT[2][4 * g][cx], LW);
+    } else {
+        for (int c = lane; c < ncols; c += 64) {
+            const int x = reflect101(xs + c, W);
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint8_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = src[(size_t)reflect101(rfirst + ry, H) * W + x];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        sS[ry * SW + c] = v[u];
+                }
+            }
+        }
     }
     __syncthreads();
-    float *dst = R + (size_t)pi * 5 * Nk;
-    for (int idx = threadIdx.x; idx < TH * (TW / 2); idx += 256) {
-        const int ty = idx / (TW / 2), cp = idx - ty * (TW / 2);
-        const int x = x0 + 2 * cp, y = y0 + ty;
-        if (x >= W || y >= H)
+    // level pixel (xr0 + cx, yr0 + ry): frame rows 2Y-1 .. 2Y+2 are staged rows 2*ry .. 2*ry+3, frame
+    // columns 2X-1 .. 2X+2 staged bytes off + 2*cx .. +3
+    for (int idx = threadIdx.x; idx < ny * LW; idx += 256) {
+        const int ry = idx / LW, cx = idx - ry * LW;
+        if (cx >= nx)
             continue;
-        float w0[2 + 2 * N], w1[2 + 2 * N], w2[2 + 2 * N];
+        const uint8_t *p = sS + (2 * ry) * SW + off + 2 * cx;
+        float r[4][2];
 #pragma unroll
-        for (int j = 0; j < 2 + 2 * N; j++) {
-            w0[j] = sT[0][ty][2 * cp + j];
-            w1[j] = sT[1][ty][2 * cp + j];
-            w2[j] = sT[2][ty][2 * cp + j];
+        for (int dy = 0; dy < 4; dy++) {
+            const uint8_t *q = p + dy * SW;
+            const float b0 = (float)q[0], b1 = (float)q[1], b2 = (float)q[2], b3 = (float)q[3];
+            r[dy][0] = b1 * kc + (b0 + b2) * k1; // row pass at frame column 2X
+            r[dy][1] = b2 * kc + (b1 + b3) * k1; //                         2X+1
         }
-        float out[2][5];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const float *T0 = w0 + q + N, *T1 = w1 + q + N, *T2 = w2 + q + N;
-            float g0 = pc.g[0];
-            double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
-#pragma unroll
-            for (int k = 1; k <= N; k++) {
-                double tg = T0[k] + T0[-k];
-                g0 = pc.g[k];
-                b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
-                b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
-                b2 += (T0[k] - T0[-k]) * pc.xg[k];
-                b3 += (T1[k] + T1[-k]) * g0;
-                b6 += (T1[k] - T1[-k]) * pc.xg[k];
-                b5 += (T2[k] + T2[-k]) * g0;
-            }
-            out[q][0] = (float)(b3 * pc.ig11);
-            out[q][1] = (float)(b2 * pc.ig11);
-            out[q][2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-            out[q][3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-            out[q][4] = (float)(b6 * pc.ig55);
-        }
-        const size_t o = (size_t)y * W + x;
-        if (x + 1 < W) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                float2w v2 = {out[0][c], out[1][c]};
-                *reinterpret_cast<float2w *>(dst + c * Nk + o) = v2;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 5; c++)
-                dst[c * Nk + o] = out[0][c];
-        }
+        float v00 = kc * r[1][0], v01 = kc * r[1][1], v10 = kc * r[2][0], v11 = kc * r[2][1];
+        v00 += k1 * (r[2][0] + r[0][0]); // column pass at frame row 2Y: centre, then (row+1 + row-1)
+        v01 += k1 * (r[2][1] + r[0][1]);
+        v10 += k1 * (r[3][0] + r[1][0]); //                          2Y+1
+        v11 += k1 * (r[3][1] + r[1][1]);
+        const float h0 = v00 * (1.f - 0.5f) + v01 * 0.5f, h1 = v10 * (1.f - 0.5f) + v11 * 0.5f;
+        sI[idx] = h0 * (1.f - 0.5f) + h1 * 0.5f;
     }
+    __syncthreads();
+    tile_expansion<N, TW, TH>(sI, sT, x0, y0, xr0, yr0, Wk, Hk, pc, R + (size_t)pi * 5 * Nk, Nk);
 }
 
 // OpenCV's border down-weighting table {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance d to an
@@ -2002,6 +2115,28 @@ static bool fb_can_fuse_level(tf_fb *fb, int k)
     return !off && L.W == fb->W && L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
 }
 
+// ... and to a level that is exactly half the frame (k_level1_polyexp_t)
+static bool fb_can_fuse_half_level(tf_fb *fb, int k)
+{
+    static const bool off = getenv("TF_FB_NO_A1A2") && atoi(getenv("TF_FB_NO_A1A2")) != 0;
+    const Level &L = *fb->lv[k];
+    return !off && 2 * L.W == fb->W && 2 * L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
+}
+
+static int fb_level1_polyexp(tf_fb *fb, int k, int n_pairs)
+{
+    Level &L = *fb->lv[k];
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
+    const float kc = L.kern_host[1], k1 = L.kern_host[2];
+    if (fb->pc.n == 5)
+        return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), prep_pad(fb),
+                      (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), fb->W,
+                      fb->H, kc, k1, fb->pc);
+    return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<7>, grid, dim3(256), prep_pad(fb),
+                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), fb->W, fb->H,
+                  kc, k1, fb->pc);
+}
+
 static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
 {
     Level &L = *fb->lv[k];
@@ -2339,6 +2474,8 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             Level &L = *fb->lv[k];
             if (fb_can_fuse_level(fb, k)) {
                 TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
+            } else if (fb_can_fuse_half_level(fb, k)) {
+                TF_TRY(fb_level1_polyexp(fb, k, n_pairs));
             } else {
                 TF_TRY(fb_level_image(fb, k, n_pairs));
                 TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
@@ -2597,6 +2734,8 @@ TF_API int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t s
     Level &L = *fb->lv[level];
     if (fb_can_fuse_level(fb, level)) {
         TF_TRY(fb_level0_polyexp(fb, level, 1));
+    } else if (fb_can_fuse_half_level(fb, level)) {
+        TF_TRY(fb_level1_polyexp(fb, level, 1));
     } else {
         TF_TRY(fb_level_image(fb, level, 1));
         TF_TRY(fb_polyexp(fb, L.W, L.H, 2, level));
