@@ -438,6 +438,194 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
 }
 
 // ---------------------------------------------------------------------------------
+// A1 for the levels with long blur kernels (ksz >= 15: scale 1/8 and coarser), as two kernels.
+// One tile of such a level depends on a frame region of (tile * scale + ksz)^2 bytes, so
+// k_level_image's tiles shrink to a few dozen outputs and its fixed costs per workgroup dominate.
+// Here the row pass runs over whole frame rows (k_level_rowpass: every lane busy, the frame read
+// once) into a [H][2*Wk] float plane per image, and the column pass + both lerps read that plane
+// through an LDS tile (k_level_colpass).  Same statements in the same order as k_level_image:
+// row pass left to right, column pass centre then pairs outwards, horizontal then vertical lerp.
+// ---------------------------------------------------------------------------------
+// lanes = R rows x (64/R) groups of two interpolation pairs; with the row pitch = 1 (mod R) dwords and
+// the groups 64/R... dwords apart the 64 aligned-dword reads of one instruction fall in 64 banks
+__global__ void __launch_bounds__(256)
+k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ rowf, int W,
+                int H, int NC, const int *__restrict__ colsrc, const float *__restrict__ kern, int ksz, int RB, int pitch,
+                int r4, int rshift)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rp[];
+    uint8_t *sS = s_rp;                                                   // [RB][pitch]: r4 + column c at byte r4 + c
+    float *sK = reinterpret_cast<float *>(s_rp + (size_t)RB * pitch);      // [ksz]
+    const int r = ksz >> 1;
+    const int pi = blockIdx.y;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const int y0 = blockIdx.x * RB, nrows = min(RB, H - y0);
+    for (int i = threadIdx.x; i < ksz; i += 256)
+        sK[i] = kern[i];
+    // stage nrows frame rows: the interior as dwords (W % 4 == 0 is required by the host), r reflected bytes each side
+    const int nq = W >> 2;
+    for (int idx = threadIdx.x; idx < nrows * nq; idx += 256) {
+        const int i = idx / nq, c = idx - i * nq;
+        *reinterpret_cast<uint32_t *>(sS + i * pitch + r4 + 4 * c) =
+            *reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + i) * W + 4 * c);
+    }
+    for (int idx = threadIdx.x; idx < nrows * 2 * r; idx += 256) {
+        const int i = idx / (2 * r), j = idx - i * 2 * r;
+        const int c = j < r ? j - r : W + (j - r); // -r..-1, W..W+r-1
+        sS[i * pitch + r4 + c] = src[(size_t)(y0 + i) * W + reflect101(c, W)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = 1 << rshift, G = 64 >> rshift;
+    const int li = lane & (R - 1), lg = lane >> rshift;
+    const int ngroups = (NC + 3) >> 2;
+    const int n_rb = (nrows + R - 1) >> rshift, n_gb = (ngroups + G - 1) / G;
+    for (int item = wave; item < n_rb * n_gb; item += 4) {
+        const int gb = item % n_gb, rb = item / n_gb;
+        const int row = rb * R + li, grp = gb * G + lg;
+        if (row >= nrows || grp >= ngroups)
+            continue;
+        const int oA = 4 * grp, oB = min(4 * grp + 2, NC - 2);
+        const int cA = colsrc[oA], cB = colsrc[oB];
+        const bool dupA = colsrc[oA + 1] == cA, dupB = colsrc[oB + 1] == cB; // pair at the right frame border: sx+1 clamps to sx
+        const int a0 = r4 + cA - r, b0 = r4 + cB - r;
+        const int da = a0 >> 2, db = b0 >> 2;
+        const unsigned sa = a0 & 3, sb = b0 & 3;
+        const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + row * pitch);
+        uint32_t loA = q32[da], loB = q32[db], hiA = q32[da + 1], hiB = q32[db + 1];
+        uint32_t wA = __builtin_amdgcn_alignbyte(hiA, loA, sa), wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+        f32x2 p0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+        f32x2 p1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+        f32x2 p2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+        f32x2 p3 = {(float)(wA >> 24), (float)(wB >> 24)};
+        f32x2 acc0, acc1; // {A, B} and {A+1, B+1}
+        int i = 0, t = 2;
+        for (; i + 4 <= ksz; i += 4, t++) {
+            loA = hiA;
+            loB = hiB;
+            hiA = q32[da + t];
+            hiB = q32[db + t];
+            wA = __builtin_amdgcn_alignbyte(hiA, loA, sa);
+            wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+            const f32x2 c0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+            const f32x2 c1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+            const f32x2 c2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+            const f32x2 c3 = {(float)(wA >> 24), (float)(wB >> 24)};
+            const float t0 = sK[i], t1 = sK[i + 1], t2 = sK[i + 2], t3 = sK[i + 3];
+            if (i == 0) {
+                acc0 = t0 * p0;
+                acc1 = t0 * p1;
+            } else {
+                acc0 += t0 * p0;
+                acc1 += t0 * p1;
+            }
+            acc0 += t1 * p1;
+            acc1 += t1 * p2;
+            acc0 += t2 * p2;
+            acc1 += t2 * p3;
+            acc0 += t3 * p3;
+            acc1 += t3 * c0;
+            p0 = c0;
+            p1 = c1;
+            p2 = c2;
+            p3 = c3;
+        }
+        if (i < ksz) { // up to three taps left; they need p0..p3 only
+            float tt = sK[i];
+            acc0 += tt * p0;
+            acc1 += tt * p1;
+            if (i + 1 < ksz) {
+                tt = sK[i + 1];
+                acc0 += tt * p1;
+                acc1 += tt * p2;
+            }
+            if (i + 2 < ksz) {
+                tt = sK[i + 2];
+                acc0 += tt * p2;
+                acc1 += tt * p3;
+            }
+        }
+        // a clamped pair reads the same column twice: the same sum
+        if (dupA)
+            acc1.x = acc0.x;
+        if (dupB)
+            acc1.y = acc0.y;
+        float *out = rowf + ((size_t)pi * H + y0 + row) * NC + 4 * grp;
+        out[0] = acc0.x;
+        out[1] = acc1.x;
+        if (4 * grp + 2 < NC) {
+            out[2] = acc0.y;
+            out[3] = acc1.y;
+        }
+    }
+}
+
+// tile of CP_TX x THo outputs; LDS holds the rows of the row-pass plane their column sums touch
+constexpr int CP_TX = 32;
+
+__global__ void __launch_bounds__(256)
+k_level_colpass(const float *__restrict__ rowf, float *__restrict__ img, int W, int H, int Wk, int Hk, int NC,
+                const float *__restrict__ kern, int ksz, const int *__restrict__ xofs, const float *__restrict__ xfrac,
+                const int *__restrict__ yofs, const float *__restrict__ yfrac, int THo, int LH)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_cp[];
+    constexpr int ST = 2 * CP_TX;
+    float *sR = reinterpret_cast<float *>(s_cp);          // [LH][ST]
+    float *sK = sR + (size_t)LH * ST;                     // [ksz]
+    const int r = ksz >> 1;
+    const int pi = blockIdx.z;
+    const int dx0 = blockIdx.x * CP_TX, dy0 = blockIdx.y * THo;
+    const int ndx = min(CP_TX, Wk - dx0), ndy = min(THo, Hk - dy0);
+    for (int i = threadIdx.x; i < ksz; i += 256)
+        sK[i] = kern[i];
+    const int y_lo = clampi(yofs[dy0], 0, H - 1) - r, y_hi = clampi(yofs[dy0 + ndy - 1] + 1, 0, H - 1) + r;
+    const int nrows = y_hi - y_lo + 1;
+    const float *plane = rowf + (size_t)pi * H * NC + 2 * dx0;
+    for (int idx = threadIdx.x; idx < nrows * ndx; idx += 256) {
+        const int j = idx / ndx, c = idx - j * ndx;
+        const float2 v = *reinterpret_cast<const float2 *>(plane + (size_t)reflect101(y_lo + j, H) * NC + 2 * c);
+        *reinterpret_cast<float2 *>(sR + j * ST + 2 * c) = v;
+    }
+    __syncthreads();
+    const float kc = sK[r];
+    float *dst = img + (size_t)pi * Wk * Hk;
+    for (int idx = threadIdx.x; idx < ndy * CP_TX; idx += 256) {
+        const int ty = idx / CP_TX, tx = idx - ty * CP_TX;
+        if (tx >= ndx)
+            continue;
+        const int dx = dx0 + tx, dy = dy0 + ty;
+        const int sy = yofs[dy];
+        const int row0 = clampi(sy, 0, H - 1) - y_lo, row1 = clampi(sy + 1, 0, H - 1) - y_lo;
+        const float *c0 = sR + row0 * ST + 2 * tx, *c1 = sR + row1 * ST + 2 * tx;
+        float v00 = kc * c0[0], v01 = kc * c0[1];
+        for (int i = 1; i <= r; i++) {
+            v00 += sK[r + i] * (c0[i * ST] + c0[-i * ST]);
+            v01 += sK[r + i] * (c0[i * ST + 1] + c0[-i * ST + 1]);
+        }
+        float v10 = v00, v11 = v01;
+        if (row1 != row0) {
+            v10 = kc * c1[0];
+            v11 = kc * c1[1];
+            for (int i = 1; i <= r; i++) {
+                v10 += sK[r + i] * (c1[i * ST] + c1[-i * ST]);
+                v11 += sK[r + i] * (c1[i * ST + 1] + c1[-i * ST + 1]);
+            }
+        }
+        const float fx = xfrac[dx], fy = yfrac[dy];
+        float h0, h1;
+        if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+            h0 = v00;
+            h1 = v10;
+        } else {
+            h0 = v00 * (1.f - fx) + v01 * fx;
+            h1 = v10 * (1.f - fx) + v11 * fx;
+        }
+        dst[(size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // A2: FarnebackPolyExp.  Tile 64x16 outputs; LDS holds the image tile with an
 // n-pixel halo, then the three vertical-pass planes; the horizontal pass runs in
 // double.  Clamped loads reproduce OpenCV's row clamping (vertical) and its
@@ -1902,6 +2090,10 @@ struct Level {
     DevBuf img, R[2];           // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
     hipEvent_t ready = nullptr; // recorded on the preparation stream once R is complete
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
+    // long blur kernels: row pass over whole frame rows, then column pass + lerps (k_level_rowpass / _colpass)
+    bool split = false;
+    DevBuf colsrc;          // source column of each of the NC = 2*W row-pass columns
+    int NC = 0, rp_RB = 0, rp_pitch = 0, rp_r4 = 0, rp_rshift = 0, cp_THo = 0, cp_LH = 0;
     LerpDev flow_lerp; // level k+1 -> this level
 };
 
@@ -1917,6 +2109,7 @@ struct tf_fb {
     // R exists twice when the preparation stream is in use: call i+1 expands its frames into one set
     // while the flow chain of call i still reads the other (`cur` = the set of the call being issued)
     DevBuf frames, img, R[2], M[2], lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
+    DevBuf rowf; // row-pass plane of the split levels, [image][H][NC], one level at a time
     int nsets = 1, cur = 0;
     hipStream_t prep_stream = nullptr;         // A1+A2 of every level run here, ahead of and beside the flow chain
     hipStream_t chain_stream = nullptr;        // the flow chain; the library stream only waits for its end, so what the
@@ -1995,12 +2188,85 @@ static size_t prep_pad(const tf_fb *fb, bool image_kernel = false)
 static int fb_level_image(tf_fb *fb, int k, int n_pairs)
 {
     Level &L = *fb->lv[k];
+    if (L.split) {
+        const size_t smem_rp = (size_t)L.rp_RB * L.rp_pitch + (size_t)L.ksz * sizeof(float);
+        TF_TRY(launch(lvl_name("fb_level_rowpass", k), k_level_rowpass, dim3(cdiv(fb->H, L.rp_RB), n_pairs * 2), dim3(256),
+                      smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(),
+                      fb->rowf.as<float>(), fb->W, fb->H, L.NC, (const int *)L.colsrc.as<int>(),
+                      (const float *)L.kern.as<float>(), L.ksz, L.rp_RB, L.rp_pitch, L.rp_r4, L.rp_rshift));
+        const size_t smem_cp = ((size_t)L.cp_LH * 2 * CP_TX + L.ksz) * sizeof(float);
+        return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, CP_TX), cdiv(L.H, L.cp_THo), n_pairs * 2),
+                      dim3(256), smem_cp, (const float *)fb->rowf.as<float>(), fb->imgk(k), fb->W, fb->H, L.W, L.H, L.NC,
+                      (const float *)L.kern.as<float>(), L.ksz, (const int *)L.img_lerp.xofs.as<int>(),
+                      (const float *)L.img_lerp.xfrac.as<float>(), (const int *)L.img_lerp.yofs.as<int>(),
+                      (const float *)L.img_lerp.yfrac.as<float>(), L.cp_THo, L.cp_LH);
+    }
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
     return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), std::min<size_t>(smem + prep_pad(fb, true), 64 * 1024),
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->imgk(k),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
+}
+
+// Plans the two-kernel form of A1 for a level with a long blur kernel (returns false where it does not
+// apply: short kernels, frame widths that are not a multiple of 4, frames too wide to stage 8 rows).
+static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
+{
+    static const bool off = getenv("TF_IMG_NO_SPLIT") && atoi(getenv("TF_IMG_NO_SPLIT")) != 0;
+    static const int min_ksz = getenv("TF_IMG_SPLIT_MIN_KSZ") ? atoi(getenv("TF_IMG_SPLIT_MIN_KSZ")) : 15;
+    if (off || L.ksz < min_ksz || L.ksz <= 5 || (W & 3) != 0 || (L.W == W && L.H == H))
+        return false;
+    std::vector<int> xo, yo;
+    std::vector<float> fr;
+    make_lerp(W, L.W, true, xo, fr);
+    make_lerp(H, L.H, false, yo, fr);
+    const int r = L.ksz / 2;
+    L.NC = 2 * L.W;
+    colsrc.resize((size_t)L.NC);
+    for (int x = 0; x < L.W; x++) {
+        colsrc[2 * x] = xo[x];
+        colsrc[2 * x + 1] = std::min(xo[x] + 1, W - 1);
+    }
+    // lanes = R rows x 64/R groups; one group = two level columns = s/2 dwords of a frame row
+    const int s_ = std::max(1, W / std::max(1, L.W));
+    int rshift = 1;
+    while ((1 << rshift) < std::min(8, std::max(2, s_ / 2)))
+        rshift++;
+    const int R = 1 << rshift;
+    L.rp_rshift = rshift;
+    L.rp_r4 = (r + 3) & ~3;
+    int pitch = (L.rp_r4 + W + r + 8 + 3) & ~3; // the dword stream may run a few bytes past the last tap
+    while (((pitch / 4) % R) != 1)
+        pitch += 4;
+    L.rp_pitch = pitch;
+    int RB = (int)((40 * 1024) / pitch) & ~(R - 1);
+    if (RB < R)
+        return false;
+    L.rp_RB = std::min(RB, 64);
+    // column pass: CP_TX x THo outputs, rows of the plane in LDS.  Small tiles win (measured at 4K x 16:
+    // 16 / 24 / 32 / 40 / 56 KB of LDS -> 100 / 117 / 123 / 144 / 235 us at level 3): as many output rows
+    // as fit ~20 KB, a single one where even that does not fit
+    static const size_t cp_cap = (getenv("TF_CP_LDS_KB") ? (size_t)atoi(getenv("TF_CP_LDS_KB")) : 20) * 1024;
+    int best = 0, best_lh = 0;
+    for (int tho = 1; tho <= 32; tho++) {
+        int worst = 0;
+        for (int d0 = 0; d0 < L.H; d0 += tho) {
+            const int d1 = std::min(L.H, d0 + tho) - 1;
+            const int lo = std::max(0, std::min(yo[d0], H - 1)) - r, hi = std::max(0, std::min(yo[d1] + 1, H - 1)) + r;
+            worst = std::max(worst, hi - lo + 1);
+        }
+        const size_t bytes = ((size_t)worst * 2 * CP_TX + L.ksz) * sizeof(float);
+        if (bytes <= cp_cap || (tho == 1 && bytes <= 56 * 1024)) {
+            best = tho;
+            best_lh = worst;
+        }
+    }
+    if (!best)
+        return false;
+    L.cp_THo = best;
+    L.cp_LH = best_lh;
+    return true;
 }
 
 // Output tile of a level: as large as fits ~60 KB of LDS, given the source extent a tile needs.
@@ -2329,6 +2595,16 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         if ((rc = L->img_lerp.upload_tabs(width, height, L->W, L->H)))
             return fail(rc);
         L->tile = choose_tile(width, height, L->W, L->H, L->ksz, k);
+        {
+            std::vector<int> colsrc;
+            L->split = plan_split_level(width, height, *L, colsrc);
+            if (L->split) {
+                if ((rc = L->colsrc.alloc(colsrc.size() * 4)))
+                    return fail(rc);
+                if (hipMemcpy(L->colsrc.p, colsrc.data(), colsrc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(set_error(TF_ERR_HIP, "hipMemcpy failed"));
+            }
+        }
         if (getenv("TF_DEBUG_TILES"))
             fprintf(stderr, "level %d: %dx%d ksz=%d tile %dx%d LW=%d LH=%d pitch=%d\n", k, L->W, L->H, L->ksz,
                     L->tile.TWo, L->tile.THo, L->tile.LW, L->tile.LH, L->tile.pitch);
@@ -2360,6 +2636,14 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         const size_t nk = (size_t)L.W * L.H;
         if ((rc = L.img.alloc(P * 2 * nk * 4)) || (rc = L.R[0].alloc(P * 10 * nk * 4)) ||
             (fb->nsets > 1 && (rc = L.R[1].alloc(P * 10 * nk * 4))))
+            return fail(rc);
+    }
+    {
+        size_t rowf_bytes = 0;
+        for (int k = 1; k <= fb->K; k++)
+            if (fb->lv[k]->split)
+                rowf_bytes = std::max(rowf_bytes, P * 2 * (size_t)height * fb->lv[k]->NC * 4);
+        if (rowf_bytes && (rc = fb->rowf.alloc(rowf_bytes)))
             return fail(rc);
     }
     for (int k = 0; k <= fb->K; k++)
