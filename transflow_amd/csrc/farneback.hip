@@ -447,116 +447,141 @@ k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs
 // row pass left to right, column pass centre then pairs outwards, horizontal then vertical lerp.
 // ---------------------------------------------------------------------------------
 // lanes = R rows x (64/R) groups of two interpolation pairs; with the row pitch = 1 (mod R) dwords and
-// the groups 64/R... dwords apart the 64 aligned-dword reads of one instruction fall in 64 banks
+// the groups s/2 dwords apart the 64 aligned-dword reads of one instruction fall in 64 banks.  One launch
+// serves every split level: the frame rows are staged once (margin of the longest kernel) and each level
+// runs its own taps over them into its own plane.
+constexpr int RP_MAX_LEVELS = 4;
+struct RowPassLevel {
+    float *rowf;        // [image][H][NC]
+    const int *colsrc;  // [NC]
+    const float *kern;  // [ksz]
+    int NC, ksz, rshift;
+};
+struct RowPassArgs {
+    int n;
+    RowPassLevel lv[RP_MAX_LEVELS];
+};
+
 __global__ void __launch_bounds__(256)
-k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ rowf, int W,
-                int H, int NC, const int *__restrict__ colsrc, const float *__restrict__ kern, int ksz, int RB, int pitch,
-                int r4, int rshift)
+k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, int W, int H, RowPassArgs args, int RB,
+                int pitch, int r4, int rmax)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_rp[];
-    uint8_t *sS = s_rp;                                                   // [RB][pitch]: r4 + column c at byte r4 + c
-    float *sK = reinterpret_cast<float *>(s_rp + (size_t)RB * pitch);      // [ksz]
-    const int r = ksz >> 1;
+    uint8_t *sS = s_rp;                                                   // [RB][pitch]: column c at byte r4 + c
+    float *sKall = reinterpret_cast<float *>(s_rp + (size_t)RB * pitch);  // the levels' taps, one after the other
     const int pi = blockIdx.y;
     const int2 pr = pairs[pi >> 1];
     const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
     const int y0 = blockIdx.x * RB, nrows = min(RB, H - y0);
-    for (int i = threadIdx.x; i < ksz; i += 256)
-        sK[i] = kern[i];
-    // stage nrows frame rows: the interior as dwords (W % 4 == 0 is required by the host), r reflected bytes each side
+    {
+        int base = 0;
+        for (int l = 0; l < args.n; l++) {
+            for (int i = threadIdx.x; i < args.lv[l].ksz; i += 256)
+                sKall[base + i] = args.lv[l].kern[i];
+            base += args.lv[l].ksz;
+        }
+    }
+    // stage nrows frame rows: the interior as dwords (W % 4 == 0 is required by the host), rmax reflected bytes each side
     const int nq = W >> 2;
     for (int idx = threadIdx.x; idx < nrows * nq; idx += 256) {
         const int i = idx / nq, c = idx - i * nq;
         *reinterpret_cast<uint32_t *>(sS + i * pitch + r4 + 4 * c) =
             *reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + i) * W + 4 * c);
     }
-    for (int idx = threadIdx.x; idx < nrows * 2 * r; idx += 256) {
-        const int i = idx / (2 * r), j = idx - i * 2 * r;
-        const int c = j < r ? j - r : W + (j - r); // -r..-1, W..W+r-1
+    for (int idx = threadIdx.x; idx < nrows * 2 * rmax; idx += 256) {
+        const int i = idx / (2 * rmax), j = idx - i * 2 * rmax;
+        const int c = j < rmax ? j - rmax : W + (j - rmax); // -rmax..-1, W..W+rmax-1
         sS[i * pitch + r4 + c] = src[(size_t)(y0 + i) * W + reflect101(c, W)];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int R = 1 << rshift, G = 64 >> rshift;
-    const int li = lane & (R - 1), lg = lane >> rshift;
-    const int ngroups = (NC + 3) >> 2;
-    const int n_rb = (nrows + R - 1) >> rshift, n_gb = (ngroups + G - 1) / G;
-    for (int item = wave; item < n_rb * n_gb; item += 4) {
-        const int gb = item % n_gb, rb = item / n_gb;
-        const int row = rb * R + li, grp = gb * G + lg;
-        if (row >= nrows || grp >= ngroups)
-            continue;
-        const int oA = 4 * grp, oB = min(4 * grp + 2, NC - 2);
-        const int cA = colsrc[oA], cB = colsrc[oB];
-        const bool dupA = colsrc[oA + 1] == cA, dupB = colsrc[oB + 1] == cB; // pair at the right frame border: sx+1 clamps to sx
-        const int a0 = r4 + cA - r, b0 = r4 + cB - r;
-        const int da = a0 >> 2, db = b0 >> 2;
-        const unsigned sa = a0 & 3, sb = b0 & 3;
-        const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + row * pitch);
-        uint32_t loA = q32[da], loB = q32[db], hiA = q32[da + 1], hiB = q32[db + 1];
-        uint32_t wA = __builtin_amdgcn_alignbyte(hiA, loA, sa), wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
-        f32x2 p0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
-        f32x2 p1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
-        f32x2 p2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
-        f32x2 p3 = {(float)(wA >> 24), (float)(wB >> 24)};
-        f32x2 acc0, acc1; // {A, B} and {A+1, B+1}
-        int i = 0, t = 2;
-        for (; i + 4 <= ksz; i += 4, t++) {
-            loA = hiA;
-            loB = hiB;
-            hiA = q32[da + t];
-            hiB = q32[db + t];
-            wA = __builtin_amdgcn_alignbyte(hiA, loA, sa);
-            wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
-            const f32x2 c0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
-            const f32x2 c1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
-            const f32x2 c2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
-            const f32x2 c3 = {(float)(wA >> 24), (float)(wB >> 24)};
-            const float t0 = sK[i], t1 = sK[i + 1], t2 = sK[i + 2], t3 = sK[i + 3];
-            if (i == 0) {
-                acc0 = t0 * p0;
-                acc1 = t0 * p1;
-            } else {
-                acc0 += t0 * p0;
-                acc1 += t0 * p1;
+    int kbase = 0;
+    for (int l = 0; l < args.n; l++) {
+        const RowPassLevel &L = args.lv[l];
+        const float *sK = sKall + kbase;
+        kbase += L.ksz;
+        const int ksz = L.ksz, r = ksz >> 1, NC = L.NC, rshift = L.rshift;
+        const int R = 1 << rshift, G = 64 >> rshift;
+        const int li = lane & (R - 1), lg = lane >> rshift;
+        const int ngroups = (NC + 3) >> 2;
+        const int n_rb = (nrows + R - 1) >> rshift, n_gb = (ngroups + G - 1) / G;
+        for (int item = wave; item < n_rb * n_gb; item += 4) {
+            const int gb = item % n_gb, rb = item / n_gb;
+            const int row = rb * R + li, grp = gb * G + lg;
+            if (row >= nrows || grp >= ngroups)
+                continue;
+            const int oA = 4 * grp, oB = min(4 * grp + 2, NC - 2);
+            const int cA = L.colsrc[oA], cB = L.colsrc[oB];
+            const bool dupA = L.colsrc[oA + 1] == cA, dupB = L.colsrc[oB + 1] == cB; // pair at the right frame border: sx+1 clamps to sx
+            const int a0 = r4 + cA - r, b0 = r4 + cB - r;
+            const int da = a0 >> 2, db = b0 >> 2;
+            const unsigned sa = a0 & 3, sb = b0 & 3;
+            const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + row * pitch);
+            uint32_t loA = q32[da], loB = q32[db], hiA = q32[da + 1], hiB = q32[db + 1];
+            uint32_t wA = __builtin_amdgcn_alignbyte(hiA, loA, sa), wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+            f32x2 p0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+            f32x2 p1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+            f32x2 p2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+            f32x2 p3 = {(float)(wA >> 24), (float)(wB >> 24)};
+            f32x2 acc0, acc1; // {A, B} and {A+1, B+1}
+            int i = 0, t = 2;
+            for (; i + 4 <= ksz; i += 4, t++) {
+                loA = hiA;
+                loB = hiB;
+                hiA = q32[da + t];
+                hiB = q32[db + t];
+                wA = __builtin_amdgcn_alignbyte(hiA, loA, sa);
+                wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+                const f32x2 c0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+                const f32x2 c1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+                const f32x2 c2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+                const f32x2 c3 = {(float)(wA >> 24), (float)(wB >> 24)};
+                const float t0 = sK[i], t1 = sK[i + 1], t2 = sK[i + 2], t3 = sK[i + 3];
+                if (i == 0) {
+                    acc0 = t0 * p0;
+                    acc1 = t0 * p1;
+                } else {
+                    acc0 += t0 * p0;
+                    acc1 += t0 * p1;
+                }
+                acc0 += t1 * p1;
+                acc1 += t1 * p2;
+                acc0 += t2 * p2;
+                acc1 += t2 * p3;
+                acc0 += t3 * p3;
+                acc1 += t3 * c0;
+                p0 = c0;
+                p1 = c1;
+                p2 = c2;
+                p3 = c3;
             }
-            acc0 += t1 * p1;
-            acc1 += t1 * p2;
-            acc0 += t2 * p2;
-            acc1 += t2 * p3;
-            acc0 += t3 * p3;
-            acc1 += t3 * c0;
-            p0 = c0;
-            p1 = c1;
-            p2 = c2;
-            p3 = c3;
-        }
-        if (i < ksz) { // up to three taps left; they need p0..p3 only
-            float tt = sK[i];
-            acc0 += tt * p0;
-            acc1 += tt * p1;
-            if (i + 1 < ksz) {
-                tt = sK[i + 1];
-                acc0 += tt * p1;
-                acc1 += tt * p2;
+            if (i < ksz) { // up to three taps left; they need p0..p3 only
+                float tt = sK[i];
+                acc0 += tt * p0;
+                acc1 += tt * p1;
+                if (i + 1 < ksz) {
+                    tt = sK[i + 1];
+                    acc0 += tt * p1;
+                    acc1 += tt * p2;
+                }
+                if (i + 2 < ksz) {
+                    tt = sK[i + 2];
+                    acc0 += tt * p2;
+                    acc1 += tt * p3;
+                }
             }
-            if (i + 2 < ksz) {
-                tt = sK[i + 2];
-                acc0 += tt * p2;
-                acc1 += tt * p3;
+            // a clamped pair reads the same column twice: the same sum
+            if (dupA)
+                acc1.x = acc0.x;
+            if (dupB)
+                acc1.y = acc0.y;
+            float *out = L.rowf + ((size_t)pi * H + y0 + row) * NC + 4 * grp;
+            out[0] = acc0.x;
+            out[1] = acc1.x;
+            if (4 * grp + 2 < NC) {
+                out[2] = acc0.y;
+                out[3] = acc1.y;
             }
-        }
-        // a clamped pair reads the same column twice: the same sum
-        if (dupA)
-            acc1.x = acc0.x;
-        if (dupB)
-            acc1.y = acc0.y;
-        float *out = rowf + ((size_t)pi * H + y0 + row) * NC + 4 * grp;
-        out[0] = acc0.x;
-        out[1] = acc1.x;
-        if (4 * grp + 2 < NC) {
-            out[2] = acc0.y;
-            out[3] = acc1.y;
         }
     }
 }
@@ -2093,7 +2118,8 @@ struct Level {
     // long blur kernels: row pass over whole frame rows, then column pass + lerps (k_level_rowpass / _colpass)
     bool split = false;
     DevBuf colsrc;          // source column of each of the NC = 2*W row-pass columns
-    int NC = 0, rp_RB = 0, rp_pitch = 0, rp_r4 = 0, rp_rshift = 0, cp_THo = 0, cp_LH = 0;
+    int NC = 0, rp_rshift = 0, cp_THo = 0, cp_LH = 0;
+    size_t rowf_off = 0;    // this level's plane inside tf_fb::rowf (floats)
     LerpDev flow_lerp; // level k+1 -> this level
 };
 
@@ -2109,7 +2135,8 @@ struct tf_fb {
     // R exists twice when the preparation stream is in use: call i+1 expands its frames into one set
     // while the flow chain of call i still reads the other (`cur` = the set of the call being issued)
     DevBuf frames, img, R[2], M[2], lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
-    DevBuf rowf; // row-pass plane of the split levels, [image][H][NC], one level at a time
+    DevBuf rowf; // row-pass planes of the split levels, [level][image][H][NC]
+    int rp_RB = 0, rp_pitch = 0, rp_r4 = 0, rp_rmax = 0, rp_first = -1; // one k_level_rowpass launch serves them all
     int nsets = 1, cur = 0;
     hipStream_t prep_stream = nullptr;         // A1+A2 of every level run here, ahead of and beside the flow chain
     hipStream_t chain_stream = nullptr;        // the flow chain; the library stream only waits for its end, so what the
@@ -2185,18 +2212,38 @@ static size_t prep_pad(const tf_fb *fb, bool image_kernel = false)
     return (size_t)std::max(0l, image_kernel ? pad_img : pad) * 1024;
 }
 
-static int fb_level_image(tf_fb *fb, int k, int n_pairs)
+// `standalone`: a single level is wanted (stage entry points): run the shared row pass regardless of the order
+static int fb_level_image(tf_fb *fb, int k, int n_pairs, bool standalone = false)
 {
     Level &L = *fb->lv[k];
     if (L.split) {
-        const size_t smem_rp = (size_t)L.rp_RB * L.rp_pitch + (size_t)L.ksz * sizeof(float);
-        TF_TRY(launch(lvl_name("fb_level_rowpass", k), k_level_rowpass, dim3(cdiv(fb->H, L.rp_RB), n_pairs * 2), dim3(256),
-                      smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(),
-                      fb->rowf.as<float>(), fb->W, fb->H, L.NC, (const int *)L.colsrc.as<int>(),
-                      (const float *)L.kern.as<float>(), L.ksz, L.rp_RB, L.rp_pitch, L.rp_r4, L.rp_rshift));
+        if (k == fb->rp_first || standalone) { // the coarsest split level comes first in the preparation: row pass of all of them now
+            RowPassArgs a;
+            memset(&a, 0, sizeof(a));
+            size_t taps = 0;
+            for (int j = fb->K; j >= 1; j--) {
+                Level &S = *fb->lv[j];
+                if (!S.split)
+                    continue;
+                RowPassLevel &rl = a.lv[a.n++];
+                rl.rowf = fb->rowf.as<float>() + S.rowf_off;
+                rl.colsrc = S.colsrc.as<int>();
+                rl.kern = S.kern.as<float>();
+                rl.NC = S.NC;
+                rl.ksz = S.ksz;
+                rl.rshift = S.rp_rshift;
+                taps += (size_t)S.ksz;
+            }
+            const size_t smem_rp = (size_t)fb->rp_RB * fb->rp_pitch + taps * sizeof(float);
+            TF_TRY(launch(lvl_name("fb_level_rowpass", -1), k_level_rowpass, dim3(cdiv(fb->H, fb->rp_RB), n_pairs * 2),
+                          dim3(256), smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(),
+                          (const int2 *)fb->pairs.as<int2>(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
+                          fb->rp_rmax));
+        }
         const size_t smem_cp = ((size_t)L.cp_LH * 2 * CP_TX + L.ksz) * sizeof(float);
         return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, CP_TX), cdiv(L.H, L.cp_THo), n_pairs * 2),
-                      dim3(256), smem_cp, (const float *)fb->rowf.as<float>(), fb->imgk(k), fb->W, fb->H, L.W, L.H, L.NC,
+                      dim3(256), smem_cp, (const float *)(fb->rowf.as<float>() + L.rowf_off), fb->imgk(k), fb->W, fb->H, L.W,
+                      L.H, L.NC,
                       (const float *)L.kern.as<float>(), L.ksz, (const int *)L.img_lerp.xofs.as<int>(),
                       (const float *)L.img_lerp.xfrac.as<float>(), (const int *)L.img_lerp.yofs.as<int>(),
                       (const float *)L.img_lerp.yfrac.as<float>(), L.cp_THo, L.cp_LH);
@@ -2214,7 +2261,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs)
 static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
 {
     static const bool off = getenv("TF_IMG_NO_SPLIT") && atoi(getenv("TF_IMG_NO_SPLIT")) != 0;
-    static const int min_ksz = getenv("TF_IMG_SPLIT_MIN_KSZ") ? atoi(getenv("TF_IMG_SPLIT_MIN_KSZ")) : 15;
+    static const int min_ksz = getenv("TF_IMG_SPLIT_MIN_KSZ") ? atoi(getenv("TF_IMG_SPLIT_MIN_KSZ")) : 9;
     if (off || L.ksz < min_ksz || L.ksz <= 5 || (W & 3) != 0 || (L.W == W && L.H == H))
         return false;
     std::vector<int> xo, yo;
@@ -2233,17 +2280,7 @@ static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
     int rshift = 1;
     while ((1 << rshift) < std::min(8, std::max(2, s_ / 2)))
         rshift++;
-    const int R = 1 << rshift;
     L.rp_rshift = rshift;
-    L.rp_r4 = (r + 3) & ~3;
-    int pitch = (L.rp_r4 + W + r + 8 + 3) & ~3; // the dword stream may run a few bytes past the last tap
-    while (((pitch / 4) % R) != 1)
-        pitch += 4;
-    L.rp_pitch = pitch;
-    int RB = (int)((40 * 1024) / pitch) & ~(R - 1);
-    if (RB < R)
-        return false;
-    L.rp_RB = std::min(RB, 64);
     // column pass: CP_TX x THo outputs, rows of the plane in LDS.  Small tiles win (measured at 4K x 16:
     // 16 / 24 / 32 / 40 / 56 KB of LDS -> 100 / 117 / 123 / 144 / 235 us at level 3): as many output rows
     // as fit ~20 KB, a single one where even that does not fit
@@ -2639,12 +2676,42 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             return fail(rc);
     }
     {
-        size_t rowf_bytes = 0;
-        for (int k = 1; k <= fb->K; k++)
-            if (fb->lv[k]->split)
-                rowf_bytes = std::max(rowf_bytes, P * 2 * (size_t)height * fb->lv[k]->NC * 4);
-        if (rowf_bytes && (rc = fb->rowf.alloc(rowf_bytes)))
-            return fail(rc);
+        // one row-pass launch for all split levels: rows staged with the longest kernel's margin, pitch = 1
+        // (mod 8) dwords (conflict-free for every lane mapping R = 2, 4, 8), ~40 KB of rows per workgroup
+        int nsplit = 0, rmax = 0;
+        size_t floats = 0;
+        for (int k = fb->K; k >= 1; k--) {
+            Level &L = *fb->lv[k];
+            if (!L.split)
+                continue;
+            if (nsplit == RP_MAX_LEVELS) { // more split levels than one launch carries: the rest keep k_level_image
+                L.split = false;
+                continue;
+            }
+            if (nsplit++ == 0)
+                fb->rp_first = k;
+            rmax = std::max(rmax, L.ksz / 2);
+            L.rowf_off = floats;
+            floats += P * 2 * (size_t)height * L.NC;
+        }
+        if (nsplit) {
+            fb->rp_rmax = rmax;
+            fb->rp_r4 = (rmax + 3) & ~3;
+            int pitch = (fb->rp_r4 + width + rmax + 8 + 3) & ~3;
+            while (((pitch / 4) % 8) != 1)
+                pitch += 4;
+            fb->rp_pitch = pitch;
+            const int RB = (int)((40 * 1024) / pitch) & ~7;
+            if (RB < 8) { // frame rows too long to stage eight of them
+                for (int k = 1; k <= fb->K; k++)
+                    fb->lv[k]->split = false;
+                fb->rp_first = -1;
+            } else {
+                fb->rp_RB = std::min(RB, 64);
+                if ((rc = fb->rowf.alloc(floats * 4)))
+                    return fail(rc);
+            }
+        }
     }
     for (int k = 0; k <= fb->K; k++)
         if (hipEventCreateWithFlags(&fb->lv[k]->ready, hipEventDisableTiming) != hipSuccess)
@@ -2978,7 +3045,7 @@ TF_API int tf_fb_stage_level_image(tf_fb *fb, const uint8_t *grey, ptrdiff_t str
     TF_TRY(tf_fb_set_frame(fb, 0, grey, stride));
     int2 pr = make_int2(0, 0);
     TF_HIP(hipMemcpy(fb->pairs.p, &pr, 8, hipMemcpyHostToDevice));
-    TF_TRY(fb_level_image(fb, level, 1));
+    TF_TRY(fb_level_image(fb, level, 1, true));
     Level &L = *fb->lv[level];
     TF_HIP(hipMemcpyAsync(out, fb->imgk(level), (size_t)L.W * L.H * 4, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
@@ -3021,7 +3088,7 @@ TF_API int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t s
     } else if (fb_can_fuse_half_level(fb, level)) {
         TF_TRY(fb_level1_polyexp(fb, level, 1));
     } else {
-        TF_TRY(fb_level_image(fb, level, 1));
+        TF_TRY(fb_level_image(fb, level, 1, true));
         TF_TRY(fb_polyexp(fb, L.W, L.H, 2, level));
     }
     return download_planar5(r_out, fb->Rk(level), (size_t)L.W * L.H, fb->scratch);
