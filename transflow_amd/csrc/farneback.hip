@@ -7,8 +7,13 @@
 //   A1 pre-blur at full resolution + bilinear resize to the pyramid level
 //   A2 polynomial expansion (separable, float vertical pass, double horizontal pass)
 //   A3 update-matrices (bilinear gather of R1 at x+flow, 2x2 system per pixel)
-//   A4 box blur of the system (double sums) + 2x2 solve, fused with the next A3
-//   A5 coarse-to-fine flow upsampling, fused into the first A3 of each level
+//   A4 box blur of the system (double sums) + 2x2 solve
+//   A5 coarse-to-fine flow upsampling
+// Kernels (DESIGN.md section 3 has the table):
+//   A1+A2  k_level0_polyexp_t (level 0), k_level1_polyexp_t (half-size level), otherwise
+//          k_level_rowpass + k_level_colpass (long blur kernels) or k_level_image, then k_polyexp_t
+//   A3+A4(+A5)  k_flow_iter_pc: one whole iteration, the 2x2 systems never leave the CU (large levels);
+//          k_update_matrices + k_blur_solve_wave on the small ones
 //
 // Arithmetic discipline: every float/double operation is written in the order of
 // the CPU path and the file is compiled with -ffp-contract=off, so A1-A3 are
@@ -16,12 +21,13 @@
 // double instead of OpenCV's running sums (differences ~1e-16 relative).
 //
 // HBM layout (per handle, sized for `max_pairs` frame pairs):
-//   frames  u8  [slot][H][W]
-//   img     f32 [pair][2][Hk*Wk]          level image of both frames (A1 output)
-//   R       f32 [pair][2][5][Hk*Wk]       polynomial coefficients, planar (SoA)
-//   M[2]    f32 [pair][5][Hk*Wk]          2x2 systems, planar, ping-pong
-//   lflow   f32 [3][pair][Hk*Wk][2]       per-level flow, rotating between iterations and levels
-// All stages are HBM-bound (<= ~60 flop/B); MFMA is not applicable.
+//   frames   u8  [slot][H][W]
+//   img      f32 [pair][2][Hk*Wk]          level image of both frames (A1 output, levels without a fused A1+A2)
+//   rowf     f32 [level][image][H][2*Wk]   row-pass planes of the long-kernel levels
+//   R[2]     f32 [pair][2][5][Hk*Wk]       polynomial coefficients, planar (SoA), one set per call parity
+//   M[2]     f32 [pair][5][Hk*Wk]          2x2 systems, planar (two-kernel iterations only)
+//   lflow[5] f32 [pair][Hk*Wk][2]          per-level flow: three rotate, two hold the result of even / odd calls
+// Stencils, gathers and 2x2 solves (<= ~60 flop/B, no dense contraction): MFMA is not applicable.
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
