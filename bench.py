@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", default=None, help="WxH: run the chosen workload's configuration at another frame size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed 1080p side measurements")
     args = ap.parse_args()
@@ -249,7 +250,9 @@ def main():
         from transflow_amd.batch import Group  # imports torch BEFORE libtfhip.so so one HIP runtime is shared
         group = Group("nccl")
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.size:
+        wl["w"], wl["h"] = (int(v) for v in args.size.lower().split("x"))
     pixmap = reset_mask = None
     if group is not None:
         # shared inputs come from rank 0 over RCCL (one-off broadcast, outside the timed region)
@@ -328,8 +331,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl)
     if world == 1 and not args.no_extra:
-        # the same kernel with nothing beside it: a second handle created with the preparation stream
-        # disabled (in the timed region above the next call's frame expansion runs beside the chain)
+        # the same kernel with nothing beside it: a second handle with everything on one stream (in the
+        # timed region above the caller's remap of one call may run beside the next call's kernels)
         os.environ["TF_FB_NO_OVERLAP"] = "1"
         try:
             j = Job(wl, args.batch, seed=2000, device=local_rank)
@@ -348,7 +351,7 @@ def main():
         cnt, ms = j.prof_report()[dominant]
         ach = kernel_alg_bytes(dominant, wl, args.batch) * n / (ms * 1e-3) / 1e9
         out["roofline"]["measured_copy_ceiling_GBs"] = copy_ceiling(job.lib, job.check)
-        out["roofline"]["exclusive"] = {"what": "same kernel, same workload, preparation stream disabled (nothing runs beside it); untimed region",
+        out["roofline"]["exclusive"] = {"what": "same kernel, same workload, TF_FB_NO_OVERLAP=1 (one stream, nothing runs beside it); untimed region",
                                         "launches": cnt, "avg_launch_ms": ms / max(1, cnt), "achieved": ach,
                                         "frac": ach / rf.HBM_PEAK_GBS}
         del j

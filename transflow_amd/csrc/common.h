@@ -17,7 +17,7 @@ namespace tf {
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 hipStream_t stream();      // the stream launches go to: the library stream unless a StreamScope is active
 hipStream_t main_stream(); // the library stream (tf_stream)
-int side_stream(int which, hipStream_t *out); // 0: preparation work (lowest priority), 1: dependent chains (highest)
+int side_stream(int which, hipStream_t *out); // 0: background work (lowest priority), 1: a call's kernels (highest)
 int ensure_init();
 
 // Routes the launches (and profiler events) of the enclosing scope to another stream.

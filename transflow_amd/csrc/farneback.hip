@@ -2118,8 +2118,7 @@ struct Level {
     ImgTile tile;
     std::vector<float> kern_host;
     DevBuf kern;
-    DevBuf img, R[2];           // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
-    hipEvent_t ready = nullptr; // recorded on the preparation stream once R is complete
+    DevBuf img, R;     // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
     // long blur kernels: row pass over whole frame rows, then column pass + lerps (k_level_rowpass / _colpass)
     bool split = false;
@@ -2138,52 +2137,40 @@ struct tf_fb {
     int slots = 0, max_pairs = 0;
     PolyConst pc;
     std::vector<Level *> lv;
-    // R exists twice when the preparation stream is in use: call i+1 expands its frames into one set
-    // while the flow chain of call i still reads the other (`cur` = the set of the call being issued)
-    DevBuf frames, img, R[2], M[2], lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
+    DevBuf frames, img, R, M[2], lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
     DevBuf rowf; // row-pass planes of the split levels, [level][image][H][NC]
     int rp_RB = 0, rp_pitch = 0, rp_r4 = 0, rp_rmax = 0, rp_first = -1; // one k_level_rowpass launch serves them all
-    int nsets = 1, cur = 0;
-    hipStream_t prep_stream = nullptr;         // A1+A2 of every level run here, ahead of and beside the flow chain
-    hipStream_t chain_stream = nullptr;        // the flow chain; the library stream only waits for its end, so what the
-                                               // caller queues after a call (its remap) runs beside the NEXT call's chain
+    int nsets = 1, cur = 0;                    // result buffers in rotation / the one this call writes
+    hipStream_t chain_stream = nullptr;        // everything a call launches; the library stream only waits for its end, so
+                                               // what the caller queues after a call (its remap) runs beside the NEXT call
     hipEvent_t entry[2] = {nullptr, nullptr};  // position of the library stream when call (parity) was issued
     bool entry_pending[2] = {false, false};
-    hipEvent_t chain_done[2] = {nullptr, nullptr}; // the chain has finished with R set s
-    bool chain_pending[2] = {false, false};
+    hipEvent_t chain_done = nullptr;           // end of the latest call's work on chain_stream
     int2 *pairs_host = nullptr;                // pinned staging of the slot pairs
     hipEvent_t pairs_copied = nullptr;
     bool pairs_pending = false;
-    hipEvent_t fine_start = nullptr;           // the previous call's chain has reached its full-resolution level
-    bool fine_pending = false;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
     // the chip with its 3-wave workgroups, as two kernels (k_update_matrices, k_blur_solve_wave)
     // otherwise.  TF_FB_FUSED=0 / 1 forces never / always.
     int fused = getenv("TF_FB_FUSED") ? atoi(getenv("TF_FB_FUSED")) : -1;
-    float *Rk(int k) { return (k <= 0 ? R[cur] : lv[k]->R[cur]).as<float>(); }
+    float *Rk(int k) { return (k <= 0 ? R : lv[k]->R).as<float>(); }
     float *imgk(int k) { return (k <= 0 ? img : lv[k]->img).as<float>(); }
     ~tf_fb()
     {
-        for (auto *l : lv) {
-            if (l->ready)
-                (void)hipEventDestroy(l->ready);
+        for (auto *l : lv)
             delete l;
-        }
-        for (auto e : chain_done)
-            if (e)
-                (void)hipEventDestroy(e);
+        if (chain_done)
+            (void)hipEventDestroy(chain_done);
         if (pairs_copied)
             (void)hipEventDestroy(pairs_copied);
-        if (fine_start)
-            (void)hipEventDestroy(fine_start);
         if (pairs_host)
             (void)hipHostFree(pairs_host);
         for (auto e : entry)
             if (e)
                 (void)hipEventDestroy(e);
-        // prep_stream / chain_stream are the library's side streams (runtime.hip), not ours to destroy
+        // chain_stream is the library's side stream (runtime.hip), not ours to destroy
     }
 };
 
@@ -2203,19 +2190,6 @@ static const char *lvl_name(const char *base, int k)
     if (it == names.end())
         it = names.emplace(key, key).first;
     return it->second.c_str();
-}
-
-// Extra dynamic LDS per preparation-kernel workgroup (bytes): caps how many of them a CU hosts, which
-// leaves wave slots to the HBM-bound flow chain running beside them on the library stream.  Measured
-// at 4K batch 16: 8 KB on the expansion kernels (5 workgroups per CU instead
-// of 7) and 8 KB on the level-image kernel give +3-5 % frames/s; more starves the preparation.
-static size_t prep_pad(const tf_fb *fb, bool image_kernel = false)
-{
-    static const long pad = getenv("TF_PREP_PAD_KB") ? atol(getenv("TF_PREP_PAD_KB")) : 8;
-    static const long pad_img = getenv("TF_PREP_PAD_IMG_KB") ? atol(getenv("TF_PREP_PAD_IMG_KB")) : 8;
-    if (fb->nsets < 2) // no second stream, nothing to leave room for
-        return 0;
-    return (size_t)std::max(0l, image_kernel ? pad_img : pad) * 1024;
 }
 
 // `standalone`: a single level is wanted (stage entry points): run the shared row pass regardless of the order
@@ -2257,7 +2231,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs, bool standalone = false
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
-    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), std::min<size_t>(smem + prep_pad(fb, true), 64 * 1024),
+    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->imgk(k),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
 }
@@ -2405,10 +2379,10 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
     const int n = fb->pc.n;
     dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
     if (n == 5)
-        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), prep_pad(fb), (const float *)fb->imgk(k),
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->imgk(k),
                       fb->Rk(k), w, h, fb->pc);
     if (n == 7)
-        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), prep_pad(fb), (const float *)fb->imgk(k),
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->imgk(k),
                       fb->Rk(k), w, h, fb->pc);
     size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
     return launch(lvl_name("fb_polyexp_generic", k), k_polyexp, grid, dim3(256), smem,
@@ -2438,10 +2412,10 @@ static int fb_level1_polyexp(tf_fb *fb, int k, int n_pairs)
     dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
-        return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), prep_pad(fb),
+        return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), 0,
                       (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), fb->W,
                       fb->H, kc, k1, fb->pc);
-    return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<7>, grid, dim3(256), prep_pad(fb),
+    return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<7>, grid, dim3(256), 0,
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), fb->W, fb->H,
                   kc, k1, fb->pc);
 }
@@ -2452,10 +2426,10 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
     dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
-        return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), prep_pad(fb),
+        return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
                       (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k),
                       L.W, L.H, kc, k1, fb->pc);
-    return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), prep_pad(fb),
+    return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), 0,
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), L.W,
                   L.H, kc, k1, fb->pc);
 }
@@ -2665,9 +2639,9 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             return fail(rc);
     }
     const size_t N0 = (size_t)width * height, P = (size_t)max_pairs;
-    fb->nsets = (fb_overlap_enabled() && fb->K > 0) ? 2 : 1; // a single scale has nothing to overlap with
+    fb->nsets = (fb_overlap_enabled() && fb->K > 0) ? 2 : 1; // a single scale: every launch fills the chip anyway
     if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
-        (rc = fb->R[0].alloc(P * 10 * N0 * 4)) || (fb->nsets > 1 && (rc = fb->R[1].alloc(P * 10 * N0 * 4))) ||
+        (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
         (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
@@ -2677,8 +2651,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
     for (int k = 1; k <= fb->K; k++) {
         Level &L = *fb->lv[k];
         const size_t nk = (size_t)L.W * L.H;
-        if ((rc = L.img.alloc(P * 2 * nk * 4)) || (rc = L.R[0].alloc(P * 10 * nk * 4)) ||
-            (fb->nsets > 1 && (rc = L.R[1].alloc(P * 10 * nk * 4))))
+        if ((rc = L.img.alloc(P * 2 * nk * 4)) || (rc = L.R.alloc(P * 10 * nk * 4)))
             return fail(rc);
     }
     {
@@ -2719,16 +2692,11 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
             }
         }
     }
-    for (int k = 0; k <= fb->K; k++)
-        if (hipEventCreateWithFlags(&fb->lv[k]->ready, hipEventDisableTiming) != hipSuccess)
-            return fail(set_error(TF_ERR_HIP, "hipEventCreate failed"));
-    if (hipEventCreateWithFlags(&fb->chain_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&fb->chain_done[1], hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&fb->chain_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->pairs_copied, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&fb->fine_start, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->entry[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->entry[1], hipEventDisableTiming) != hipSuccess ||
-        side_stream(1, &fb->chain_stream) != TF_OK || side_stream(0, &fb->prep_stream) != TF_OK ||
+        side_stream(1, &fb->chain_stream) != TF_OK ||
         hipHostMalloc((void **)&fb->pairs_host, P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "creating the handle's events and staging buffer failed"));
     *out = fb;
@@ -2790,67 +2758,45 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         fb->pairs_host[i] = make_int2(prev_slots[i], next_slots[i]);
     const int m = fb->prm.winsize / 2;
     const bool fusable = m == 3 || m == 5 || m == 7; // the pair-sum window of the fused kernel
-    // A1+A2 of every level depend on the frames only: they run on the preparation stream, coarse
-    // level first, while the flow chain (which needs the coarser level's result) follows on the
-    // library stream as each level's coefficients become ready.  The call returns without waiting,
-    // and R exists twice: the next call's preparation (VALU-bound) runs beside this call's
-    // full-resolution iterations (HBM-bound) instead of in front of its own chain.
+    // A call's work goes to a stream of its own.  The library stream -- where the caller's work on the
+    // result goes (post_process, the remap of each pair) -- waits for its end, and the NEXT call does
+    // not wait for that work: the result lands in one of two buffers by call parity, and this call
+    // only waits for what the library stream had been given when the PREVIOUS call was issued (all
+    // that could still read this parity's buffer).  So the remap of call i (a serial chain of
+    // per-pair launches) runs beside the coarse levels of call i+1 (small launches, mostly idle chip).
+    // Within a call everything is in order on the one stream: running the expansion of the next batch
+    // beside the flow chain on a third stream was measured slower at every size.
     const bool overlap = fb->nsets > 1;
     const int set = fb->cur;
-    // The chain has a stream of its own as well.  The library stream -- where the caller's work on the
-    // result goes (post_process, the remap of each pair) -- waits for the chain's end, and the chain of
-    // the NEXT call does not wait for that work: the result lands in one of two buffers by call
-    // parity, and this call's chain only waits for what the library stream had been given when the
-    // PREVIOUS call was issued (all that could still read this parity's buffer).  So the remap of call
-    // i (HBM-bound, full-size) runs beside the coarse levels of call i+1 (small launches, mostly idle chip).
-    static const bool own_chain_stream = !(getenv("TF_FB_NO_CHAIN_STREAM") && atoi(getenv("TF_FB_NO_CHAIN_STREAM")) != 0);
-    hipStream_t cs = (overlap && own_chain_stream) ? fb->chain_stream : main_stream();
-    if (overlap && own_chain_stream) {
+    hipStream_t cs = overlap ? fb->chain_stream : main_stream();
+    if (overlap) {
         TF_HIP(hipEventRecord(fb->entry[set], main_stream()));
         fb->entry_pending[set] = true;
         if (fb->entry_pending[set ^ 1])
             TF_HIP(hipStreamWaitEvent(cs, fb->entry[set ^ 1], 0));
     }
-    {
-        hipStream_t ps = overlap ? fb->prep_stream : main_stream();
-        // R set `set` was last read by the chain two calls ago.  Frames: tf_fb_set_frame returns with the
-        // frame in place; a caller writing frames on the device orders that itself (tfhip.h).
-        if (overlap && fb->chain_pending[set])
-            TF_HIP(hipStreamWaitEvent(ps, fb->chain_done[set], 0));
-        // ... and this call's expansion starts when the previous call's chain enters its full-resolution
-        // level: the coarse levels' small launches are not starved by the expansion's big grids, and
-        // the expansion (VALU-bound) then hides under the longest HBM-bound stretch of the chain
-        static const bool defer = !(getenv("TF_FB_NO_DEFER") && atoi(getenv("TF_FB_NO_DEFER")) != 0);
-        if (overlap && defer && fb->fine_pending)
-            TF_HIP(hipStreamWaitEvent(ps, fb->fine_start, 0));
-        TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, ps));
-        TF_HIP(hipEventRecord(fb->pairs_copied, ps));
-        fb->pairs_pending = true;
-        StreamScope scope(ps);
-        for (int k = fb->K; k >= 0; k--) {
-            Level &L = *fb->lv[k];
-            if (fb_can_fuse_level(fb, k)) {
-                TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
-            } else if (fb_can_fuse_half_level(fb, k)) {
-                TF_TRY(fb_level1_polyexp(fb, k, n_pairs));
-            } else {
-                TF_TRY(fb_level_image(fb, k, n_pairs));
-                TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
-            }
-            if (overlap)
-                TF_HIP(hipEventRecord(L.ready, ps));
+    // Frames: tf_fb_set_frame returns with the frame in place; a caller writing frames on the device
+    // orders that itself (tfhip.h).
+    TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, cs));
+    TF_HIP(hipEventRecord(fb->pairs_copied, cs));
+    fb->pairs_pending = true;
+    StreamScope chain_scope(cs);
+    // A1+A2 of every level (they depend on the frames only), coarse level first: the shared row pass
+    // of the long-kernel levels is launched with the coarsest of them
+    for (int k = fb->K; k >= 0; k--) {
+        Level &L = *fb->lv[k];
+        if (fb_can_fuse_level(fb, k)) {
+            TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
+        } else if (fb_can_fuse_half_level(fb, k)) {
+            TF_TRY(fb_level1_polyexp(fb, k, n_pairs));
+        } else {
+            TF_TRY(fb_level_image(fb, k, n_pairs));
+            TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
         }
     }
     int coarse = -1; // lflow buffer holding the coarser level's result
-    StreamScope chain_scope(cs);
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
-        if (overlap)
-            TF_HIP(hipStreamWaitEvent(cs, L.ready, 0));
-        if (overlap && k == 0) {
-            TF_HIP(hipEventRecord(fb->fine_start, cs));
-            fb->fine_pending = true;
-        }
         FlowInit fi;
         memset(&fi, 0, sizeof(fi));
         if (k < fb->K) {
@@ -2912,10 +2858,8 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         fb->final_buf = result;
     }
     if (overlap) {
-        TF_HIP(hipEventRecord(fb->chain_done[set], cs));
-        fb->chain_pending[set] = true;
-        if (cs != main_stream())
-            TF_HIP(hipStreamWaitEvent(main_stream(), fb->chain_done[set], 0));
+        TF_HIP(hipEventRecord(fb->chain_done, cs));
+        TF_HIP(hipStreamWaitEvent(main_stream(), fb->chain_done, 0));
     }
     fb->cur = (set + 1) % fb->nsets;
     fb->last_pairs = n_pairs;
