@@ -138,6 +138,12 @@ def kernel_alg_bytes(name, wl, batch, iterations=3):
     for k in range(len(n)):
         nc = n[k + 1] if k + 1 < len(n) else 0
         mult = 1
+        if name in ("fb_level_rowpass", "fb_level_colpass") and k < 2:   # long blur kernels start at level 2 (pyr_scale 0.5)
+            continue
+        if name == "fb_flow_iter" and not rf.level_is_fused(n[k], batch):
+            continue
+        if name in ("fb_update_matrices", "fb_blur_solve") and rf.level_is_fused(n[k], batch):
+            continue
         if name == "fb_blur_solve":
             mult = iterations
         elif name in ("fb_update_matrices", "fb_flow_iter"):
@@ -164,7 +170,7 @@ def measured_traffic(name, wl, batch, launches_per_step, iterations=3):
     per_level_launches = {"fb_update_matrices": iterations, "fb_blur_solve": iterations,
                           "fb_flow_iter": iterations}.get(name, 1)
     if name == "fb_flow_iter":          # runs on the levels of >= 4M pixels over the batch only
-        n = [v for v in n if v * batch >= (4 << 20)]
+        n = [v for v in n if rf.level_is_fused(v, batch)]
     images = 2 if name in ("fb_polyexp", "fb_level_image") else 1
     total = table[name]["bytes_per_px"] * sum(n) * batch * images * per_level_launches
     return total / max(1.0, launches_per_step)
@@ -264,16 +270,18 @@ def main():
                                                if rank == 0 else np.zeros((wl["h"], wl["w"]), np.float32))
     job = Job(wl, args.batch, seed=2000 + 17 * rank, device=local_rank, pixmap=pixmap, reset_mask=reset_mask)
 
-    # warmup; the first warmup step is profiled per kernel to find the dominant one
-    job.prof(True)
-    job.prof_reset()
-    for i in range(max(1, args.warmup)):
-        job.step()
-        if i == 0:
+    # warmup; the last warmup step is profiled per kernel to find the dominant one (the first step of a
+    # process pays one-off costs inside whichever kernel happens to run first)
+    n_warm = max(1, args.warmup)
+    for i in range(n_warm):
+        if i == n_warm - 1:
             job.sync()
-            per_kernel = job.prof_report()
-            job.prof(False)
+            job.prof(True)
+            job.prof_reset()
+        job.step()
     job.sync()
+    per_kernel = job.prof_report()
+    job.prof(False)
     fb_kernels = {k: v for k, v in per_kernel.items() if k.startswith("fb_")}
     dominant = max(fb_kernels, key=lambda k: fb_kernels[k][1])
     job.prof_reset()

@@ -2818,7 +2818,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             b = 1;
         }
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
-        static const long fuse_min_px = getenv("TF_FB_FUSE_MIN_PX") ? atol(getenv("TF_FB_FUSE_MIN_PX")) : (4l << 20);
+        static const long fuse_min_px = getenv("TF_FB_FUSE_MIN_PX") ? atol(getenv("TF_FB_FUSE_MIN_PX")) : 4000000l; // two 1080p levels (4.15M) are in
         const bool fused_here = fusable && L.W >= 2 && L.H >= 2 &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)

@@ -47,11 +47,27 @@ def remap_bytes(width, height, reset_mask=False, external_uniform=False, forward
     return per_px * width * height
 
 
+FUSE_MIN_PX = 4_000_000   # the library's default threshold (TF_FB_FUSE_MIN_PX): pixels of a level over the batch
+
+
+def level_is_fused(nk: int, pairs: int) -> bool:
+    """Whether a level's iterations run as k_flow_iter_pc (one kernel) or as update_matrices + blur_solve."""
+    import os
+    forced = os.environ.get("TF_FB_FUSED")
+    if forced is not None and int(forced) >= 0:
+        return int(forced) > 0
+    return nk * pairs >= int(os.environ.get("TF_FB_FUSE_MIN_PX", FUSE_MIN_PX))
+
+
 # per-launch algorithmic bytes of each kernel, per pixel of the level it runs on
 # (n0 = full-res pixels, nk = level pixels, nc = pixels of the next coarser level)
 def kernel_bytes(name: str, n0: int, nk: int, nc: int, pairs: int) -> int:
     if name == "fb_level_image":                               # S1: u8 frame in, f32 level out, x2 images
         return pairs * 2 * (n0 + 4 * nk)
+    if name == "fb_level_rowpass":                             # S1 of a long-kernel level, first half: the frame read
+        return pairs * 2 * n0
+    if name == "fb_level_colpass":                             # ... second half: the level image written
+        return pairs * 2 * 4 * nk
     if name == "fb_polyexp":                                   # S2 x2 images
         return pairs * 2 * 24 * nk
     if name == "fb_update_matrices":                           # S4 (+S3: upsample read + level flow write)
