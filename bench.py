@@ -294,9 +294,13 @@ def main():
     for _ in range(args.steps):
         job.step()
     job.sync()
+    t_sync = time.perf_counter() - t0
     if group is not None:
         group.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("TF_BENCH_DEBUG"):
+        print(f"[bench] rank {rank}: steps done after {t_sync * 1e3:.2f} ms, closing barrier {(elapsed - t_sync) * 1e3:.2f} ms",
+              file=sys.stderr)
     if group is not None:
         elapsed = group.max_over_ranks(elapsed)
     job.prof(False)
