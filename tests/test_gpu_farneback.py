@@ -228,6 +228,31 @@ def test_fused_and_two_kernel_iterations_agree(FB, monkeypatch):
     assert np.abs(out[None] - out["0"]).max() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("shape,kw", CASES + [
+    ((135, 241), dict(levels=2, winsize=7)),                # window half-widths 3 and 5 of the fused kernel
+    ((97, 113), dict(levels=1, winsize=11)),
+    ((33, 2), dict(levels=0)),                              # narrower than one lane pair, shorter than the window
+    ((2, 300), dict(levels=0)),
+])
+def test_full_calc_close_fused_on_every_level(FB, monkeypatch, shape, kw):
+    """The one-kernel iteration forced on every level it supports (TF_FB_FUSED=1; by default only levels of
+    >= 4M pixels use it): ragged widths and heights, strips narrower than a workgroup, every window width."""
+    monkeypatch.setenv("TF_FB_FUSED", "1")
+    h, w = shape
+    a, b = synth_pair(h, w, seed=23)
+    ref = O.calc(a, b, **kw)
+    fb = FB(w, h, max_pairs=2, frame_slots=2, **kw)
+    fb.set_frame(0, a)
+    fb.set_frame(1, b)
+    fb.calc_slots([0, 1], [1, 0])
+    got = fb.get_flow(0)
+    err = np.abs(got - ref).max()
+    assert err <= flow_tol(ref), f"max|d|={err} tol={flow_tol(ref)}"
+    back = O.calc(b, a, **kw)
+    assert np.abs(fb.get_flow(1) - back).max() <= flow_tol(back)
+    fb.close()
+
+
 def test_strided_input_and_errors(FB):
     h, w = 64, 96
     a, b = synth_pair(h, w + 8, seed=60)
