@@ -330,6 +330,11 @@ def main():
                                f"(reset {'random p=0.5 through a float mask, u drawn on the GPU' if wl['reset'] else 'off'}), "
                                "1 RGB pixmap source, render",
                    "frame_pairs_per_step_per_gpu": args.batch,
+                   "frames_per_step_per_gpu": args.batch + 1,
+                   "frame_expansions": "pairs t and t+1 of a step share frame t+1: its pyramid levels and polynomial "
+                                       "expansion (A1+A2, functions of the frame alone) are computed once per step and "
+                                       "read by both; nothing is kept between steps (TF_FB_NO_SHARE=1 expands per pair "
+                                       "and side: other_workloads_untimed_region.unshared_expansions)",
                    "parallelism": f"frames sharded over {max(1, world)} GPU(s), one remap stream per GPU"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / rf.HBM_PEAK_GBS, "traffic": traffic,
@@ -389,6 +394,21 @@ def main():
             extra[name] = {"frames_per_s": n * b2 / dt, "frame_pairs_per_step": b2,
                            "whole_step_frac_of_8TBs": sb * n / dt / 1e9 / 8000.0}
             del j
+        # the main workload with one expansion per pair and side, as 16 separate calls would do them
+        os.environ["TF_FB_NO_SHARE"] = "1"
+        try:
+            for _ in range(2):
+                job.step()
+            job.sync()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                job.step()
+            job.sync()
+            extra["unshared_expansions"] = {"frames_per_s": n * args.batch / (time.perf_counter() - t0),
+                                            "what": f"{args.workload}, TF_FB_NO_SHARE=1"}
+        finally:
+            del os.environ["TF_FB_NO_SHARE"]
         out["other_workloads_untimed_region"] = extra
     print(json.dumps(out))
     if group is not None:

@@ -171,6 +171,42 @@ def test_batch_equals_single(FB):
     fb.close()
 
 
+def test_shared_frames_are_expanded_once_with_identical_results(FB, monkeypatch):
+    """Pairs of a batch that name the same frame slot share its expansion (A1+A2 depend on the frame
+    alone): bit-identical to expanding per pair and side (TF_FB_NO_SHARE=1), whatever the order, with
+    repeated pairs and a pair of a frame with itself."""
+    h, w = 270, 480
+    frames = [synth_pair(h, w, seed=90, shift=(0.8 * i, 0.5 * i))[1] for i in range(5)]   # one texture, five displacements
+    prev = [0, 1, 2, 3, 3, 1, 4, 2]
+    nxt = [1, 2, 3, 4, 3, 0, 0, 3]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TF_FB_NO_SHARE", mode)
+        fb = FB(w, h, levels=3, max_pairs=len(prev), frame_slots=len(frames))
+        for i, f in enumerate(frames):
+            fb.set_frame(i, f)
+        fb.calc_slots(prev, nxt)
+        out[mode] = [fb.get_flow(i) for i in range(len(prev))]
+        fb.calc_slots(nxt, prev)                      # a second call on the same handle: the map is per call
+        back = [fb.get_flow(i) for i in range(len(prev))]
+        fb.close()
+        for i in range(len(prev)):
+            if prev[i] == nxt[i]:
+                continue    # a frame against itself is ill-conditioned on the first row and column (see below)
+            ref = O.calc(frames[prev[i]], frames[nxt[i]], levels=3)
+            assert np.abs(out[mode][i] - ref).max() <= flow_tol(ref)
+        ref = O.calc(frames[nxt[0]], frames[prev[0]], levels=3)
+        assert np.abs(back[0] - ref).max() <= flow_tol(ref)
+    for a, b in zip(out["0"], out["1"]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out["0"][2], out["0"][7])       # the same pair twice in one batch
+    # A frame against itself: zero flow away from the borders.  On the first row / column the sign of a
+    # 1e-8 flow decides whether x + dx floors to -1 (R1 "absent", cv2's bounds test) or to 0, so any two
+    # implementations that differ in the last bit of the window sums part ways there: checked loosely.
+    assert np.abs(out["0"][4][40:-40, 40:-40]).max() < 1e-3
+    assert np.abs(out["0"][4]).max() < 0.5
+
+
 def test_pipelined_calls_equal_single_calls(FB):
     """tf_fb_calc_slots only enqueues: six calls issued back to back without a host synchronisation
     (the next call's frame expansion runs on the second stream beside the previous call's

@@ -89,11 +89,13 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-// 1/d for a positive, normal double: hardware estimate + two Newton steps (relative error ~1e-16, not
-// correctly rounded; a true division is ~25 instructions).  For determinants that carry +1e-3.
+// 1/d for a positive, normal double: hardware estimate, two Newton steps and the residual correction --
+// the compiler's own IEEE division sequence for a numerator of 1 without its scaling and fix-up of
+// denormal / infinite operands (~25 instructions), which determinants that carry +1e-3 never are.
 __device__ __forceinline__ double fast_recip(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
@@ -1208,7 +1210,15 @@ struct FlowInit {
     const int *xofs, *yofs;
     const float *xfrac, *yfrac;
     float mul;
+    // which two expansions (images of R, [image][5][Nk]) pair p compares: frames shared by the pairs of a
+    // batch are expanded once.  Null: images 2p and 2p+1 (stage entry points).
+    const int2 *rmap;
 };
+
+__device__ __forceinline__ int2 pair_images(const FlowInit &fi, int pair)
+{
+    return fi.rmap ? fi.rmap[pair] : make_int2(2 * pair, 2 * pair + 1);
+}
 
 struct GatherRegs {
     float2 r0[5];   // R0 at the two pixels, per channel (x: first pixel, y: second)
@@ -1357,7 +1367,8 @@ k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, in
         fa = f[xa];
         fb = f[xbc];
     }
-    const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
+    const int2 im = pair_images(fi, pair);
+    const float *R0 = R + (size_t)im.x * 5 * Nk, *R1 = R + (size_t)im.y * 5 * Nk;
     float m[2][5];
     if (Wk >= 2 && Hk >= 2) {
         GatherRegs g;
@@ -1730,10 +1741,11 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const int col = wave * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
         PlaneBases pb;
+        const int2 im = pair_images(fi, pair);
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            pb.r0[c] = R + (size_t)pair * 10 * Nk + (size_t)c * Nk;
-            pb.r1[c] = pb.r0[c] + 5 * Nk;
+            pb.r0[c] = R + (size_t)im.x * 5 * Nk + (size_t)c * Nk;
+            pb.r1[c] = R + (size_t)im.y * 5 * Nk + (size_t)c * Nk;
         }
         const float2 *fin = FLOW == 1 ? flow_in + (size_t)pair * Nk : nullptr;
         const float2 *coarse = FLOW == 2 ? fi.src + (size_t)pair * fi.Wc * fi.Hc : nullptr;
@@ -2146,7 +2158,9 @@ struct tf_fb {
     hipEvent_t entry[2] = {nullptr, nullptr};  // position of the library stream when call (parity) was issued
     bool entry_pending[2] = {false, false};
     hipEvent_t chain_done = nullptr;           // end of the latest call's work on chain_stream
-    int2 *pairs_host = nullptr;                // pinned staging of the slot pairs
+    int2 *pairs_host = nullptr;                // pinned staging: the call's image list (slots, 2P ints), then its pair -> image map (P int2)
+    const int2 *rmap_dev = nullptr;            // that map on the device while a batch is being issued; null: images 2p, 2p+1
+    std::vector<int> image_of;                 // slot -> index in the image list of the call being issued
     hipEvent_t pairs_copied = nullptr;
     bool pairs_pending = false;
     int last_pairs = 0;
@@ -2193,7 +2207,7 @@ static const char *lvl_name(const char *base, int k)
 }
 
 // `standalone`: a single level is wanted (stage entry points): run the shared row pass regardless of the order
-static int fb_level_image(tf_fb *fb, int k, int n_pairs, bool standalone = false)
+static int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone = false)
 {
     Level &L = *fb->lv[k];
     if (L.split) {
@@ -2215,13 +2229,13 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs, bool standalone = false
                 taps += (size_t)S.ksz;
             }
             const size_t smem_rp = (size_t)fb->rp_RB * fb->rp_pitch + taps * sizeof(float);
-            TF_TRY(launch(lvl_name("fb_level_rowpass", -1), k_level_rowpass, dim3(cdiv(fb->H, fb->rp_RB), n_pairs * 2),
+            TF_TRY(launch(lvl_name("fb_level_rowpass", -1), k_level_rowpass, dim3(cdiv(fb->H, fb->rp_RB), n_images),
                           dim3(256), smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(),
                           (const int2 *)fb->pairs.as<int2>(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
                           fb->rp_rmax));
         }
         const size_t smem_cp = ((size_t)L.cp_LH * 2 * CP_TX + L.ksz) * sizeof(float);
-        return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, CP_TX), cdiv(L.H, L.cp_THo), n_pairs * 2),
+        return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, CP_TX), cdiv(L.H, L.cp_THo), n_images),
                       dim3(256), smem_cp, (const float *)(fb->rowf.as<float>() + L.rowf_off), fb->imgk(k), fb->W, fb->H, L.W,
                       L.H, L.NC,
                       (const float *)L.kern.as<float>(), L.ksz, (const int *)L.img_lerp.xofs.as<int>(),
@@ -2229,7 +2243,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_pairs, bool standalone = false
                       (const float *)L.img_lerp.yfrac.as<float>(), L.cp_THo, L.cp_LH);
     }
     const ImgTile &t = L.tile;
-    dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_pairs * 2);
+    dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_images);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
     return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
                   (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->imgk(k),
@@ -2406,10 +2420,10 @@ static bool fb_can_fuse_half_level(tf_fb *fb, int k)
     return !off && 2 * L.W == fb->W && 2 * L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
 }
 
-static int fb_level1_polyexp(tf_fb *fb, int k, int n_pairs)
+static int fb_level1_polyexp(tf_fb *fb, int k, int n_images)
 {
     Level &L = *fb->lv[k];
-    dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_images);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), 0,
@@ -2420,10 +2434,10 @@ static int fb_level1_polyexp(tf_fb *fb, int k, int n_pairs)
                   kc, k1, fb->pc);
 }
 
-static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
+static int fb_level0_polyexp(tf_fb *fb, int k, int n_images)
 {
     Level &L = *fb->lv[k];
-    dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_pairs * 2);
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, 16), n_images);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
@@ -2437,8 +2451,10 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_pairs)
 static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
 {
     dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
+    FlowInit f = fi;
+    f.rmap = fb->rmap_dev;
     return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->Rk(k),
-                  fb->M[mbuf].as<float>(), w, h, fi);
+                  fb->M[mbuf].as<float>(), w, h, f);
 }
 
 template <int M>
@@ -2521,9 +2537,13 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     FlowInit none;
     memset(&none, 0, sizeof(none));
-    if (up)
+    none.rmap = fb->rmap_dev;
+    if (up) {
+        FlowInit f = *up;
+        f.rmap = fb->rmap_dev;
         return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
-                      seg, *up);
+                      seg, f);
+    }
     if (flow_in)
         return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
                       seg, none);
@@ -2646,7 +2666,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
         (fb->nsets > 1 && ((rc = fb->lflow[3].alloc(P * N0 * 8)) || (rc = fb->lflow[4].alloc(P * N0 * 8)))) ||
-        (rc = fb->pairs.alloc(P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
+        (rc = fb->pairs.alloc(2 * P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
         return fail(rc);
     for (int k = 1; k <= fb->K; k++) {
         Level &L = *fb->lv[k];
@@ -2697,7 +2717,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         hipEventCreateWithFlags(&fb->entry[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->entry[1], hipEventDisableTiming) != hipSuccess ||
         side_stream(1, &fb->chain_stream) != TF_OK ||
-        hipHostMalloc((void **)&fb->pairs_host, P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void **)&fb->pairs_host, 2 * P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "creating the handle's events and staging buffer failed"));
     *out = fb;
     return TF_OK;
@@ -2754,8 +2774,28 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         TF_HIP(hipEventSynchronize(fb->pairs_copied));
         fb->pairs_pending = false;
     }
-    for (int i = 0; i < n_pairs; i++)
-        fb->pairs_host[i] = make_int2(prev_slots[i], next_slots[i]);
+    // A1+A2 depend on the frame alone, and consecutive pairs of a video share one: every slot the batch
+    // names is expanded once (16 consecutive pairs: 17 expansions, not 32) and each pair carries the
+    // indices of its two.  TF_FB_NO_SHARE=1: one expansion per pair and side, as separate calls would do.
+    const bool no_share = getenv("TF_FB_NO_SHARE") && atoi(getenv("TF_FB_NO_SHARE")) != 0; // read per call
+    const int P = fb->max_pairs;
+    int *image_slot = reinterpret_cast<int *>(fb->pairs_host); // [2P], read by the kernels as int2[P]
+    int2 *rmap_host = fb->pairs_host + P;
+    int n_images = 0;
+    fb->image_of.assign((size_t)fb->slots, -1);
+    auto image = [&](int slot) {
+        if (no_share || fb->image_of[slot] < 0) {
+            fb->image_of[slot] = n_images;
+            image_slot[n_images++] = slot;
+        }
+        return fb->image_of[slot];
+    };
+    for (int i = 0; i < n_pairs; i++) {
+        const int a = image(prev_slots[i]);
+        rmap_host[i] = make_int2(a, image(next_slots[i]));
+    }
+    if (n_images & 1)
+        image_slot[n_images] = image_slot[0]; // the unused half of the last int2
     const int m = fb->prm.winsize / 2;
     const bool fusable = m == 3 || m == 5 || m == 7; // the pair-sum window of the fused kernel
     // A call's work goes to a stream of its own.  The library stream -- where the caller's work on the
@@ -2777,21 +2817,26 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     }
     // Frames: tf_fb_set_frame returns with the frame in place; a caller writing frames on the device
     // orders that itself (tfhip.h).
-    TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)n_pairs * sizeof(int2), hipMemcpyHostToDevice, cs));
+    TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)2 * P * sizeof(int2), hipMemcpyHostToDevice, cs));
     TF_HIP(hipEventRecord(fb->pairs_copied, cs));
     fb->pairs_pending = true;
+    struct MapScope { // the chain launchers below read the map from the handle; stage entry points run without one
+        tf_fb *fb;
+        ~MapScope() { fb->rmap_dev = nullptr; }
+    } map_scope{fb};
+    fb->rmap_dev = fb->pairs.as<int2>() + P;
     StreamScope chain_scope(cs);
     // A1+A2 of every level (they depend on the frames only), coarse level first: the shared row pass
     // of the long-kernel levels is launched with the coarsest of them
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
         if (fb_can_fuse_level(fb, k)) {
-            TF_TRY(fb_level0_polyexp(fb, k, n_pairs)); // A1+A2 in one kernel: the level image stays on chip
+            TF_TRY(fb_level0_polyexp(fb, k, n_images)); // A1+A2 in one kernel: the level image stays on chip
         } else if (fb_can_fuse_half_level(fb, k)) {
-            TF_TRY(fb_level1_polyexp(fb, k, n_pairs));
+            TF_TRY(fb_level1_polyexp(fb, k, n_images));
         } else {
-            TF_TRY(fb_level_image(fb, k, n_pairs));
-            TF_TRY(fb_polyexp(fb, L.W, L.H, n_pairs * 2, k));
+            TF_TRY(fb_level_image(fb, k, n_images));
+            TF_TRY(fb_polyexp(fb, L.W, L.H, n_images, k));
         }
     }
     int coarse = -1; // lflow buffer holding the coarser level's result
@@ -2995,7 +3040,7 @@ TF_API int tf_fb_stage_level_image(tf_fb *fb, const uint8_t *grey, ptrdiff_t str
     TF_TRY(tf_fb_set_frame(fb, 0, grey, stride));
     int2 pr = make_int2(0, 0);
     TF_HIP(hipMemcpy(fb->pairs.p, &pr, 8, hipMemcpyHostToDevice));
-    TF_TRY(fb_level_image(fb, level, 1, true));
+    TF_TRY(fb_level_image(fb, level, 2, true));
     Level &L = *fb->lv[level];
     TF_HIP(hipMemcpyAsync(out, fb->imgk(level), (size_t)L.W * L.H * 4, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
@@ -3034,11 +3079,11 @@ TF_API int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t s
     TF_HIP(hipMemcpy(fb->pairs.p, &pr, 8, hipMemcpyHostToDevice));
     Level &L = *fb->lv[level];
     if (fb_can_fuse_level(fb, level)) {
-        TF_TRY(fb_level0_polyexp(fb, level, 1));
+        TF_TRY(fb_level0_polyexp(fb, level, 2));
     } else if (fb_can_fuse_half_level(fb, level)) {
-        TF_TRY(fb_level1_polyexp(fb, level, 1));
+        TF_TRY(fb_level1_polyexp(fb, level, 2));
     } else {
-        TF_TRY(fb_level_image(fb, level, 1, true));
+        TF_TRY(fb_level_image(fb, level, 2, true));
         TF_TRY(fb_polyexp(fb, L.W, L.H, 2, level));
     }
     return download_planar5(r_out, fb->Rk(level), (size_t)L.W * L.H, fb->scratch);
