@@ -103,7 +103,9 @@ int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint
 
 /* Resident path: upload grey frames into slots, compute n pairs in one pass
    (pairs are independent with flags == 0: cv.py:478,489), read results back or
-   hand the device pointer on.  tf_fb_calc_slots only enqueues, on a stream of the library's
+   hand the device pointer on.  A slot named by several pairs of one call (consecutive pairs of a
+   video share a frame) is expanded once for all of them; nothing is kept between calls.
+   tf_fb_calc_slots only enqueues, on a stream of the library's
    own that does not wait for what the library stream was given last (the caller's remap of the
    previous result keeps running beside it), so a caller that fills frame slots on the device itself (through tf_fb_frame_ptr) calls tf_sync() before the next tf_fb_calc_slots;
    tf_fb_set_frame already returns with the frame in place. */
