@@ -104,10 +104,12 @@ class Job:
         if self.flow_ptrs is None or self.flow_ptrs[0] != base:
             self.flow_ptrs = [base + i * self.wl["w"] * self.wl["h"] * 8 for i in range(self.batch)]
         for i in range(self.batch):
-            if d == 0:  # FORWARD: scatter-inversion passes, then the fused remap kernel
-                fb.post_process(i, d)
-            # BACKWARD post_process is the clip alone: folded into the remap kernel
-            layer.step_dev(comp, self.flow_ptrs[i], self.pixmap_dev, 3, clip_flow=(d == 1), seed=20251003)
+            if d == 0:
+                # FORWARD post_process: the scatter pass here, the rest (source.py:359-362) inside the remap kernel
+                layer.step_dev(comp, fb.post_process_scatter(i), self.pixmap_dev, 3, clip_flow=2, seed=20251003)
+            else:
+                # BACKWARD post_process is the clip alone: folded into the remap kernel
+                layer.step_dev(comp, self.flow_ptrs[i], self.pixmap_dev, 3, clip_flow=True, seed=20251003)
 
     def sync(self):
         self.check(self.lib.tf_sync())

@@ -120,6 +120,12 @@ int tf_fb_flow_ptr(tf_fb *fb, int pair, void **dev);
    scatter-invert with last-write-wins, :349-360), 1 = BACKWARD; both end with the
    clip to the frame (:361-362).  In place. */
 int tf_fb_post_process(tf_fb *fb, int pair, int direction);                 /* device flow of `pair` */
+/* The first half of FORWARD post_process alone (source.py:349-358: clip, round, every moving source
+   claims its target, the highest source index wins): *winners_dev = int32 [H][W], the winning source
+   index per target or -1.  The handle owns the map; the next scatter or post_process overwrites it.
+   tf_remap_step_dev(clip_flow = 2) takes it in place of the flow and does the rest (:359-362) in
+   registers, which saves writing and re-reading the flow. */
+int tf_fb_post_process_scatter(tf_fb *fb, int pair, void **winners_dev);
 int tf_fb_post_process_host(tf_fb *fb, float *flow_inout, int direction);   /* host array, same H,W */
 
 /* The optional pre-steps of post_process (source.py:339-345), applied before the direction
@@ -292,8 +298,10 @@ int tf_remap_render(tf_remap *layer, tf_comp *comp);
      tf_remap_gather_dev(source 0); tf_comp_begin; tf_remap_render
    for a compositor with this single layer and a single source.  Runs as ONE kernel when
    the layer needs no second pass (moving_pixels_leave_empty_spot off, reset off/random),
-   otherwise as those separate kernels.  With clip_flow the clipped flow is written back
-   only in the unfused form; the fused form clips in registers. */
+   otherwise as those separate kernels.  clip_flow: 0 = flow_dev is a post-processed flow; 1 = clip it
+   first (BACKWARD post_process is the clip alone; written back only in the unfused form, the fused
+   form clips in registers); 2 = flow_dev is the winner map of tf_fb_post_process_scatter, the flow
+   it stands for (source.py:359-362) is formed in registers. */
 int tf_remap_step_dev(tf_remap *layer, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev,
                       uint64_t seed, const void *pixmap_dev, int channels);
 

@@ -260,6 +260,53 @@ def test_fused_step_clips_like_post_process(tf):
     assert layer.out_of_frame()
 
 
+@pytest.mark.parametrize("leave_empty", [False, True])     # one kernel / the separate kernels
+def test_fused_step_finishes_forward_post_process(tf, leave_empty):
+    """FORWARD post_process split in two -- tf_fb_post_process_scatter, then step_dev(clip_flow=2) forming
+    the flow from the winner map in registers -- equals post_process then the step, and the oracle."""
+    import ctypes as C
+    from transflow_amd import _lib
+    from transflow_amd.device import DevBuffer
+    farneback, remap = tf
+    h, w = 203, 317
+    rng = np.random.default_rng(13)
+    raw = rng.normal(0, 12, (h, w, 2)).astype(np.float32)      # collisions and out-of-frame targets
+    raw[rng.random((h, w)) < 0.3] = 0
+    pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    kw = dict(moving_pixels_leave_empty_spot=True) if leave_empty else {}
+    ora = R.MoveRefLayer(h, w, oracle_params(kw), introduction_masks=[np.ones((h, w), bool)])
+    fb = farneback.Farneback(w, h, levels=0)
+    fb.calc_slots([0], [0])                                    # gives the handle a result buffer
+    lib = _lib.load()
+    pm_dev = DevBuffer.from_array(pm)
+    layers = []
+    for mode in ("two calls", "split"):
+        layer = remap.RemapLayer(h, w, **kw)
+        layer.set_sources([np.ones((h, w), np.uint8)])
+        comp = remap.CompImage(h, w, (1, 2, 3))
+        for t in range(3):                                     # a recurrence, so the state matters
+            flow_t = np.ascontiguousarray(np.roll(raw, 7 * t, axis=1))
+            _lib.check(lib.tf_dev_upload(C.c_void_p(fb.flow_ptr(0)), C.c_void_p(flow_t.ctypes.data), flow_t.nbytes))
+            if mode == "two calls":
+                fb.post_process(0, 0)
+                layer.step_dev(comp, fb.flow_ptr(0), pm_dev.ptr, 3, clip_flow=False)
+            else:
+                layer.step_dev(comp, fb.post_process_scatter(0), pm_dev.ptr, 3, clip_flow=2)
+            if mode == "split":
+                ora.update(R.post_process(flow_t.copy(), R.FORWARD), [pm])
+        layers.append((layer.get_state(), comp.download()))
+        assert not layer.out_of_frame()
+    (d0, r0), i0 = layers[0]
+    (d1, r1), i1 = layers[1]
+    np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(r0, r1)
+    np.testing.assert_array_equal(i0, i1)
+    np.testing.assert_array_equal(d1, ora.data)
+    exp = R.composite(np.broadcast_to(np.uint8([1, 2, 3]), (h, w, 3)), [ora.render()])
+    np.testing.assert_array_equal(i1, exp)
+    fb.close()
+
+
 def test_flow_presteps_golden_gpu(tf):
     """scale / threshold / clip filters and the flow mask on the GPU (tf_fb_post_process_host_ex),
     through the FlowSource mirror, against the reference's outputs -- bit for bit, including which

@@ -3020,6 +3020,21 @@ TF_API int tf_fb_post_process(tf_fb *fb, int pair, int direction)
     return pp_run(fb, (float2 *)p, direction);
 }
 
+TF_API int tf_fb_post_process_scatter(tf_fb *fb, int pair, void **winners_dev)
+{
+    TF_REQUIRE(fb && winners_dev, "tf_fb_post_process_scatter: null pointer");
+    TF_REQUIRE(pair >= 0 && pair < fb->max_pairs, "tf_fb_post_process_scatter: pair %d out of range", pair);
+    TF_TRY(ensure_init());
+    void *p;
+    TF_TRY(tf_fb_flow_ptr(fb, pair, &p));
+    const int N = fb->W * fb->H;
+    TF_HIP(hipMemsetAsync(fb->winner.p, 0xFF, (size_t)N * 4, stream()));
+    TF_TRY(launch("pp_fwd_scatter", k_pp_fwd_scatter, dim3(cdiv((size_t)N, 256)), dim3(256), 0, (const float2 *)p,
+                  fb->winner.as<int>(), fb->W, fb->H));
+    *winners_dev = fb->winner.p;
+    return TF_OK;
+}
+
 TF_API int tf_fb_post_process_host(tf_fb *fb, float *flow_inout, int direction)
 {
     TF_REQUIRE(fb && flow_inout, "tf_fb_post_process_host: null pointer");

@@ -274,7 +274,8 @@ __global__ void k_remap_render(uchar4 *__restrict__ rgba, const float *__restric
 // through LDS so the 3-byte pixels leave as whole dwords.
 struct StepParams {
     MoveFlags fl;
-    int clip_flow;     // apply source.py:361-362 to the flow in registers (BACKWARD post_process)
+    int clip_flow;     // 1: apply source.py:361-362 to the flow in registers (BACKWARD post_process);
+                       // 2: `flow` is the winner map of a FORWARD post_process: source.py:359-362 in registers
     int reset_random;  // reset_mode == random
     float factor;
     int reset_source;
@@ -296,7 +297,14 @@ k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4
     uint8_t *s8 = reinterpret_cast<uint8_t *>(s_rgb);
     if (t < N) {
         const int i = t / W, j = t % W;
-        float2 f = flow[t];
+        float2 f;
+        if (sp.clip_flow == 2) {
+            const int w = reinterpret_cast<const int *>(flow)[t];
+            const int src = w >= 0 ? w : t;
+            f = make_float2((float)(src % W - j), (float)(src / W - i)); // source.py:359-360
+        } else {
+            f = flow[t];
+        }
         if (sp.clip_flow) {
             f.x = clip_nan(f.x, (float)(-j), (float)(W - 1 - j));
             f.y = clip_nan(f.y, (float)(-i), (float)(H - 1 - i));
@@ -387,6 +395,21 @@ __global__ void k_remap_clip_flow(float2 *flow, int W, int H)
         return;
     int i = t / W, j = t % W;
     float2 f = flow[t];
+    f.x = clip_nan(f.x, (float)(-j), (float)(W - 1 - j));
+    f.y = clip_nan(f.y, (float)(-i), (float)(H - 1 - i));
+    flow[t] = f;
+}
+
+// source.py:359-362 alone: the flow a FORWARD winner map stands for (the unfused step's first launch)
+__global__ void k_remap_winner_flow(const int *__restrict__ winner, float2 *__restrict__ flow, int W, int H)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= W * H)
+        return;
+    int i = t / W, j = t % W;
+    const int w = winner[t];
+    const int src = w >= 0 ? w : t;
+    float2 f = make_float2((float)(src % W - j), (float)(src / W - i));
     f.x = clip_nan(f.x, (float)(-j), (float)(W - 1 - j));
     f.y = clip_nan(f.y, (float)(-i), (float)(H - 1 - i));
     flow[t] = f;
@@ -611,6 +634,7 @@ struct tf_remap {
     int depth() const { return cfg.layer_class == TF_LAYER_INTRODUCTION ? 8 : (cfg.layer_class == TF_LAYER_STATIC ? 0 : 4); }
     DevBuf err;
     DevBuf scratch_flow, scratch_u, scratch_pix;
+    DevBuf flow_scratch; // tf_remap_step_dev's unfused form on a winner map: the flow it stands for
     uint64_t frame = 0;
     int4 *cur_data() { return data[cur].as<int4>(); }
 };
@@ -993,9 +1017,16 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     TF_TRY(ensure_init());
     if (L->N == 0)
         return TF_OK;
+    TF_REQUIRE(clip_flow >= 0 && clip_flow <= 2, "tf_remap_step_dev: clip_flow must be 0, 1 or 2, got %d", clip_flow);
     const bool fusable = !L->fl.leave_empty && (L->cfg.reset_mode == 0 || L->cfg.reset_mode == 1);
     if (!fusable) { // same statements, one launch each
-        if (clip_flow)
+        if (clip_flow == 2) { // the winner map becomes a flow array first (kept in the layer's own scratch)
+            if (!L->flow_scratch.p)
+                TF_TRY(L->flow_scratch.alloc((size_t)L->N * 8));
+            TF_TRY(launch("remap_winner_flow", k_remap_winner_flow, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
+                          (const int *)flow_dev, L->flow_scratch.as<float2>(), L->W, L->H));
+            flow_dev = L->flow_scratch.p;
+        } else if (clip_flow)
             TF_TRY(launch("remap_clip_flow", k_remap_clip_flow, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
                           (float2 *)const_cast<void *>(flow_dev), L->W, L->H));
         TF_TRY(tf_remap_update_dev(L, flow_dev, uniform_dev, seed));
@@ -1005,7 +1036,7 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     }
     StepParams sp;
     sp.fl = L->fl;
-    sp.clip_flow = clip_flow != 0;
+    sp.clip_flow = clip_flow;
     sp.reset_random = L->cfg.reset_mode == 1;
     sp.factor = (float)L->cfg.reset_random_factor;
     sp.reset_source = L->cfg.reset_source;

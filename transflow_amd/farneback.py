@@ -99,6 +99,13 @@ class Farneback:
     def post_process(self, pair: int, direction: int) -> None:
         check(self._lib.tf_fb_post_process(self._h, int(pair), int(direction)))
 
+    def post_process_scatter(self, pair: int) -> int:
+        """First half of FORWARD post_process: device address of the int32 [H, W] winner map
+        (RemapLayer.step_dev(..., clip_flow=2) does the rest)."""
+        p = C.c_void_p()
+        check(self._lib.tf_fb_post_process_scatter(self._h, int(pair), C.byref(p)))
+        return p.value
+
     def post_process_host(self, flow: np.ndarray, direction: int) -> np.ndarray:
         """In place on a float32 C-contiguous [H,W,2] array, like the reference."""
         if (not isinstance(flow, np.ndarray) or flow.dtype != np.float32 or not flow.flags.c_contiguous

@@ -140,10 +140,12 @@ class RemapLayer:
     def gather_dev(self, source_index: int, pixmap_dev: int, channels: int) -> None:
         check(self._lib.tf_remap_gather_dev(self._h, int(source_index), C.c_void_p(pixmap_dev), int(channels)))
 
-    def step_dev(self, comp: "CompImage", flow_dev: int, pixmap_dev: int, channels: int = 3, clip_flow: bool = False,
+    def step_dev(self, comp: "CompImage", flow_dev: int, pixmap_dev: int, channels: int = 3, clip_flow=False,
                  uniform_dev: int | None = None, seed: int = 0) -> None:
-        """update + gather(source 0) + begin + render in one call (one kernel when possible)."""
-        check(self._lib.tf_remap_step_dev(self._h, comp._h, C.c_void_p(flow_dev), int(bool(clip_flow)),
+        """update + gather(source 0) + begin + render in one call (one kernel when possible).
+        clip_flow: False / True (BACKWARD post_process, the clip alone, folded in) / 2 (flow_dev is the
+        winner map of Farneback.post_process_scatter: the rest of FORWARD post_process folded in)."""
+        check(self._lib.tf_remap_step_dev(self._h, comp._h, C.c_void_p(flow_dev), int(clip_flow),
                                           C.c_void_p(uniform_dev) if uniform_dev else None,
                                           C.c_uint64(seed & (2**64 - 1)), C.c_void_p(pixmap_dev), int(channels)))
 
