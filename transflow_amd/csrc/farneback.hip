@@ -22,10 +22,10 @@
 //
 // HBM layout (per handle, sized for `max_pairs` frame pairs):
 //   frames   u8  [slot][H][W]
-//   img      f32 [pair][2][Hk*Wk]          level image of both frames (A1 output, levels without a fused A1+A2)
+//   img      f32 [image][Hk*Wk]            level images (A1 output, levels without a fused A1+A2)
 //   rowf     f32 [level][image][H][2*Wk]   row-pass planes of the long-kernel levels
-//   R[2]     f32 [pair][2][5][Hk*Wk]       polynomial coefficients, planar (SoA), one set per call parity
-//   M[2]     f32 [pair][5][Hk*Wk]          2x2 systems, planar (two-kernel iterations only)
+//   R        f32 [image][5][Hk*Wk]         polynomial coefficients, planar (SoA); image = a frame of the batch
+//   M        f32 [pair][5][Hk*Wk]          2x2 systems, planar (two-kernel iterations only)
 //   lflow[5] f32 [pair][Hk*Wk][2]          per-level flow: three rotate, two hold the result of even / odd calls
 // Stencils, gathers and 2x2 solves (<= ~60 flop/B, no dense contraction): MFMA is not applicable.
 #include <cfloat>
@@ -1388,17 +1388,14 @@ k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, in
 }
 
 // ---------------------------------------------------------------------------------
-// A4 (+A3 of the next iteration): box blur of M over (2m+1)^2 with replicated
-// borders, 2x2 solve, optional recomputation of M from the new flow.
+// A4, any window width: box blur of M over (2m+1)^2 with replicated borders, 2x2 solve.
 // One block marches a strip of 256 columns (256-2m outputs + halo) down `seg`
 // rows, holding the vertical window sums of its column in double registers.
 // ---------------------------------------------------------------------------------
 constexpr int BS_THREADS = 256;
 
-template <bool UPDATE>
 __global__ void __launch_bounds__(BS_THREADS)
-k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__restrict__ flow_out,
-             const float *__restrict__ R, int Wk, int Hk, int m, double scale, int seg)
+k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, int m, double scale, int seg)
 {
     __shared__ double s_v[2][5][BS_THREADS];
     const int tid = threadIdx.x;
@@ -1417,7 +1414,6 @@ k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__
             vs[c] += (double)Mi[c * Nk + ro];
     }
     const bool is_out = tid >= m && tid < BS_THREADS - m && col < Wk;
-    const float *R0 = R + (size_t)pair * 10 * Nk, *R1 = R0 + 5 * Nk;
     int buf = 0;
     for (int y = r0; y < r1; y++) {
         if (y > r0) {
@@ -1442,16 +1438,7 @@ k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout, float2 *__
             double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
             float fx = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
             float fy = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
-            if (flow_out)
-                flow_out[(size_t)pair * Nk + (size_t)y * Wk + col] = make_float2(fx, fy);
-            if (UPDATE) {
-                float mm[5];
-                update_matrix_px(R0, R1, Nk, Wk, Hk, col, y, fx, fy, mm);
-                float *Mo = Mout + (size_t)pair * 5 * Nk + (size_t)y * Wk + col;
-#pragma unroll
-                for (int c = 0; c < 5; c++)
-                    Mo[c * Nk] = mm[c];
-            }
+            flow_out[(size_t)pair * Nk + (size_t)y * Wk + col] = make_float2(fx, fy);
         }
         buf ^= 1;
     }
@@ -2149,7 +2136,7 @@ struct tf_fb {
     int slots = 0, max_pairs = 0;
     PolyConst pc;
     std::vector<Level *> lv;
-    DevBuf frames, img, R, M[2], lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
+    DevBuf frames, img, R, M, lflow[5], pairs, winner, scratch; // lflow[3..4]: the result of even / odd calls
     DevBuf rowf; // row-pass planes of the split levels, [level][image][H][NC]
     int rp_RB = 0, rp_pitch = 0, rp_r4 = 0, rp_rmax = 0, rp_first = -1; // one k_level_rowpass launch serves them all
     int nsets = 1, cur = 0;                    // result buffers in rotation / the one this call writes
@@ -2448,17 +2435,17 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_images)
                   L.H, kc, k1, fb->pc);
 }
 
-static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int mbuf, int k = -1)
+static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int k = -1)
 {
     dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
     FlowInit f = fi;
     f.rmap = fb->rmap_dev;
     return launch(lvl_name("fb_update_matrices", k), k_update_matrices, grid, dim3(256), 0, (const float *)fb->Rk(k),
-                  fb->M[mbuf].as<float>(), w, h, f);
+                  fb->M.as<float>(), w, h, f);
 }
 
 template <int M>
-static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out, double scale, int k)
+static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, double scale, int k)
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
@@ -2473,24 +2460,24 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, int mbuf
     if (getenv("TF_BLUR_SEG"))
         seg = std::max(8, atoi(getenv("TF_BLUR_SEG")));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
-    return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M[mbuf_in].as<float>(),
+    return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M.as<float>(),
                   flow_out, w, h, scale, seg);
 }
 
-static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, float2 *flow_out, int k = -1)
+static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, int k = -1)
 {
     const int m = fb->prm.winsize / 2;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     switch (m) {
-    case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 3: return launch_blur_solve_wave<3>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 4: return launch_blur_solve_wave<4>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 5: return launch_blur_solve_wave<5>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 6: return launch_blur_solve_wave<6>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 7: return launch_blur_solve_wave<7>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 8: return launch_blur_solve_wave<8>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 10: return launch_blur_solve_wave<10>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
-    case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, mbuf_in, flow_out, scale, k);
+    case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 3: return launch_blur_solve_wave<3>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 4: return launch_blur_solve_wave<4>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 5: return launch_blur_solve_wave<5>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 6: return launch_blur_solve_wave<6>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 7: return launch_blur_solve_wave<7>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 8: return launch_blur_solve_wave<8>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 10: return launch_blur_solve_wave<10>(fb, w, h, n_pairs, flow_out, scale, k);
+    case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, flow_out, scale, k);
     default: break;
     }
     // any other window: the generic block-per-strip kernel
@@ -2499,9 +2486,8 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, int mbuf_in, floa
     long segs_wanted = std::max(1l, 1024 / std::max(1l, (long)strips * n_pairs));
     int seg = (int)std::min<long>(128, std::max<long>(16, (h + segs_wanted - 1) / segs_wanted));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
-    return launch("fb_blur_solve_generic", k_blur_solve<false>, grid, dim3(BS_THREADS), 0,
-                  (const float *)fb->M[mbuf_in].as<float>(), (float *)nullptr, flow_out,
-                  (const float *)fb->Rk(0), w, h, m, scale, seg);
+    return launch("fb_blur_solve_generic", k_blur_solve, grid, dim3(BS_THREADS), 0, (const float *)fb->M.as<float>(),
+                  flow_out, w, h, m, scale, seg);
 }
 
 // `up`: the first iteration of a level below the coarsest takes its flow from the coarser level (A5 fused)
@@ -2662,7 +2648,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
     fb->nsets = (fb_overlap_enabled() && fb->K > 0) ? 2 : 1; // a single scale: every launch fills the chip anyway
     if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
         (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
-        (rc = fb->M[0].alloc(P * 5 * N0 * 4)) || (rc = fb->M[1].alloc(P * 5 * N0 * 4)) ||
+        (rc = fb->M.alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
         (fb->nsets > 1 && ((rc = fb->lflow[3].alloc(P * N0 * 8)) || (rc = fb->lflow[4].alloc(P * N0 * 8)))) ||
@@ -2887,15 +2873,15 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             }
             result = p;
         } else {
-            TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, 0, k));
+            TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, k));
             FlowInit fl;
             memset(&fl, 0, sizeof(fl));
             fl.mode = 2;
             fl.src = fb->lflow[a].as<float2>();
             for (int i = 0; i < fb->prm.iterations; i++) {
-                TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, 0, fb->lflow[a].as<float2>(), k));
+                TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, fb->lflow[a].as<float2>(), k));
                 if (i < fb->prm.iterations - 1) // M is a pure function of (R0, R1, flow): rebuild it in place
-                    TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, 0, k));
+                    TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, k));
             }
             result = a;
         }
@@ -3130,8 +3116,8 @@ TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *
     memset(&fi, 0, sizeof(fi));
     fi.mode = 2;
     fi.src = fb->lflow[0].as<float2>();
-    TF_TRY(fb_update_matrices(fb, w, h, 1, fi, 0));
-    return download_planar5(m_out, fb->M[0].as<float>(), n, fb->scratch);
+    TF_TRY(fb_update_matrices(fb, w, h, 1, fi));
+    return download_planar5(m_out, fb->M.as<float>(), n, fb->scratch);
 }
 
 TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out)
@@ -3140,8 +3126,8 @@ TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float
     TF_TRY(check_stage_size(fb, w, h));
     TF_TRY(ensure_init());
     size_t n = (size_t)w * h;
-    TF_TRY(upload_planar5(fb->M[0].as<float>(), m, n, fb->scratch));
-    TF_TRY(fb_blur_solve(fb, w, h, 1, 0, fb->lflow[0].as<float2>()));
+    TF_TRY(upload_planar5(fb->M.as<float>(), m, n, fb->scratch));
+    TF_TRY(fb_blur_solve(fb, w, h, 1, fb->lflow[0].as<float2>()));
     TF_HIP(hipMemcpyAsync(flow_out, fb->lflow[0].p, n * 8, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
     return TF_OK;
