@@ -307,6 +307,62 @@ def test_fused_step_finishes_forward_post_process(tf, leave_empty):
     fb.close()
 
 
+def test_fused_step_state_in_int16_round_trips(tf):
+    """The fused step keeps the layer state as int16 x 4 between its own launches; any other entry point
+    sees the reference's int32 layout again.  Interleaves fused steps, a host update, state reads and a
+    restored checkpoint whose values do not fit int16 (the step then stays on int32)."""
+    from transflow_amd.device import DevBuffer
+    _, remap = tf
+    h, w = 120, 173
+    rng = np.random.default_rng(14)
+    pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pm_dev = DevBuffer.from_array(pm)
+    ora = R.MoveRefLayer(h, w, introduction_masks=[np.ones((h, w), bool)])
+    layer = remap.RemapLayer(h, w)
+    layer.set_sources([np.ones((h, w), np.uint8)])
+    comp = remap.CompImage(h, w, (9, 8, 7))
+
+    def flow_t(t):
+        return R.post_process(rng.normal(0, 3, (h, w, 2)).astype(np.float32), R.BACKWARD)
+
+    def fused(f):
+        buf = DevBuffer.from_array(f)
+        layer.step_dev(comp, buf.ptr, pm_dev.ptr, 3)
+        ora.update(f, [pm])
+        buf.close()
+
+    for t in range(2):
+        fused(flow_t(t))
+    np.testing.assert_array_equal(layer.get_state()[0], ora.data)          # read in the middle of a run
+    fused(flow_t(2))
+    f = flow_t(3)                                                          # the separate calls on the same layer
+    layer.update(f)
+    layer.gather(0, pm)
+    ora.update(f, [pm])
+    fused(flow_t(4))
+    data, rgba = layer.get_state()
+    np.testing.assert_array_equal(data, ora.data)
+    np.testing.assert_array_equal(rgba, ora.rgba)
+    exp = R.composite(np.broadcast_to(np.uint8([9, 8, 7]), (h, w, 3)), [ora.render()])
+    np.testing.assert_array_equal(comp.download(), exp)
+    # a checkpoint with a value outside int16 (extra/control.py may write anything into layer.data)
+    data = data.copy()
+    data[5, 6, 0] = 100000
+    data[7, 8, 1] = -70000
+    layer.set_state(data, rgba)
+    ora.data[...] = data
+    for t in range(5, 7):
+        fused(flow_t(t))
+    np.testing.assert_array_equal(layer.get_state()[0], ora.data)
+    assert (layer.get_state()[0] == 100000).any()
+    # ... and back to values that fit
+    layer.set_state(np.clip(layer.get_state()[0], 0, 100), None)
+    ora.data[...] = np.clip(ora.data, 0, 100)
+    fused(flow_t(7))
+    np.testing.assert_array_equal(layer.get_state()[0], ora.data)
+    assert not layer.out_of_frame()
+
+
 def test_flow_presteps_golden_gpu(tf):
     """scale / threshold / clip filters and the flow mask on the GPU (tf_fb_post_process_host_ex),
     through the FlowSource mirror, against the reference's outputs -- bit for bit, including which

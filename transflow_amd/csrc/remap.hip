@@ -11,6 +11,7 @@
 // pixel; masks one byte / one float per pixel, absent (nullptr) when default.
 // All kernels are bandwidth-bound, one pixel per lane, 16-byte accesses on `data`.
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -122,29 +123,21 @@ __global__ void k_remap_leave_empty(const float2 *__restrict__ flow, const int4 
         neu[s].z = 0;
 }
 
-// ---- Philox4x32-10 (counter-based; one 4x32 block per pixel and frame) ---------
-__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0,
-                                             uint32_t k1)
-{
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
-}
-
+// ---- Philox2x32-10 (counter-based, Salmon et al. 2011: Random123): one 2x32 block per pixel and frame
+// gives the 64 bits a float64 uniform needs.  Counter = (pixel, frame), key = the seed's halves mixed.
+// (The 4x32 form costs twice the multiplies for 128 bits of which 64 went unused; this kernel is bound
+// by its instructions, not by HBM.)
 __device__ __forceinline__ double philox_uniform(uint32_t pixel, uint64_t frame, uint64_t seed)
 {
-    uint32_t c0 = pixel, c1 = (uint32_t)frame, c2 = (uint32_t)(frame >> 32), c3 = 0x7f4a7c15u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t M = 0xD256D193u;
+    uint32_t c0 = pixel, c1 = (uint32_t)frame ^ ((uint32_t)(frame >> 32) * 0x85EBCA6Bu);
+    uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        philox_round(c0, c1, c2, c3, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+        const uint32_t hi = __umulhi(M, c0), lo = M * c0;
+        c0 = hi ^ k ^ c1;
+        c1 = lo;
+        k += 0x9E3779B9u;
     }
     // 53-bit mantissa, as numpy's random_sample builds it from two 32-bit draws
     return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) * (1.0 / 9007199254740992.0);
@@ -274,6 +267,8 @@ __global__ void k_remap_render(uchar4 *__restrict__ rgba, const float *__restric
 // through LDS so the 3-byte pixels leave as whole dwords.
 struct StepParams {
     MoveFlags fl;
+    uint32_t div_m;    // t / W without a division: fast_div below (W is the same for every pixel of a launch)
+    int div_s1, div_s2;
     int clip_flow;     // 1: apply source.py:361-362 to the flow in registers (BACKWARD post_process);
                        // 2: `flow` is the winner map of a FORWARD post_process: source.py:359-362 in registers
     int reset_random;  // reset_mode == random
@@ -284,9 +279,66 @@ struct StepParams {
     uchar4 bg;
 };
 
-template <int C>
+// The layer state in HBM: int32 x 4 per pixel as the reference keeps it (data.py:6-17), or -- while only
+// this kernel touches it -- int16 x 4: row, column, alpha and source index all fit, and the kernel is
+// HBM-bound with the state as 48 of its ~58 bytes per pixel.
+struct short4s {
+    short x, y, z, w;
+};
+__device__ __forceinline__ int4 state_load(const int4 *p, size_t t) { return p[t]; }
+__device__ __forceinline__ int4 state_load(const short4s *p, size_t t)
+{
+    const uint2 v = reinterpret_cast<const uint2 *>(p)[t];
+    return make_int4((short)(v.x & 0xffff), (short)(v.x >> 16), (short)(v.y & 0xffff), (short)(v.y >> 16));
+}
+__device__ __forceinline__ void state_store(int4 *p, size_t t, int4 d) { p[t] = d; }
+__device__ __forceinline__ void state_store(short4s *p, size_t t, int4 d)
+{
+    reinterpret_cast<uint2 *>(p)[t] = make_uint2(((unsigned)d.x & 0xffffu) | ((unsigned)d.y << 16),
+                                                 ((unsigned)d.z & 0xffffu) | ((unsigned)d.w << 16));
+}
+
+__global__ void k_state_pack(const int4 *__restrict__ src, short4s *__restrict__ dst, int N)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < N)
+        state_store(dst, t, src[t]);
+}
+
+__global__ void k_state_unpack(const short4s *__restrict__ src, int4 *__restrict__ dst, int N)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < N)
+        dst[t] = state_load(src, t);
+}
+
+// Unsigned division by a launch-wide constant d >= 1 (Granlund-Montgomery, round-up form): with
+// s = ceil(log2 d), m = floor(2^32 (2^s - d) / d) + 1:  q = (((t - hi) >> min(s,1)) + hi) >> max(s-1,0),
+// hi = umulhi(t, m).  Exact for every 32-bit t; 5 instructions instead of the ~40 of a division.
+struct FastDiv {
+    uint32_t m;
+    int s1, s2;
+};
+static FastDiv fast_div_setup(uint32_t d)
+{
+    int s = 0;
+    while ((1ull << s) < d)
+        s++;
+    FastDiv f;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    f.s1 = s < 1 ? s : 1;
+    f.s2 = s > 1 ? s - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t t, uint32_t m, int s1, int s2)
+{
+    const uint32_t hi = __umulhi(t, m);
+    return (((t - hi) >> s1) + hi) >> s2;
+}
+
+template <int C, typename S>
 __global__ void __launch_bounds__(BLOCK)
-k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4 *__restrict__ neu,
+k_remap_step(const float2 *__restrict__ flow, const S *__restrict__ old, S *__restrict__ neu,
              const uint8_t *__restrict__ msrc, const uint8_t *__restrict__ mdst, const double *__restrict__ u,
              const float *__restrict__ reset_mask, const uint8_t *__restrict__ intro, uchar4 *__restrict__ rgba,
              const uint8_t *__restrict__ pixmap, const float *__restrict__ mask_alpha, uint8_t *__restrict__ image,
@@ -296,12 +348,13 @@ k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     uint8_t *s8 = reinterpret_cast<uint8_t *>(s_rgb);
     if (t < N) {
-        const int i = t / W, j = t % W;
+        const int i = (int)fast_div((uint32_t)t, sp.div_m, sp.div_s1, sp.div_s2), j = t - i * W;
         float2 f;
         if (sp.clip_flow == 2) {
             const int w = reinterpret_cast<const int *>(flow)[t];
             const int src = w >= 0 ? w : t;
-            f = make_float2((float)(src % W - j), (float)(src / W - i)); // source.py:359-360
+            const int si = (int)fast_div((uint32_t)src, sp.div_m, sp.div_s1, sp.div_s2);
+            f = make_float2((float)(src - si * W - j), (float)(si - i)); // source.py:359-360
         } else {
             f = flow[t];
         }
@@ -310,7 +363,7 @@ k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4
             f.y = clip_nan(f.y, (float)(-i), (float)(H - 1 - i));
         }
         // --- move (movement.py:20-60)
-        int4 me = old[t];
+        int4 me = state_load(old, t);
         int4 d = me;
         long long off = flow_offset(f, W);
         if (off != 0) {
@@ -318,7 +371,7 @@ k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4
             if (s < 0 || s >= N) {
                 atomicOr(err, 1);
             } else {
-                int4 so = old[s];
+                int4 so = state_load(old, (size_t)s);
                 bool src_filled = so.z != 0;
                 bool ms = (msrc ? msrc[s] != 0 : true) && (sp.fl.transparent_can_move || src_filled);
                 bool md = (mdst ? mdst[t] != 0 : true) && (sp.fl.to_empty || me.z != 0) && (sp.fl.to_filled || me.z == 0);
@@ -343,7 +396,7 @@ k_remap_step(const float2 *__restrict__ flow, const int4 *__restrict__ old, int4
                             d.w = s;
             }
         }
-        neu[t] = d;
+        state_store(neu, t, d);
         // --- gather of source 0 (reference.py:94-105)
         bool sel = d.w == 0 && d.z != 0;
         uchar4 px;
@@ -636,8 +689,45 @@ struct tf_remap {
     DevBuf scratch_flow, scratch_u, scratch_pix;
     DevBuf flow_scratch; // tf_remap_step_dev's unfused form on a winner map: the flow it stands for
     uint64_t frame = 0;
+    // the fused step keeps the state as int16 x 4 (k_remap_step's note); every other entry point that
+    // touches `data` converts it back first (state_unpacked)
+    DevBuf pdata[2];
+    int pcur = 0;
+    bool packed = false;       // pdata[pcur] is current, data[cur] is stale
+    bool state_fits = true;    // false after a set_state with values outside int16
     int4 *cur_data() { return data[cur].as<int4>(); }
 };
+
+// Makes data[cur] (int32) the current state.
+static int state_unpacked(tf_remap *L)
+{
+    if (!L->packed)
+        return TF_OK;
+    TF_TRY(launch("remap_state_unpack", k_state_unpack, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
+                  (const short4s *)L->pdata[L->pcur].as<short4s>(), L->cur_data(), L->N));
+    L->packed = false;
+    return TF_OK;
+}
+
+static bool state_can_pack(const tf_remap *L)
+{
+    static const bool off = getenv("TF_REMAP_NO_PACK") && atoi(getenv("TF_REMAP_NO_PACK")) != 0;
+    return !off && L->state_fits && L->H <= 32767 && L->W <= 32767 && L->n_sources <= 32767;
+}
+
+// Makes pdata[pcur] (int16) the current state.
+static int state_packed(tf_remap *L)
+{
+    if (L->packed)
+        return TF_OK;
+    for (auto &b : L->pdata)
+        if (!b.p)
+            TF_TRY(b.alloc((size_t)L->N * sizeof(short4s)));
+    TF_TRY(launch("remap_state_pack", k_state_pack, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
+                  (const int4 *)L->cur_data(), L->pdata[L->pcur].as<short4s>(), L->N));
+    L->packed = true;
+    return TF_OK;
+}
 
 static int upload(DevBuf &buf, const void *host, size_t bytes)
 {
@@ -775,6 +865,7 @@ TF_API int tf_remap_set_sources(tf_remap *L, int n_sources, const uint8_t *const
         TF_HIP(hipMemcpyAsync(L->intro.as<uint8_t>() + n * s, introduction_masks[s], n, hipMemcpyHostToDevice,
                               stream()));
     }
+    TF_TRY(state_unpacked(L));
     if (L->depth() == 4) // ReferenceLayer.set_sources (reference.py:54-56); the other classes only keep the masks
         TF_TRY(launch("remap_set_sources", k_remap_set_sources, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, L->cur_data(),
                       L->intro.as<uint8_t>(), n_sources, L->N));
@@ -785,6 +876,7 @@ TF_API int tf_remap_set_sources(tf_remap *L, int n_sources, const uint8_t *const
 // Queues move (+ leave-empty) + reset on the stream, writing the other data buffer.
 static int queue_update(tf_remap *L, const float2 *flow, const double *u, uint64_t seed)
 {
+    TF_TRY(state_unpacked(L));
     int N = L->N;
     dim3 grid(cdiv((size_t)N, BLOCK)), block(BLOCK);
     const int4 *old = L->data[L->cur].as<int4>();
@@ -893,6 +985,7 @@ TF_API int tf_remap_gather_dev(tf_remap *L, int source_index, const void *pixmap
     TF_REQUIRE(L->cfg.layer_class != TF_LAYER_INTRODUCTION, "tf_remap_gather: an introduction layer takes its pixmaps "
                                                             "through tf_remap_introduce");
     TF_TRY(ensure_init());
+    TF_TRY(state_unpacked(L));
     dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
     if (L->cfg.layer_class == TF_LAYER_STATIC) {
         TF_REQUIRE(source_index >= 0 && source_index < L->n_sources, "tf_remap_gather: source %d of %d (set_sources first)",
@@ -984,6 +1077,7 @@ TF_API int tf_remap_get_state(tf_remap *L, int32_t *data, uint8_t *rgba)
 {
     TF_REQUIRE(L, "tf_remap_get_state: null handle");
     TF_TRY(ensure_init());
+    TF_TRY(state_unpacked(L));
     size_t n = (size_t)L->N;
     if (data && n && L->depth())
         TF_HIP(hipMemcpyAsync(data, L->cur_data(), n * 4 * L->depth(), hipMemcpyDeviceToHost, stream()));
@@ -997,7 +1091,14 @@ TF_API int tf_remap_set_state(tf_remap *L, const int32_t *data, const uint8_t *r
 {
     TF_REQUIRE(L, "tf_remap_set_state: null handle");
     TF_TRY(ensure_init());
+    TF_TRY(state_unpacked(L));
     size_t n = (size_t)L->N;
+    if (data && n && L->depth() == 4) { // a checkpoint may hold anything: the int16 form only for values that fit
+        bool fits = true;
+        for (size_t q = 0; q < n * 4 && fits; q++)
+            fits = data[q] >= -32768 && data[q] <= 32767;
+        L->state_fits = fits;
+    }
     if (data && n && L->depth())
         TF_HIP(hipMemcpyAsync(L->cur_data(), data, n * 4 * L->depth(), hipMemcpyHostToDevice, stream()));
     if (rgba && n)
@@ -1037,6 +1138,10 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     StepParams sp;
     sp.fl = L->fl;
     sp.clip_flow = clip_flow;
+    const FastDiv fd = fast_div_setup((uint32_t)L->W);
+    sp.div_m = fd.m;
+    sp.div_s1 = fd.s1;
+    sp.div_s2 = fd.s2;
     sp.reset_random = L->cfg.reset_mode == 1;
     sp.factor = (float)L->cfg.reset_random_factor;
     sp.reset_source = L->cfg.reset_source;
@@ -1045,22 +1150,31 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     sp.frame = L->frame;
     sp.bg = comp->bg;
     dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
-    const int4 *old = L->data[L->cur].as<int4>();
-    int4 *neu = L->data[L->cur ^ 1].as<int4>();
-    if (channels == 4)
-        TF_TRY(launch("remap_step_rgba", k_remap_step<4>, grid, block, 0, (const float2 *)flow_dev, old, neu,
+    auto run = [&](auto *old, auto *neu) {
+        using S = typename std::remove_const<typename std::remove_pointer<decltype(old)>::type>::type;
+        if (channels == 4)
+            return launch("remap_step_rgba", k_remap_step<4, S>, grid, block, 0, (const float2 *)flow_dev, old, neu,
+                          (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
+                          (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
+                          (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
+                          (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
+                          L->err.as<int>());
+        return launch("remap_step_rgb", k_remap_step<3, S>, grid, block, 0, (const float2 *)flow_dev, old, neu,
                       (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
                       (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
                       (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
                       (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
-                      L->err.as<int>()));
-    else
-        TF_TRY(launch("remap_step_rgb", k_remap_step<3>, grid, block, 0, (const float2 *)flow_dev, old, neu,
-                      (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
-                      (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
-                      (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
-                      (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
-                      L->err.as<int>()));
+                      L->err.as<int>());
+    };
+    if (state_can_pack(L)) {
+        TF_TRY(state_packed(L));
+        TF_TRY(run((const short4s *)L->pdata[L->pcur].as<short4s>(), L->pdata[L->pcur ^ 1].as<short4s>()));
+        L->pcur ^= 1;
+        L->frame++;
+        return TF_OK;
+    }
+    TF_TRY(state_unpacked(L));
+    TF_TRY(run((const int4 *)L->data[L->cur].as<int4>(), L->data[L->cur ^ 1].as<int4>()));
     L->cur ^= 1;
     L->frame++;
     return TF_OK;
