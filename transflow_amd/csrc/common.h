@@ -88,6 +88,30 @@ struct DevBuf {
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // numpy.clip semantics: minimum(maximum(v, lo), hi) with NaN propagated (fminf/fmaxf drop it)
+// Unsigned division by a launch-wide constant d >= 1 (Granlund-Montgomery, round-up form): with
+// s = ceil(log2 d), m = floor(2^32 (2^s - d) / d) + 1:  q = (((t - hi) >> min(s,1)) + hi) >> max(s-1,0),
+// hi = umulhi(t, m).  Exact for every 32-bit t; 5 instructions instead of the ~40 of a division.
+struct FastDiv {
+    uint32_t m;
+    int s1, s2;
+};
+inline FastDiv fast_div_setup(uint32_t d)
+{
+    int s = 0;
+    while ((1ull << s) < d)
+        s++;
+    FastDiv f;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    f.s1 = s < 1 ? s : 1;
+    f.s2 = s > 1 ? s - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t t, FastDiv f)
+{
+    const uint32_t hi = __umulhi(t, f.m);
+    return (((t - hi) >> f.s1) + hi) >> f.s2;
+}
+
 __device__ __forceinline__ float clip_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
 
 } // namespace tf

@@ -1853,23 +1853,25 @@ __device__ __forceinline__ float2 clip_to_frame(float2 f, int i, int j, int W, i
     return f;
 }
 
-__global__ void k_pp_clip(float2 *flow, int W, int H)
+__global__ void k_pp_clip(float2 *flow, int W, int H, FastDiv dw)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * H)
         return;
-    flow[t] = clip_to_frame(flow[t], t / W, t % W, W, H);
+    const int i = (int)fast_div((uint32_t)t, dw);
+    flow[t] = clip_to_frame(flow[t], i, t - i * W, W, H);
 }
 
 // source.py:350-358: every moving source p claims target p+d; numpy.put writes in
 // ascending p, so the largest p wins -> atomicMax on the source index.
-__global__ void k_pp_fwd_scatter(const float2 *__restrict__ flow, int *__restrict__ winner, int W, int H)
+__global__ void k_pp_fwd_scatter(const float2 *__restrict__ flow, int *__restrict__ winner, int W, int H, FastDiv dw)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = W * H;
     if (t >= N)
         return;
-    float2 f = clip_to_frame(flow[t], t / W, t % W, W, H);
+    const int i = (int)fast_div((uint32_t)t, dw);
+    float2 f = clip_to_frame(flow[t], i, t - i * W, W, H);
     int ix = (int)rintf(f.x), iy = (int)rintf(f.y);
     int d = iy * W + ix;
     if (d == 0)
@@ -1878,15 +1880,16 @@ __global__ void k_pp_fwd_scatter(const float2 *__restrict__ flow, int *__restric
     atomicMax(&winner[target], t);
 }
 
-__global__ void k_pp_fwd_resolve(float2 *__restrict__ flow, const int *__restrict__ winner, int W, int H)
+__global__ void k_pp_fwd_resolve(float2 *__restrict__ flow, const int *__restrict__ winner, int W, int H, FastDiv dw)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * H)
         return;
     int w = winner[t];
     int src = w >= 0 ? w : t;
-    int i = t / W, j = t % W;
-    float2 f = make_float2((float)(src % W - j), (float)(src / W - i)); // source.py:359-360
+    const int i = (int)fast_div((uint32_t)t, dw), j = t - i * W;
+    const int si = (int)fast_div((uint32_t)src, dw);
+    float2 f = make_float2((float)(src - si * W - j), (float)(si - i)); // source.py:359-360
     flow[t] = clip_to_frame(f, i, j, W, H);                            // :361-362
 }
 
@@ -2934,14 +2937,15 @@ static int pp_run(tf_fb *fb, float2 *flow, int direction)
                direction);
     const int N = fb->W * fb->H;
     dim3 grid(cdiv((size_t)N, 256)), block(256);
+    const FastDiv dw = fast_div_setup((uint32_t)fb->W);
     if (direction == 0) {
         TF_HIP(hipMemsetAsync(fb->winner.p, 0xFF, (size_t)N * 4, stream()));
         TF_TRY(launch("pp_fwd_scatter", k_pp_fwd_scatter, grid, block, 0, (const float2 *)flow, fb->winner.as<int>(),
-                      fb->W, fb->H));
+                      fb->W, fb->H, dw));
         return launch("pp_fwd_resolve", k_pp_fwd_resolve, grid, block, 0, flow, (const int *)fb->winner.as<int>(), fb->W,
-                      fb->H);
+                      fb->H, dw);
     }
-    return launch("pp_clip", k_pp_clip, grid, block, 0, flow, fb->W, fb->H);
+    return launch("pp_clip", k_pp_clip, grid, block, 0, flow, fb->W, fb->H, dw);
 }
 
 static int pp_ops_run(tf_fb *fb, float2 *flow, int n_ops, const tf_flow_op *ops, const float *mask_dev)
@@ -3016,7 +3020,7 @@ TF_API int tf_fb_post_process_scatter(tf_fb *fb, int pair, void **winners_dev)
     const int N = fb->W * fb->H;
     TF_HIP(hipMemsetAsync(fb->winner.p, 0xFF, (size_t)N * 4, stream()));
     TF_TRY(launch("pp_fwd_scatter", k_pp_fwd_scatter, dim3(cdiv((size_t)N, 256)), dim3(256), 0, (const float2 *)p,
-                  fb->winner.as<int>(), fb->W, fb->H));
+                  fb->winner.as<int>(), fb->W, fb->H, fast_div_setup((uint32_t)fb->W)));
     *winners_dev = fb->winner.p;
     return TF_OK;
 }

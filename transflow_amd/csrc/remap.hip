@@ -267,8 +267,7 @@ __global__ void k_remap_render(uchar4 *__restrict__ rgba, const float *__restric
 // through LDS so the 3-byte pixels leave as whole dwords.
 struct StepParams {
     MoveFlags fl;
-    uint32_t div_m;    // t / W without a division: fast_div below (W is the same for every pixel of a launch)
-    int div_s1, div_s2;
+    FastDiv div;       // t / W without a division (W is the same for every pixel of a launch)
     int clip_flow;     // 1: apply source.py:361-362 to the flow in registers (BACKWARD post_process);
                        // 2: `flow` is the winner map of a FORWARD post_process: source.py:359-362 in registers
     int reset_random;  // reset_mode == random
@@ -312,30 +311,6 @@ __global__ void k_state_unpack(const short4s *__restrict__ src, int4 *__restrict
         dst[t] = state_load(src, t);
 }
 
-// Unsigned division by a launch-wide constant d >= 1 (Granlund-Montgomery, round-up form): with
-// s = ceil(log2 d), m = floor(2^32 (2^s - d) / d) + 1:  q = (((t - hi) >> min(s,1)) + hi) >> max(s-1,0),
-// hi = umulhi(t, m).  Exact for every 32-bit t; 5 instructions instead of the ~40 of a division.
-struct FastDiv {
-    uint32_t m;
-    int s1, s2;
-};
-static FastDiv fast_div_setup(uint32_t d)
-{
-    int s = 0;
-    while ((1ull << s) < d)
-        s++;
-    FastDiv f;
-    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
-    f.s1 = s < 1 ? s : 1;
-    f.s2 = s > 1 ? s - 1 : 0;
-    return f;
-}
-__device__ __forceinline__ uint32_t fast_div(uint32_t t, uint32_t m, int s1, int s2)
-{
-    const uint32_t hi = __umulhi(t, m);
-    return (((t - hi) >> s1) + hi) >> s2;
-}
-
 template <int C, typename S>
 __global__ void __launch_bounds__(BLOCK)
 k_remap_step(const float2 *__restrict__ flow, const S *__restrict__ old, S *__restrict__ neu,
@@ -348,12 +323,12 @@ k_remap_step(const float2 *__restrict__ flow, const S *__restrict__ old, S *__re
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     uint8_t *s8 = reinterpret_cast<uint8_t *>(s_rgb);
     if (t < N) {
-        const int i = (int)fast_div((uint32_t)t, sp.div_m, sp.div_s1, sp.div_s2), j = t - i * W;
+        const int i = (int)fast_div((uint32_t)t, sp.div), j = t - i * W;
         float2 f;
         if (sp.clip_flow == 2) {
             const int w = reinterpret_cast<const int *>(flow)[t];
             const int src = w >= 0 ? w : t;
-            const int si = (int)fast_div((uint32_t)src, sp.div_m, sp.div_s1, sp.div_s2);
+            const int si = (int)fast_div((uint32_t)src, sp.div);
             f = make_float2((float)(src - si * W - j), (float)(si - i)); // source.py:359-360
         } else {
             f = flow[t];
@@ -1138,10 +1113,7 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     StepParams sp;
     sp.fl = L->fl;
     sp.clip_flow = clip_flow;
-    const FastDiv fd = fast_div_setup((uint32_t)L->W);
-    sp.div_m = fd.m;
-    sp.div_s1 = fd.s1;
-    sp.div_s2 = fd.s2;
+    sp.div = fast_div_setup((uint32_t)L->W);
     sp.reset_random = L->cfg.reset_mode == 1;
     sp.factor = (float)L->cfg.reset_random_factor;
     sp.reset_source = L->cfg.reset_source;
