@@ -110,6 +110,12 @@ int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint
    previous result keeps running beside it), so a caller that fills frame slots on the device itself (through tf_fb_frame_ptr) calls tf_sync() before the next tf_fb_calc_slots;
    tf_fb_set_frame already returns with the frame in place. */
 int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t stride);
+/* Streaming use (cv.py:460-490 holds prev_gray and reads one new frame per call): with `on`, the
+   pyramid levels and polynomial expansion of a slot are kept from call to call and redone only
+   after tf_fb_set_frame wrote the slot, so the frame that was "next" in one call costs nothing as
+   "prev" in the following one.  Slots handed out by tf_fb_frame_ptr are expanded on every call.
+   Needs frame_slots <= 2 * max_pairs.  Off by default: a call then depends on nothing but the frames. */
+int tf_fb_keep_expansions(tf_fb *fb, int on);
 int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev);
 int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const int *next_slots);
 int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out);

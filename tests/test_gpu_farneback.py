@@ -207,6 +207,51 @@ def test_shared_frames_are_expanded_once_with_identical_results(FB, monkeypatch)
     assert np.abs(out["0"][4]).max() < 0.5
 
 
+def test_kept_expansions_stream_like_fresh_calls(FB):
+    """tf_fb_keep_expansions: a stream of frames through two alternating slots, one new frame per call
+    (what HipFlowSource does), equals a fresh handle per pair bit for bit -- also after a slot is
+    rewritten out of turn, when nothing at all needs expanding, and for a slot written on the device."""
+    import ctypes as C
+    from transflow_amd import _lib
+    h, w = 270, 480
+    frames = [synth_pair(h, w, seed=95, shift=(0.9 * i, 0.6 * i))[1] for i in range(6)]
+
+    def fresh(a, b):
+        fb = FB(w, h, levels=3)
+        out = fb.calc(a, b)
+        fb.close()
+        return out
+
+    fb = FB(w, h, levels=3, frame_slots=2, max_pairs=1)
+    fb.keep_expansions(True)
+    fb.set_frame(0, frames[0])
+    prev = 0
+    for t in range(1, 5):
+        new = prev ^ 1
+        fb.set_frame(new, frames[t])
+        fb.calc_slots([new], [prev])                                   # BACKWARD ordering (cv.py:470-472)
+        np.testing.assert_array_equal(fb.get_flow(0), fresh(frames[t], frames[t - 1]), err_msg=f"frame {t}")
+        prev = new
+    fb.calc_slots([prev], [prev ^ 1])                                  # nothing was written: no expansion at all
+    np.testing.assert_array_equal(fb.get_flow(0), fresh(frames[4], frames[3]))
+    fb.set_frame(prev, frames[5])                                      # the slot that would have been kept
+    fb.calc_slots([prev ^ 1], [prev])
+    np.testing.assert_array_equal(fb.get_flow(0), fresh(frames[3], frames[5]))
+    # a slot the caller writes on the device is expanded every time
+    lib = _lib.load()
+    ptr = fb.frame_ptr(0)
+    for f in (frames[1], frames[2]):
+        _lib.check(lib.tf_dev_upload(C.c_void_p(ptr), C.c_void_p(f.ctypes.data), f.nbytes))
+        fb.calc_slots([0], [1])                                        # tf_dev_upload returns with the bytes in place
+        other = frames[5] if prev == 1 else frames[3]
+        np.testing.assert_array_equal(fb.get_flow(0), fresh(f, other))
+    fb.close()
+    big = FB(w, h, levels=3, frame_slots=5, max_pairs=2)
+    with pytest.raises(ValueError):
+        big.keep_expansions(True)                                       # 5 slots, room for 4 expansions
+    big.close()
+
+
 def test_pipelined_calls_equal_single_calls(FB):
     """tf_fb_calc_slots only enqueues: six calls issued back to back without a host synchronisation
     (the next call's frame expansion runs on the second stream beside the previous call's

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "tf_fb_calc_slots": (_I, [_P, _I, _PI, _PI]),
     "tf_fb_get_flow": (_I, [_P, _I, _P]),
     "tf_fb_flow_ptr": (_I, [_P, _I, _PP]),
+    "tf_fb_keep_expansions": (_I, [_P, _I]),
     "tf_fb_post_process": (_I, [_P, _I, _I]),
     "tf_fb_post_process_scatter": (_I, [_P, _I, _PP]),
     "tf_fb_post_process_host": (_I, [_P, _P, _I]),

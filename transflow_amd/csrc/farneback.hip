@@ -28,6 +28,7 @@
 //   M        f32 [pair][5][Hk*Wk]          2x2 systems, planar (two-kernel iterations only)
 //   lflow[5] f32 [pair][Hk*Wk][2]          per-level flow: three rotate, two hold the result of even / odd calls
 // Stencils, gathers and 2x2 solves (<= ~60 flop/B, no dense contraction): MFMA is not applicable.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -2148,7 +2149,7 @@ struct tf_fb {
     hipEvent_t entry[2] = {nullptr, nullptr};  // position of the library stream when call (parity) was issued
     bool entry_pending[2] = {false, false};
     hipEvent_t chain_done = nullptr;           // end of the latest call's work on chain_stream
-    int2 *pairs_host = nullptr;                // pinned staging: the call's image list (slots, 2P ints), then its pair -> image map (P int2)
+    int2 *pairs_host = nullptr;                // pinned staging: the call's image list (slots, up to 4P ints), then its pair -> image map (P int2)
     const int2 *rmap_dev = nullptr;            // that map on the device while a batch is being issued; null: images 2p, 2p+1
     std::vector<int> image_of;                 // slot -> index in the image list of the call being issued
     hipEvent_t pairs_copied = nullptr;
@@ -2160,6 +2161,14 @@ struct tf_fb {
     // otherwise.  TF_FB_FUSED=0 / 1 forces never / always.
     int fused = getenv("TF_FB_FUSED") ? atoi(getenv("TF_FB_FUSED")) : -1;
     float *Rk(int k) { return (k <= 0 ? R : lv[k]->R).as<float>(); }
+    // where the expansion launches being issued write and which part of the image list they read
+    // (tf_fb_calc_slots; zero outside it)
+    int prep_image0 = 0, prep_list0 = 0;
+    float *Rk_out(int k) { return Rk(k) + (size_t)prep_image0 * 5 * (k <= 0 ? (size_t)W * H : (size_t)lv[k]->W * lv[k]->H); }
+    const int2 *image_list() { return pairs.as<int2>() + prep_list0; }
+    // tf_fb_keep_expansions: R is indexed by frame slot and an expansion stays valid until its slot is written
+    bool keep = false;
+    std::vector<char> expanded, external;
     float *imgk(int k) { return (k <= 0 ? img : lv[k]->img).as<float>(); }
     ~tf_fb()
     {
@@ -2221,7 +2230,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone = fals
             const size_t smem_rp = (size_t)fb->rp_RB * fb->rp_pitch + taps * sizeof(float);
             TF_TRY(launch(lvl_name("fb_level_rowpass", -1), k_level_rowpass, dim3(cdiv(fb->H, fb->rp_RB), n_images),
                           dim3(256), smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(),
-                          (const int2 *)fb->pairs.as<int2>(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
+                          fb->image_list(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
                           fb->rp_rmax));
         }
         const size_t smem_cp = ((size_t)L.cp_LH * 2 * CP_TX + L.ksz) * sizeof(float);
@@ -2236,7 +2245,7 @@ static int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone = fals
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_images);
     size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
     return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
-                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->imgk(k),
+                  (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->imgk(k),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
 }
 
@@ -2384,13 +2393,13 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
     dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
     if (n == 5)
         return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->imgk(k),
-                      fb->Rk(k), w, h, fb->pc);
+                      fb->Rk_out(k), w, h, fb->pc);
     if (n == 7)
         return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->imgk(k),
-                      fb->Rk(k), w, h, fb->pc);
+                      fb->Rk_out(k), w, h, fb->pc);
     size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
     return launch(lvl_name("fb_polyexp_generic", k), k_polyexp, grid, dim3(256), smem,
-                  (const float *)fb->imgk(k), fb->Rk(k), w, h, fb->pc);
+                  (const float *)fb->imgk(k), fb->Rk_out(k), w, h, fb->pc);
 }
 
 // A1+A2 fusion applies to a level that is a copy-sized resize of the frame with the 3-tap blur
@@ -2417,10 +2426,10 @@ static int fb_level1_polyexp(tf_fb *fb, int k, int n_images)
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), 0,
-                      (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), fb->W,
+                      (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k), fb->W,
                       fb->H, kc, k1, fb->pc);
     return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<7>, grid, dim3(256), 0,
-                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), fb->W, fb->H,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k), fb->W, fb->H,
                   kc, k1, fb->pc);
 }
 
@@ -2431,10 +2440,10 @@ static int fb_level0_polyexp(tf_fb *fb, int k, int n_images)
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
-                      (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k),
+                      (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k),
                       L.W, L.H, kc, k1, fb->pc);
     return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), 0,
-                  (const uint8_t *)fb->frames.as<uint8_t>(), (const int2 *)fb->pairs.as<int2>(), fb->Rk(k), L.W,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k), L.W,
                   L.H, kc, k1, fb->pc);
 }
 
@@ -2655,7 +2664,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
         (fb->nsets > 1 && ((rc = fb->lflow[3].alloc(P * N0 * 8)) || (rc = fb->lflow[4].alloc(P * N0 * 8)))) ||
-        (rc = fb->pairs.alloc(2 * P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
+        (rc = fb->pairs.alloc(3 * P * 8)) || (rc = fb->winner.alloc(N0 * 4)) || (rc = fb->scratch.alloc(N0 * 20)))
         return fail(rc);
     for (int k = 1; k <= fb->K; k++) {
         Level &L = *fb->lv[k];
@@ -2706,7 +2715,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         hipEventCreateWithFlags(&fb->entry[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->entry[1], hipEventDisableTiming) != hipSuccess ||
         side_stream(1, &fb->chain_stream) != TF_OK ||
-        hipHostMalloc((void **)&fb->pairs_host, 2 * P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void **)&fb->pairs_host, 3 * P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "creating the handle's events and staging buffer failed"));
     *out = fb;
     return TF_OK;
@@ -2737,6 +2746,8 @@ TF_API int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t s
     TF_REQUIRE(stride >= fb->W, "tf_fb_set_frame: stride %td smaller than width %d", stride, fb->W);
     TF_TRY(ensure_init());
     uint8_t *dst = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
+    if (fb->keep)
+        fb->expanded[slot] = 0;
     TF_HIP(hipMemcpy2DAsync(dst, fb->W, grey, (size_t)stride, fb->W, fb->H, hipMemcpyHostToDevice, stream()));
     TF_HIP(hipStreamSynchronize(stream())); // the host frame is borrowed for this call only
     return TF_OK;
@@ -2746,7 +2757,21 @@ TF_API int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev)
 {
     TF_REQUIRE(fb && dev, "tf_fb_frame_ptr: null pointer");
     TF_REQUIRE(slot >= 0 && slot < fb->slots, "tf_fb_frame_ptr: slot %d out of range", slot);
+    if (fb->keep)
+        fb->external[slot] = 1; // written behind the library's back from now on: expanded on every call
     *dev = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
+    return TF_OK;
+}
+
+TF_API int tf_fb_keep_expansions(tf_fb *fb, int on)
+{
+    TF_REQUIRE(fb, "tf_fb_keep_expansions: null handle");
+    TF_REQUIRE(!on || fb->slots <= 2 * fb->max_pairs, "tf_fb_keep_expansions: %d frame slots need room for %d expansions, "
+                                                      "the handle holds %d (2 x max_pairs)", fb->slots, fb->slots,
+               2 * fb->max_pairs);
+    fb->keep = on != 0;
+    fb->expanded.assign((size_t)fb->slots, 0);
+    fb->external.assign((size_t)fb->slots, 0);
     return TF_OK;
 }
 
@@ -2766,25 +2791,60 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     // A1+A2 depend on the frame alone, and consecutive pairs of a video share one: every slot the batch
     // names is expanded once (16 consecutive pairs: 17 expansions, not 32) and each pair carries the
     // indices of its two.  TF_FB_NO_SHARE=1: one expansion per pair and side, as separate calls would do.
+    // With tf_fb_keep_expansions an image IS its slot and survives the call: only slots written since
+    // their last expansion are listed, in runs of consecutive slots (a run = one set of launches).
     const bool no_share = getenv("TF_FB_NO_SHARE") && atoi(getenv("TF_FB_NO_SHARE")) != 0; // read per call
     const int P = fb->max_pairs;
-    int *image_slot = reinterpret_cast<int *>(fb->pairs_host); // [2P], read by the kernels as int2[P]
-    int2 *rmap_host = fb->pairs_host + P;
-    int n_images = 0;
-    fb->image_of.assign((size_t)fb->slots, -1);
-    auto image = [&](int slot) {
-        if (no_share || fb->image_of[slot] < 0) {
-            fb->image_of[slot] = n_images;
-            image_slot[n_images++] = slot;
-        }
-        return fb->image_of[slot];
+    int *image_slot = reinterpret_cast<int *>(fb->pairs_host); // [4P]: the runs, each padded to an even length
+    int2 *rmap_host = fb->pairs_host + 2 * P;
+    struct Run {
+        int image0, list0, n; // first image index written, offset into image_slot (even), images
     };
-    for (int i = 0; i < n_pairs; i++) {
-        const int a = image(prev_slots[i]);
-        rmap_host[i] = make_int2(a, image(next_slots[i]));
+    std::vector<Run> runs;
+    if (fb->keep) {
+        std::vector<int> need;
+        fb->image_of.assign((size_t)fb->slots, -1);
+        for (int i = 0; i < n_pairs; i++) {
+            for (int s : {prev_slots[i], next_slots[i]})
+                if (fb->image_of[s] < 0 && (!fb->expanded[s] || fb->external[s])) {
+                    fb->image_of[s] = 1;
+                    need.push_back(s);
+                }
+            rmap_host[i] = make_int2(prev_slots[i], next_slots[i]);
+        }
+        std::sort(need.begin(), need.end());
+        int off = 0;
+        for (size_t q = 0; q < need.size();) {
+            size_t e = q + 1;
+            while (e < need.size() && need[e] == need[e - 1] + 1)
+                e++;
+            runs.push_back({need[q], off, (int)(e - q)});
+            for (size_t j = q; j < e; j++)
+                image_slot[off++] = need[j];
+            if (off & 1)
+                image_slot[off++] = need[q];
+            q = e;
+        }
+        for (int s : need)
+            fb->expanded[s] = 1;
+    } else {
+        int n_images = 0;
+        fb->image_of.assign((size_t)fb->slots, -1);
+        auto image = [&](int slot) {
+            if (no_share || fb->image_of[slot] < 0) {
+                fb->image_of[slot] = n_images;
+                image_slot[n_images++] = slot;
+            }
+            return fb->image_of[slot];
+        };
+        for (int i = 0; i < n_pairs; i++) {
+            const int a = image(prev_slots[i]);
+            rmap_host[i] = make_int2(a, image(next_slots[i]));
+        }
+        if (n_images & 1)
+            image_slot[n_images] = image_slot[0]; // the unused half of the last int2
+        runs.push_back({0, 0, n_images});
     }
-    if (n_images & 1)
-        image_slot[n_images] = image_slot[0]; // the unused half of the last int2
     const int m = fb->prm.winsize / 2;
     const bool fusable = m == 3 || m == 5 || m == 7; // the pair-sum window of the fused kernel
     // A call's work goes to a stream of its own.  The library stream -- where the caller's work on the
@@ -2806,28 +2866,37 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     }
     // Frames: tf_fb_set_frame returns with the frame in place; a caller writing frames on the device
     // orders that itself (tfhip.h).
-    TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)2 * P * sizeof(int2), hipMemcpyHostToDevice, cs));
+    TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)3 * P * sizeof(int2), hipMemcpyHostToDevice, cs));
     TF_HIP(hipEventRecord(fb->pairs_copied, cs));
     fb->pairs_pending = true;
-    struct MapScope { // the chain launchers below read the map from the handle; stage entry points run without one
+    struct MapScope { // the launchers below read these from the handle; stage entry points run without them
         tf_fb *fb;
-        ~MapScope() { fb->rmap_dev = nullptr; }
+        ~MapScope()
+        {
+            fb->rmap_dev = nullptr;
+            fb->prep_image0 = fb->prep_list0 = 0;
+        }
     } map_scope{fb};
-    fb->rmap_dev = fb->pairs.as<int2>() + P;
+    fb->rmap_dev = fb->pairs.as<int2>() + 2 * P;
     StreamScope chain_scope(cs);
     // A1+A2 of every level (they depend on the frames only), coarse level first: the shared row pass
     // of the long-kernel levels is launched with the coarsest of them
-    for (int k = fb->K; k >= 0; k--) {
-        Level &L = *fb->lv[k];
-        if (fb_can_fuse_level(fb, k)) {
-            TF_TRY(fb_level0_polyexp(fb, k, n_images)); // A1+A2 in one kernel: the level image stays on chip
-        } else if (fb_can_fuse_half_level(fb, k)) {
-            TF_TRY(fb_level1_polyexp(fb, k, n_images));
-        } else {
-            TF_TRY(fb_level_image(fb, k, n_images));
-            TF_TRY(fb_polyexp(fb, L.W, L.H, n_images, k));
+    for (const Run &run : runs) {
+        fb->prep_image0 = run.image0;
+        fb->prep_list0 = run.list0 / 2;
+        for (int k = fb->K; k >= 0; k--) {
+            Level &L = *fb->lv[k];
+            if (fb_can_fuse_level(fb, k)) {
+                TF_TRY(fb_level0_polyexp(fb, k, run.n)); // A1+A2 in one kernel: the level image stays on chip
+            } else if (fb_can_fuse_half_level(fb, k)) {
+                TF_TRY(fb_level1_polyexp(fb, k, run.n));
+            } else {
+                TF_TRY(fb_level_image(fb, k, run.n));
+                TF_TRY(fb_polyexp(fb, L.W, L.H, run.n, k));
+            }
         }
     }
+    fb->prep_image0 = fb->prep_list0 = 0;
     int coarse = -1; // lflow buffer holding the coarser level's result
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];

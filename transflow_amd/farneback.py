@@ -99,6 +99,10 @@ class Farneback:
     def post_process(self, pair: int, direction: int) -> None:
         check(self._lib.tf_fb_post_process(self._h, int(pair), int(direction)))
 
+    def keep_expansions(self, on: bool = True) -> None:
+        """Streaming: a slot's pyramid and polynomial expansion stay valid until set_frame writes it."""
+        check(self._lib.tf_fb_keep_expansions(self._h, int(bool(on))))
+
     def post_process_scatter(self, pair: int) -> int:
         """First half of FORWARD post_process: device address of the int32 [H, W] winner map
         (RemapLayer.step_dev(..., clip_flow=2) does the rest)."""

@@ -482,6 +482,7 @@ class HipFlowSource(FlowSource):
         if self._fb is None:
             from .farneback import Farneback
             self._fb = Farneback(self.width, self.height, device=self.device, **self.config.fb_kwargs())
+            self._fb.keep_expansions(True)  # the frame that was "next" stays expanded for its turn as "prev"
             self._pp = self._fb  # one handle serves both calls
         return self._fb
 
