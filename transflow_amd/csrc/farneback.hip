@@ -2825,8 +2825,6 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
                 image_slot[off++] = need[q];
             q = e;
         }
-        for (int s : need)
-            fb->expanded[s] = 1;
     } else {
         int n_images = 0;
         fb->image_of.assign((size_t)fb->slots, -1);
@@ -2897,6 +2895,10 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         }
     }
     fb->prep_image0 = fb->prep_list0 = 0;
+    if (fb->keep) // valid from here on (until tf_fb_set_frame writes the slot)
+        for (const Run &run : runs)
+            for (int j = 0; j < run.n; j++)
+                fb->expanded[run.image0 + j] = 1;
     int coarse = -1; // lflow buffer holding the coarser level's result
     for (int k = fb->K; k >= 0; k--) {
         Level &L = *fb->lv[k];
