@@ -239,8 +239,8 @@ def cpu_baseline(wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", default=None, help="WxH: run the chosen workload's configuration at another frame size")
