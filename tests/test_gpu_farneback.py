@@ -101,6 +101,32 @@ CASES = [
 ]
 
 
+SWEEP = [
+    ((360, 642), dict(levels=4, pyr_scale=0.7)),                 # non-dyadic pyramid: every level resized with fractions
+    ((358, 639), dict(levels=3, pyr_scale=0.5, winsize=21)),     # odd sizes, window half-width 10
+    ((240, 320), dict(levels=2, winsize=25, iterations=5)),      # half-width 12, more iterations
+    ((300, 400), dict(levels=3, winsize=5, iterations=1)),       # half-width 2, a single iteration
+    ((270, 482), dict(levels=5, poly_n=7, poly_sigma=1.5)),      # width % 4 != 0: no split level images
+    ((540, 960), dict(levels=5, poly_n=5, poly_sigma=1.1)),      # quarter-4K: the bench's level structure
+    ((128, 4096), dict(levels=2)),                               # wide and flat
+    ((2048, 64), dict(levels=1)),                                # tall and narrow
+    ((90, 130), dict(levels=1, pyr_scale=0.3)),                  # a big step between two scales
+]
+
+
+@pytest.mark.parametrize("shape,kw", SWEEP)
+def test_parameter_sweep_close(FB, shape, kw):
+    """More of cv.py:273-281's parameter space against the oracle, default kernel choice per level."""
+    h, w = shape
+    a, b = synth_pair(h, w, seed=31, shift=(2.0, -1.5))
+    ref = O.calc(a, b, **kw)
+    fb = FB(w, h, **kw)
+    got = fb.calc(a, b)
+    err = np.abs(got - ref).max()
+    assert err <= flow_tol(ref), f"max|d|={err} tol={flow_tol(ref)}"
+    fb.close()
+
+
 @pytest.mark.parametrize("shape,kw", CASES)
 def test_full_calc_close(FB, shape, kw):
     h, w = shape
