@@ -61,7 +61,7 @@ def test_polyexp_bit_exact(FB, shape, poly):
     fb.close()
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (67, 131), (270, 480), (11, 13)])
+@pytest.mark.parametrize("shape", [(64, 64), (67, 131), (270, 480), (11, 13), (9, 40), (40, 9), (7, 8), (3, 12), (1, 1)])
 def test_update_matrices_bit_exact(FB, shape):
     h, w = shape
     rng = np.random.default_rng(4)
@@ -125,6 +125,43 @@ def test_parameter_sweep_close(FB, shape, kw):
     err = np.abs(got - ref).max()
     assert err <= flow_tol(ref), f"max|d|={err} tol={flow_tol(ref)}"
     fb.close()
+
+
+def test_small_and_degenerate_shapes_close(FB):
+    """Every shape down to one pixel, one row and one column, odd and prime sizes, with random pyramid
+    depth and window: the path never reads outside a frame and stays within tolerance of the oracle."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1), (1, 2), (2, 1), (2, 2), (3, 3), (1, 64), (64, 1), (1, 300), (300, 1), (3, 130), (130, 3),
+              (31, 33), (32, 32), (33, 31), (63, 65), (64, 64), (65, 63)]
+    shapes += [(int(rng.integers(1, 90)), int(rng.integers(1, 150))) for _ in range(14)]
+    for h, w in shapes:
+        kw = dict(levels=int(rng.integers(0, 4)), winsize=int(rng.choice([5, 7, 9, 11, 15, 21])),
+                  iterations=int(rng.integers(1, 4)), poly_n=int(rng.choice([5, 7])))
+        kw["poly_sigma"] = 1.2 if kw["poly_n"] == 5 else 1.5
+        a, b = synth_pair(h, w, seed=h * 1000 + w, shift=(1.2, -0.7), noise=2.0)
+        ref = O.calc(a, b, **kw)
+        fb = FB(w, h, **kw)
+        got = fb.calc(a, b)
+        fb.close()
+        assert got.shape == (h, w, 2) and np.isfinite(got).all(), f"{h}x{w} {kw}"
+        err = np.abs(got - ref).max()
+        assert err <= flow_tol(ref), f"{h}x{w} {kw}: max|d|={err} tol={flow_tol(ref)}"
+
+
+def test_random_pyramids_close(FB):
+    """Random mid-size frames, pyramid scales and depths: every level is resized with different fractions."""
+    rng = np.random.default_rng(77)
+    for _ in range(14):
+        h, w = int(rng.integers(70, 420)), int(rng.integers(70, 520))
+        kw = dict(levels=int(rng.integers(1, 6)), pyr_scale=float(rng.choice([0.5, 0.6, 0.75, 0.8, 0.9])),
+                  winsize=int(rng.choice([7, 11, 15, 19])), iterations=int(rng.integers(1, 4)))
+        a, b = synth_pair(h, w, seed=h * 1000 + w, shift=(1.7, 0.9))
+        ref = O.calc(a, b, **kw)
+        fb = FB(w, h, **kw)
+        got = fb.calc(a, b)
+        fb.close()
+        err = np.abs(got - ref).max()
+        assert err <= flow_tol(ref), f"{h}x{w} {kw}: max|d|={err} tol={flow_tol(ref)}"
 
 
 @pytest.mark.parametrize("shape,kw", CASES)

@@ -1137,6 +1137,15 @@ k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
 // edge (1 beyond 5 px), as selects instead of a memory table: a table lookup is a global load,
 // and its wait would drain every prefetched gather
 __device__ __forceinline__ float border_weight(int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); }
+// The weight FarnebackUpdateMatrices applies: the product of the four edge weights, but only where its
+// own test fires -- (unsigned)(x - 5) >= (unsigned)(W - 10) || the same in y.  For W, H >= 10 that is
+// exactly where a weight differs from 1; below, W - 10 wraps and the test fires on fewer pixels than
+// lie within 5 of an edge (W = 9: column 4 alone), and the others stay unweighted.  Kept as it is.
+__device__ __forceinline__ float border_scale(int x, int y, int W, int H)
+{
+    const bool fires = (unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10);
+    return fires ? border_weight(x) * border_weight(W - x - 1) * border_weight(y) * border_weight(H - y - 1) : 1.f;
+}
 
 // ---------------------------------------------------------------------------------
 // A3: one pixel of FarnebackUpdateMatrices.  R0/R1 planar; out[5] = M.
@@ -1185,8 +1194,7 @@ __device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, c
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     {
-        // multiplying by 1.f away from the borders is exact, so no branch is needed
-        float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
+        float scale = border_scale(x, y, Wk, Hk);
         r2 *= scale;
         r3 *= scale;
         r4 *= scale;
@@ -1298,7 +1306,7 @@ __device__ __forceinline__ void gather_finish(const GatherRegs &g, int Wk, int H
         r2 += r4 * dy + r6 * dx;
         r3 += r6 * dy + r5 * dx;
         {
-            float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
+            float scale = border_scale(x, y, Wk, Hk);
             r2 *= scale;
             r3 *= scale;
             r4 *= scale;
@@ -2553,7 +2561,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
 static bool fb_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flow_in, float2 *flow_out, int k, int &rc,
                          const FlowInit *up = nullptr)
 {
-    if (w < 2 || h < 2)
+    if (w < 10 || h < 10) // border_scale: below 10 x 10 the two-kernel form carries OpenCV's edge test
         return false;
     switch (fb->prm.winsize / 2) { // odd half-widths: the pair-sum window
     case 3: rc = launch_flow_iter<3>(fb, w, h, n_pairs, flow_in, flow_out, k, up); return true;
@@ -2924,7 +2932,8 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         }
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         static const long fuse_min_px = getenv("TF_FB_FUSE_MIN_PX") ? atol(getenv("TF_FB_FUSE_MIN_PX")) : 4000000l; // two 1080p levels (4.15M) are in
-        const bool fused_here = fusable && L.W >= 2 && L.H >= 2 &&
+        // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
+        const bool fused_here = fusable && L.W >= 10 && L.H >= 10 &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;
@@ -2940,8 +2949,9 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             for (int i = 1; i <= I; i++) {
                 int rc = TF_OK;
                 // the first iteration below the coarsest scale upsamples the coarser level's flow itself
-                fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[buf_of(i)].as<float2>(), k, rc,
-                             (i == 1 && k < fb->K) ? &fi : nullptr);
+                if (!fb_flow_iter(fb, L.W, L.H, n_pairs, src, fb->lflow[buf_of(i)].as<float2>(), k, rc,
+                                  (i == 1 && k < fb->K) ? &fi : nullptr))
+                    return set_error(TF_ERR_STATE, "tf_fb_calc_slots: no one-kernel iteration for level %d", k);
                 TF_TRY(rc);
                 src = fb->lflow[buf_of(i)].as<float2>();
             }
