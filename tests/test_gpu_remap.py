@@ -78,6 +78,65 @@ def test_layer_sequences_golden(tf, path):
         np.testing.assert_array_equal(rgba, z[f"rgba_after_render_{t}"])
 
 
+def test_random_layer_configurations_vs_oracle(tf):
+    """Beyond the 18 captured cases: random moveref configurations -- every move flag, every reset mode,
+    masks present or not, 1-3 sources of 3 or 4 channels, shapes down to one pixel -- three frames each,
+    through the separate calls and (single-source cases) through the fused step; bit for bit."""
+    from transflow_amd.device import DevBuffer
+    _, remap = tf
+    rng = np.random.default_rng(4242)
+    for trial in range(40):
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        cfg = dict(transparent_pixels_can_move=bool(rng.integers(2)), pixels_can_move_to_empty_spot=bool(rng.integers(2)),
+                   pixels_can_move_to_filled_spot=bool(rng.integers(2)), moving_pixels_leave_empty_spot=bool(rng.integers(2)),
+                   reset_mode=str(rng.choice(["off", "random", "constant", "linear"])),
+                   reset_random_factor=float(rng.choice([0.0, 0.3, 1.0])), reset_constant_step=float(rng.choice([0.5, 1.0, 2.5])),
+                   reset_linear_factor=float(rng.choice([0.1, 0.5])), reset_source=bool(rng.integers(2)))
+        masks = {}
+        if rng.integers(2):
+            masks["mask_src"] = rng.random((h, w)) < 0.8
+        if rng.integers(2):
+            masks["mask_dst"] = rng.random((h, w)) < 0.8
+        if rng.integers(2):
+            masks["mask_alpha"] = rng.choice([0.0, 0.5, 1.0], (h, w)).astype(np.float32)
+        if rng.integers(2):
+            masks["reset_mask"] = rng.random((h, w)).astype(np.float32)
+        ns = int(rng.integers(1, 4))
+        intro = [rng.random((h, w)) < 0.5 for _ in range(ns)]
+        chans = [int(rng.choice([3, 4])) for _ in range(ns)]
+        bg = tuple(int(v) for v in rng.integers(0, 256, 3))
+        ora = R.MoveRefLayer(h, w, oracle_params(cfg), introduction_masks=intro, **masks)
+        layer = remap.RemapLayer(h, w, **cfg, **{k: (v.astype(np.uint8) if v.dtype == bool else v) for k, v in masks.items()})
+        layer.set_sources([m.astype(np.uint8) for m in intro])
+        fused = remap.RemapLayer(h, w, **cfg, **{k: (v.astype(np.uint8) if v.dtype == bool else v) for k, v in masks.items()})
+        fused.set_sources([m.astype(np.uint8) for m in intro])
+        comp, comp_f = remap.CompImage(h, w, bg), remap.CompImage(h, w, bg)
+        np.testing.assert_array_equal(layer.get_state()[0], ora.data, err_msg=f"trial {trial} init")
+        for t in range(3):
+            flow = R.post_process(rng.normal(0, 3, (h, w, 2)).astype(np.float32), R.BACKWARD)
+            u = rng.random((h, w))
+            pms = [rng.integers(0, 256, (h, w, c), dtype=np.uint8) for c in chans]
+            ora.update(flow, pms, u)
+            layer.update(flow, u)
+            for k, pm in enumerate(pms):
+                layer.gather(k, pm)
+            msg = f"trial {trial} ({h}x{w}, {cfg}, masks {sorted(masks)}, {ns} sources) frame {t}"
+            np.testing.assert_array_equal(layer.get_state()[0], ora.data, err_msg=msg)
+            np.testing.assert_array_equal(layer.get_state()[1], ora.rgba, err_msg=msg)
+            comp.begin()
+            layer.render(comp)
+            exp = R.composite(np.broadcast_to(np.uint8(bg), (h, w, 3)), [ora.render()])
+            np.testing.assert_array_equal(comp.download(), exp, err_msg=msg)
+            if ns == 1:
+                bufs = [DevBuffer.from_array(a) for a in (flow, pms[0], u)]
+                fused.step_dev(comp_f, bufs[0].ptr, bufs[1].ptr, chans[0], uniform_dev=bufs[2].ptr)
+                np.testing.assert_array_equal(fused.get_state()[0], ora.data, err_msg="fused " + msg)
+                np.testing.assert_array_equal(comp_f.download(), exp, err_msg="fused " + msg)
+                for b in bufs:
+                    b.close()
+        assert not layer.out_of_frame()
+
+
 def test_reference_known_answers(tf):
     """reference tests/test_compositor.py:20-54 through the C ABI."""
     _, remap = tf
