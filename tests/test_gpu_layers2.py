@@ -109,3 +109,75 @@ def test_layer2_argument_errors():
     mv = RemapLayer(4, 5)
     with pytest.raises((TfError, ValueError, RuntimeError)):
         mv.introduce(0, pm, 0)
+
+
+def test_random_introduction_and_sum_configurations_vs_oracle():
+    """Beyond the captured cases: random flag combinations of the introduction layer (move flags x
+    introduce_* flags, masks, 1-2 sources of 3 or 4 channels) and of the sum layer (every reset mode),
+    small odd shapes, four frames each, through HipCompositor; bit for bit against the oracle."""
+    from oracle import remap_ref as R
+    from tests.helpers import INTRO_KEYS, PRM_KEYS, capture_frame_numbers
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    rng = np.random.default_rng(999)
+    orig = np.random.random
+    for trial in range(30):
+        h, w = int(rng.integers(1, 30)), int(rng.integers(1, 45))
+        cls = "introduction" if trial % 3 else "sum"
+        cfg = dict(transparent_pixels_can_move=bool(rng.integers(2)), pixels_can_move_to_empty_spot=bool(rng.integers(2)),
+                   pixels_can_move_to_filled_spot=bool(rng.integers(2)), moving_pixels_leave_empty_spot=bool(rng.integers(2)))
+        if cls == "introduction":
+            cfg.update({k: bool(rng.integers(2)) for k in INTRO_KEYS})
+        else:
+            cfg.update(reset_mode=str(rng.choice(["off", "random", "constant", "linear"])),
+                       reset_random_factor=float(rng.choice([0.2, 1.0])), reset_source=bool(rng.integers(2)))
+        masks = dict(mask_alpha=rng.choice([0.0, 0.5, 1.0], (h, w)).astype(np.float32))
+        if cls == "introduction":
+            masks.update(mask_src=rng.random((h, w)) < 0.85, mask_dst=rng.random((h, w)) < 0.85)
+        else:
+            masks.update(reset_mask=rng.random((h, w)).astype(np.float32))
+        ns = int(rng.integers(1, 3))
+        intro = [rng.random((h, w)) < 0.6 for _ in range(ns)]
+        chans = [int(rng.choice([3, 4])) for _ in range(ns)]
+        nframes = 4
+        pixmaps = [[rng.integers(0, 256, (h, w, c), dtype=np.uint8) for _ in range(nframes)] for c in chans]
+        bg = tuple(int(v) for v in rng.integers(0, 256, 3))
+        comp = HipCompositor.from_args(h, w, [LayerConfig(0, classname=cls, **cfg)],
+                                       background_color="#%02x%02x%02x" % bg)
+        layer = comp.layers[0]
+        for key, val in masks.items():
+            setattr(layer, key, val)
+        comp.set_sources({0: [FakeSource(pixmaps[s], intro[s]) for s in range(ns)]})
+        if cls == "introduction":
+            prm = R.IntroParams(**{k: v for k, v in cfg.items() if k in PRM_KEYS + INTRO_KEYS})
+            ora = R.IntroductionLayer(h, w, prm, introduction_masks=intro, **masks)
+        else:
+            ora = R.SumLayer(h, w, R.LayerParams(**{k: v for k, v in cfg.items() if k in PRM_KEYS}),
+                             introduction_masks=intro, **masks)
+        for t in range(nframes):
+            flow = rng.normal(0, 2.5, (h, w, 2)).astype(np.float32)
+            if cls == "introduction":
+                flow = R.post_process(flow, R.BACKWARD)            # a moving layer needs in-frame targets
+            u = rng.random((h, w))
+            np.random.random = lambda size=None, _u=u: _u.copy()
+            try:
+                comp.update(flow)
+            finally:
+                np.random.random = orig
+            pms = [pixmaps[s][t % nframes] for s in range(ns)]
+            if cls == "introduction":
+                # a source is read only in frames in which the layer introduces (introduction.py:21-22)
+                once_done = prm.introduce_once and t > 0
+                if not once_done:
+                    ora.update(flow, [pixmaps[s][t] for s in range(ns)], frame_numbers=capture_frame_numbers(prm, t, ns))
+                else:
+                    ora.update(flow, pms, frame_numbers=capture_frame_numbers(prm, t, ns))
+            else:
+                ora.update(flow, pms, u=u)
+            msg = f"trial {trial} {cls} {h}x{w} {cfg} frame {t}"
+            np.testing.assert_array_equal(layer.data, ora.data, err_msg=msg)
+            frame = comp.render()
+            exp = R.composite(np.broadcast_to(np.uint8(bg), (h, w, 3)), [ora.render()])
+            np.testing.assert_array_equal(frame, exp, err_msg=msg)
+            np.testing.assert_array_equal(layer.data, ora.data, err_msg="after render " + msg)
+        comp.close()
