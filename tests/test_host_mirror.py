@@ -274,3 +274,111 @@ def test_flow_archive_format_is_the_references(tmp_path):
     src.archive.close()
     rb.archive.close()
     assert find_unique_path(ours) == str(tmp_path / "a.000.flow.zip")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/transflow"), reason="needs the reference tree (build container only)")
+def test_iteration_logic_matches_the_reference_class_on_random_schedules():
+    """Differential check of FlowSource.__next__ (locks, rewinds, lengths: source.py:286-332) against
+    the reference's own class driven by the same scripted next(): random frame ranges, lengths, STAY
+    schedules and SKIP predicates; same values, same input-frame bookkeeping, same exceptions."""
+    import sys
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from transflow.flow.sources.source import FlowSource as Ref
+
+    def scripted(base):
+        class S(base):
+            def __init__(self, *a, **k):
+                self.calls, self.rewinds = 0, 0
+                base.__init__(self, *a, **k)
+
+            def next(self):
+                self.calls += 1
+                return np.full((2, 3, 2), float(self.calls), np.float32)
+
+            def rewind(self):
+                self.rewinds += 1
+                base.rewind(self)
+
+            def post_process(self, raw):
+                return raw
+        return S
+
+    Mine, Theirs = scripted(FlowSource), scripted(Ref)
+    rng = np.random.default_rng(31337)
+    for trial in range(300):
+        fps = float(rng.choice([1.0, 10.0, 24.0, 29.97]))
+        start = int(rng.integers(0, 4))
+        end = start + int(rng.integers(1, 8))
+        ckpt = int(rng.integers(start, end + 1))
+        length = None if rng.random() < 0.2 else int(rng.integers(0, 25))
+        mode = int(rng.integers(3))
+        kw_m, kw_t = {}, {}
+        if mode == 1:
+            pairs, t0 = [], 0.0
+            for _ in range(int(rng.integers(1, 4))):
+                t0 += float(rng.uniform(0, 6 / fps))
+                d = float(rng.uniform(0, 5 / fps))
+                pairs.append((t0, d))
+                t0 += d
+            kw_m = dict(lock_mode=FlowSource.LockMode.STAY, lock_expr_stay=tuple(pairs))
+            kw_t = dict(lock_mode=Ref.LockMode.STAY, lock_expr_stay=tuple(pairs))
+        elif mode == 2:
+            a, b = sorted(float(v) for v in rng.uniform(0, 20 / fps, 2))
+            pred = (lambda t, a=a, b=b: a < t < b)
+            kw_m = dict(lock_mode=FlowSource.LockMode.SKIP, lock_expr_skip=pred)
+            kw_t = dict(lock_mode=Ref.LockMode.SKIP, lock_expr_skip=pred)
+        m = Mine(FlowSource.Direction.BACKWARD, 3, 2, fps, length, start, ckpt, end, **kw_m)
+        r = Theirs(Ref.Direction.BACKWARD, 3, 2, fps, length, start, ckpt, end, **kw_t)
+        for step in range(30):
+            out = []
+            for obj in (m, r):
+                try:
+                    out.append(("value", float(next(obj)[0, 0, 0])))
+                except (StopIteration, IndexError, RuntimeError) as e:
+                    out.append((type(e).__name__, None))
+            ctx = f"trial {trial} step {step}: fps={fps} range=({start},{ckpt},{end}) length={length} mode={mode}"
+            assert out[0] == out[1], ctx
+            assert (m.calls, m.rewinds, m.input_frame_index, m.output_frame_index) == \
+                   (r.calls, r.rewinds, r.input_frame_index, r.output_frame_index), ctx
+            if out[0][0] != "value":
+                break
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/transflow"), reason="needs the reference tree (build container only)")
+def test_builder_arithmetic_matches_the_reference_class_on_random_arguments():
+    """Differential check of FlowSource.Builder.build (source.py:125-197): random seek / duration /
+    repeat / checkpoint / lock arguments over random base lengths and frame rates, streams included."""
+    import sys
+    import warnings
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from transflow.flow.sources.source import FlowSource as Ref
+    rng = np.random.default_rng(8086)
+    fields = ("start_frame", "end_frame", "length", "ckpt_start_frame", "is_stream", "repeat", "seek_time",
+              "base_length", "lock_expr_stay")
+    for trial in range(400):
+        kw = dict(direction=str(rng.choice(["forward", "backward"])),
+                  seek_time=None if rng.random() < 0.4 else float(rng.choice([0.0, 0.25, 1.0, 2.5, 3.3333])),
+                  duration_time=None if rng.random() < 0.4 else float(rng.choice([0.1, 0.5, 1.0, 7.0])),
+                  repeat=int(rng.choice([0, 1, 1, 2, 5])),
+                  seek_ckpt=None if rng.random() < 0.6 else int(rng.integers(0, 200)))
+        r = rng.random()
+        if r < 0.3:
+            kw.update(lock_mode="stay", lock_expr=str(rng.choice(["0.5,0.2", "(0.2,0.4),(1,0.2)", "(0,1)"])))
+        elif r < 0.5:
+            kw.update(lock_mode="skip", lock_expr="t > 1")
+        base_length = int(rng.choice([-1, 0, 1, 7, 50, 300]))
+        fps = float(rng.choice([10.0, 25.0, 29.97, 60.0]))
+        out = []
+        for cls in (FlowSource, Ref):
+            b = cls.Builder(**kw)
+            b.width, b.height, b.framerate, b.base_length = 6, 4, fps, base_length
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    b.build()
+                out.append(tuple(getattr(b, f) for f in fields))
+            except Exception as e:                      # e.g. a stream with a duration-less range: both must agree
+                out.append(type(e).__name__)
+        assert out[0] == out[1], f"trial {trial}: {kw} base_length={base_length} fps={fps}: {out}"
