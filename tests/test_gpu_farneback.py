@@ -397,6 +397,28 @@ def test_full_calc_close_fused_on_every_level(FB, monkeypatch, shape, kw):
     fb.close()
 
 
+def test_fused_iteration_on_random_shapes_and_batches(FB, monkeypatch):
+    """The one-kernel iteration forced everywhere (TF_FB_FUSED=1) over random frame shapes, window widths
+    and batch sizes: strips narrower and wider than a workgroup, segments shorter than the window, the last
+    strip and the last segment ragged; every pair of the batch against the oracle."""
+    monkeypatch.setenv("TF_FB_FUSED", "1")
+    rng = np.random.default_rng(606)
+    for _ in range(16):
+        h, w = int(rng.integers(10, 260)), int(rng.integers(10, 420))
+        kw = dict(levels=int(rng.integers(0, 4)), winsize=int(rng.choice([7, 11, 15])), iterations=int(rng.integers(1, 4)))
+        n = int(rng.integers(1, 6))
+        frames = [synth_pair(h, w, seed=h * 1000 + w, shift=(0.7 * i, -0.4 * i))[1] for i in range(n + 1)]
+        fb = FB(w, h, max_pairs=n, frame_slots=n + 1, **kw)
+        for i, f in enumerate(frames):
+            fb.set_frame(i, f)
+        fb.calc_slots(list(range(1, n + 1)), list(range(n)))
+        for i in range(n):
+            ref = O.calc(frames[i + 1], frames[i], **kw)
+            err = np.abs(fb.get_flow(i) - ref).max()
+            assert err <= flow_tol(ref), f"{h}x{w} {kw} pair {i} of {n}: max|d|={err} tol={flow_tol(ref)}"
+        fb.close()
+
+
 def test_strided_input_and_errors(FB):
     h, w = 64, 96
     a, b = synth_pair(h, w + 8, seed=60)
