@@ -419,6 +419,42 @@ def test_fused_iteration_on_random_shapes_and_batches(FB, monkeypatch):
         fb.close()
 
 
+def test_unusual_parameter_values_close(FB):
+    """Values cv2 accepts but nobody picks: even window sizes (the window is 2*(winsize/2)+1 wide, the
+    scale 1/winsize^2: optflowgf.cpp as written), windows of 1-3 pixels, every polynomial radius from 1 to
+    9 (the generic expansion kernel below 5 and between), poly_sigma <= 0 (0.3*n instead), one scale
+    after the other of a 0.95 pyramid."""
+    h, w = 120, 164
+    a, b = synth_pair(h, w, seed=41, shift=(1.4, 0.8))
+    rng = np.random.default_rng(12)
+    cases = [dict(winsize=ws) for ws in (1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24)]
+    cases += [dict(poly_n=n, poly_sigma=float(s)) for n, s in ((1, 0.5), (2, 0.8), (3, 1.0), (4, 1.1), (6, 1.4), (8, 1.7), (9, 0.0))]
+    cases += [dict(levels=4, pyr_scale=0.95), dict(levels=30, pyr_scale=0.5), dict(iterations=7, winsize=9)]
+    cases += [dict(winsize=int(rng.integers(1, 30)), poly_n=int(rng.integers(1, 10)), poly_sigma=float(rng.uniform(0.4, 2)),
+                   iterations=int(rng.integers(1, 4)), levels=int(rng.integers(0, 3))) for _ in range(8)]
+    for kw in cases:
+        ref = O.calc(a, b, **kw)
+        fb = FB(w, h, **kw)
+        got = fb.calc(a, b)
+        fb.close()
+        d = np.abs(got - ref)
+        assert np.isfinite(got).all(), kw
+        if kw.get("winsize", 15) >= 4:
+            assert d.max() <= flow_tol(ref), f"{kw}: max|d|={d.max()} tol={flow_tol(ref)}"
+            continue
+        # Windows of 1-3 pixels: 1-9 samples per 2x2 system, so G is close to singular wherever the
+        # image is locally one-dimensional, and a last-bit difference in the window sums (OpenCV slides
+        # them with float differences, the kernels add the samples) is amplified through the iterations
+        # and scales.  One iteration at one scale must agree; the full run in all but a few pixels.
+        assert (d > flow_tol(ref)).mean() < 0.01, f"{kw}: {(d > flow_tol(ref)).mean():.4f} of the pixels beyond tolerance"
+        one = dict(kw, levels=0, iterations=1)
+        ref1 = O.calc(a, b, **one)
+        fb = FB(w, h, **one)
+        err1 = np.abs(fb.calc(a, b) - ref1).max()
+        fb.close()
+        assert err1 <= flow_tol(ref1), f"{one}: max|d|={err1} tol={flow_tol(ref1)}"
+
+
 def test_strided_input_and_errors(FB):
     h, w = 64, 96
     a, b = synth_pair(h, w + 8, seed=60)

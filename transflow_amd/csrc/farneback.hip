@@ -1453,6 +1453,28 @@ k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int W
     }
 }
 
+// winsize 1 (m = 0).  FarnebackUpdateFlow_Blur primes its running sums with (m + 2) copies of the first
+// row / column and takes one back when row m enters; with m = 0 the row that "enters" at y = 0 is row 0
+// itself, the extra copy is never taken back, and every sum is first + current instead of current:
+// G(y, x) = M(0,0) + M(y,0) + M(0,x) + M(y,x) (scale 1).  A setting nobody uses; kept as OpenCV computes it.
+__global__ void k_blur_solve_w1(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wk)
+        return;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *Mi = Min + (size_t)blockIdx.z * 5 * Nk;
+    double g[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float *P = Mi + c * Nk;
+        g[c] = ((double)P[0] + (double)P[(size_t)y * Wk]) + ((double)P[x] + (double)P[(size_t)y * Wk + x]);
+    }
+    const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+    flow_out[(size_t)blockIdx.z * Nk + (size_t)y * Wk + x] =
+        make_float2((float)((g[0] * g[4] - g[1] * g[3]) * idet), (float)((g[2] * g[3] - g[1] * g[4]) * idet));
+}
+
 // ---------------------------------------------------------------------------------
 // A4, fast path: one WAVE marches a strip of 128 columns (two per lane) down `seg`
 // rows; no block barrier, so waves run decoupled and hide each other's latency.
@@ -2500,6 +2522,9 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
     case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, flow_out, scale, k);
     default: break;
     }
+    if (m == 0)
+        return launch("fb_blur_solve_w1", k_blur_solve_w1, dim3(cdiv(w, 256), h, n_pairs), dim3(256), 0,
+                      (const float *)fb->M.as<float>(), flow_out, w, h);
     // any other window: the generic block-per-strip kernel
     const int out_cols = BS_THREADS - 2 * m;
     const unsigned strips = cdiv(w, out_cols);
