@@ -455,6 +455,41 @@ def test_unusual_parameter_values_close(FB):
         assert err1 <= flow_tol(ref1), f"{one}: max|d|={err1} tol={flow_tol(ref1)}"
 
 
+def test_frame_content_extremes_close(FB):
+    """Flat frames, saturated frames, white noise, a one-pixel checkerboard, a displacement larger than
+    the window (most gathers leave the frame at the fine scales), a pure ramp: one iteration at one scale
+    within tolerance everywhere; the default pyramid within tolerance on the smooth ones and in all but
+    a sliver of the pixels on the noise ones (no structure: nothing damps a last-bit difference)."""
+    h, w = 150, 200
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    tex, moved = synth_pair(h, w, seed=55, shift=(31.0, -17.0))
+    noise = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(2)]
+    check = ((yy + xx) & 1).astype(np.uint8) * 255
+    ramp = np.clip(xx * 255 // (w - 1), 0, 255).astype(np.uint8)
+    pairs = {
+        "zeros": (np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8), True),
+        "saturated": (np.full((h, w), 255, np.uint8), np.full((h, w), 255, np.uint8), True),
+        "flat vs texture": (np.full((h, w), 128, np.uint8), tex, True),
+        "large shift": (tex, moved, True),
+        "ramp shifted": (ramp, np.roll(ramp, 3, axis=1), True),
+        "noise": (noise[0], noise[1], False),
+        "checkerboard": (check, np.roll(check, 1, axis=1), False),
+    }
+    for name, (a, b, smooth) in pairs.items():
+        for kw in (dict(levels=0, iterations=1), dict()):
+            ref = O.calc(a, b, **kw)
+            fb = FB(w, h, **kw)
+            got = fb.calc(a, b)
+            fb.close()
+            d = np.abs(got - ref)
+            assert np.isfinite(got).all(), name
+            if smooth or kw:
+                assert d.max() <= flow_tol(ref), f"{name} {kw}: max|d|={d.max()} tol={flow_tol(ref)}"
+            else:
+                assert (d > flow_tol(ref)).mean() < 0.01, f"{name}: {(d > flow_tol(ref)).mean():.4f} beyond tolerance"
+
+
 def test_strided_input_and_errors(FB):
     h, w = 64, 96
     a, b = synth_pair(h, w + 8, seed=60)
