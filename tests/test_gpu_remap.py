@@ -319,15 +319,16 @@ def test_fused_step_clips_like_post_process(tf):
     assert layer.out_of_frame()
 
 
+@pytest.mark.parametrize("shape", [(203, 317), (1, 1), (1, 9), (7, 1), (2, 3), (33, 64)])
 @pytest.mark.parametrize("leave_empty", [False, True])     # one kernel / the separate kernels
-def test_fused_step_finishes_forward_post_process(tf, leave_empty):
+def test_fused_step_finishes_forward_post_process(tf, leave_empty, shape):
     """FORWARD post_process split in two -- tf_fb_post_process_scatter, then step_dev(clip_flow=2) forming
     the flow from the winner map in registers -- equals post_process then the step, and the oracle."""
     import ctypes as C
     from transflow_amd import _lib
     from transflow_amd.device import DevBuffer
     farneback, remap = tf
-    h, w = 203, 317
+    h, w = shape
     rng = np.random.default_rng(13)
     raw = rng.normal(0, 12, (h, w, 2)).astype(np.float32)      # collisions and out-of-frame targets
     raw[rng.random((h, w)) < 0.3] = 0
