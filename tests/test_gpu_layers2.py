@@ -181,3 +181,65 @@ def test_random_introduction_and_sum_configurations_vs_oracle():
             np.testing.assert_array_equal(frame, exp, err_msg=msg)
             np.testing.assert_array_equal(layer.data, ora.data, err_msg="after render " + msg)
         comp.close()
+
+
+def test_random_layer_stacks_vs_oracle():
+    """Two to four layers of random classes in one compositor (compositor.py:27-40: every layer updated with
+    the same flow, painted in order over the background), random flags each; three frames; bit for bit."""
+    from oracle import remap_ref as R
+    from tests.helpers import INTRO_KEYS, PRM_KEYS, capture_frame_numbers
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    rng = np.random.default_rng(1212)
+    orig = np.random.random
+    for trial in range(12):
+        h, w = int(rng.integers(2, 28)), int(rng.integers(2, 40))
+        classes = [str(rng.choice(["moveref", "introduction", "static", "sum"])) for _ in range(int(rng.integers(2, 5)))]
+        cfgs, oras, srcs = [], [], {}
+        nframes = 3
+        for li, cls in enumerate(classes):
+            cfg = dict(transparent_pixels_can_move=bool(rng.integers(2)), moving_pixels_leave_empty_spot=bool(rng.integers(2)))
+            if cls == "introduction":
+                cfg.update({k: bool(rng.integers(2)) for k in INTRO_KEYS})
+            elif cls in ("moveref", "sum"):
+                cfg.update(reset_mode=str(rng.choice(["off", "random", "linear"])), reset_random_factor=0.4)
+            intro = [rng.random((h, w)) < 0.6]
+            pms = [rng.integers(0, 256, (h, w, int(rng.choice([3, 4]))), dtype=np.uint8) for _ in range(nframes)]
+            alpha = rng.choice([0.0, 1.0, 1.0], (h, w)).astype(np.float32)
+            cfgs.append(LayerConfig(li, classname=cls, **cfg))
+            srcs[li] = (pms, intro, alpha)
+            if cls == "introduction":
+                prm = R.IntroParams(**{k: v for k, v in cfg.items() if k in PRM_KEYS + INTRO_KEYS})
+                oras.append(R.IntroductionLayer(h, w, prm, introduction_masks=intro, mask_alpha=alpha))
+            elif cls == "static":
+                oras.append(R.StaticLayer(h, w, mask_alpha=alpha, introduction_masks=intro))
+            else:
+                prm = R.LayerParams(**{k: v for k, v in cfg.items() if k in PRM_KEYS})
+                oras.append((R.SumLayer if cls == "sum" else R.MoveRefLayer)(h, w, prm, introduction_masks=intro,
+                                                                              mask_alpha=alpha))
+        bg = tuple(int(v) for v in rng.integers(0, 256, 3))
+        comp = HipCompositor.from_args(h, w, cfgs, background_color="#%02x%02x%02x" % bg)
+        for li, layer in enumerate(comp.layers):
+            layer.mask_alpha = srcs[li][2]
+        comp.set_sources({li: [FakeSource(srcs[li][0], srcs[li][1][0])] for li in range(len(classes))})
+        for t in range(nframes):
+            flow = R.post_process(rng.normal(0, 2.0, (h, w, 2)).astype(np.float32), R.BACKWARD)
+            u = rng.random((h, w))
+            np.random.random = lambda size=None, _u=u: _u.copy()
+            try:
+                comp.update(flow)
+            finally:
+                np.random.random = orig
+            imgs = []
+            for li, (cls, ora) in enumerate(zip(classes, oras)):
+                pm = [srcs[li][0][t]]
+                if cls == "introduction":
+                    ora.update(flow, pm, frame_numbers=capture_frame_numbers(ora.prm, t, 1))
+                else:
+                    ora.update(flow, pm, u=u)
+            frame = comp.render()
+            for ora in oras:
+                imgs.append(ora.render())
+            exp = R.composite(np.broadcast_to(np.uint8(bg), (h, w, 3)), imgs)
+            np.testing.assert_array_equal(frame, exp, err_msg=f"trial {trial} {classes} {h}x{w} frame {t}")
+        comp.close()
