@@ -416,6 +416,163 @@ k_remap_step(const float2 *__restrict__ flow, const S *__restrict__ old, S *__re
     }
 }
 
+// The same step with PX pixels per thread, written in phases (all loads addressed by the pixel, then all
+// loads addressed by its source, then the pixmap gathers) and without branches around loads.  The
+// one-pixel form above waits on counters 83 % of its wave cycles at full occupancy -- three dependent
+// loads per pixel: flow -> moved state -> pixmap -- so what helps is more of those chains in flight
+// per wave, not fewer bytes.  Same statements, same results.
+template <int C, typename S, int PX>
+__global__ void __launch_bounds__(BLOCK)
+k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *__restrict__ neu,
+                const uint8_t *__restrict__ msrc, const uint8_t *__restrict__ mdst, const double *__restrict__ u,
+                const float *__restrict__ reset_mask, const uint8_t *__restrict__ intro, uchar4 *__restrict__ rgba,
+                const uint8_t *__restrict__ pixmap, const float *__restrict__ mask_alpha, uint8_t *__restrict__ image,
+                int N, int H, int W, StepParams sp, int *err)
+{
+    __shared__ uint32_t s_rgb[PX * BLOCK * 3 / 4];
+    uint8_t *s8 = reinterpret_cast<uint8_t *>(s_rgb);
+    const int t0 = blockIdx.x * (PX * BLOCK) + threadIdx.x;
+    int t[PX], tc[PX];
+    bool live[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        t[p] = t0 + p * BLOCK;
+        live[p] = t[p] < N;
+        tc[p] = live[p] ? t[p] : N - 1; // a dead lane of the last block reads a valid pixel and stores nothing
+    }
+    // --- phase 1: what the pixel itself addresses
+    float2 f[PX];
+    int wv[PX];
+    int4 me[PX];
+    uint8_t mdv[PX];
+    float rm[PX], ma[PX];
+    double uv[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        if (sp.clip_flow == 2)
+            wv[p] = reinterpret_cast<const int *>(flow)[tc[p]];
+        else
+            f[p] = flow[tc[p]];
+        me[p] = state_load(old, (size_t)tc[p]);
+        mdv[p] = mdst ? mdst[tc[p]] : (uint8_t)1;
+        rm[p] = (sp.reset_random && reset_mask) ? reset_mask[tc[p]] : 1.f;
+        uv[p] = (sp.reset_random && u) ? u[tc[p]] : 0.0;
+        ma[p] = mask_alpha ? mask_alpha[tc[p]] : 0.f;
+    }
+    // --- phase 2: the source pixel of the move (movement.py:20-48)
+    int pi[PX], pj[PX], sidx[PX];
+    bool moved[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        const int i = (int)fast_div((uint32_t)tc[p], sp.div), j = tc[p] - i * W;
+        pi[p] = i;
+        pj[p] = j;
+        float2 g;
+        if (sp.clip_flow == 2) {
+            const int src = wv[p] >= 0 ? wv[p] : tc[p];
+            const int si = (int)fast_div((uint32_t)src, sp.div);
+            g = make_float2((float)(src - si * W - j), (float)(si - i)); // source.py:359-360
+        } else {
+            g = f[p];
+        }
+        if (sp.clip_flow) {
+            g.x = clip_nan(g.x, (float)(-j), (float)(W - 1 - j));
+            g.y = clip_nan(g.y, (float)(-i), (float)(H - 1 - i));
+        }
+        const long long off = flow_offset(g, W);
+        const long long s = tc[p] + off;
+        const bool inside = s >= 0 && s < N;
+        if (off != 0 && !inside && live[p])
+            atomicOr(err, 1);
+        moved[p] = off != 0 && inside;
+        sidx[p] = moved[p] ? (int)s : tc[p];
+    }
+    // --- phase 3: what the source addresses
+    int4 so[PX];
+    uint8_t msv[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        so[p] = state_load(old, (size_t)sidx[p]);
+        msv[p] = msrc ? msrc[sidx[p]] : (uint8_t)1;
+    }
+    // --- phase 4: the new state (move, then the random reset of reference.py:58-67), the gather address
+    int4 d[PX];
+    bool sel[PX];
+    size_t gidx[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        d[p] = me[p];
+        const bool src_filled = so[p].z != 0;
+        const bool ms = msv[p] != 0 && (sp.fl.transparent_can_move || src_filled);
+        const bool md = mdv[p] != 0 && (sp.fl.to_empty || me[p].z != 0) && (sp.fl.to_filled || me[p].z == 0);
+        if (moved[p] && ms && md) {
+            d[p] = so[p];
+            if (!sp.fl.transparent_can_move || src_filled)
+                d[p].z = 1;
+        }
+        if (sp.reset_random) {
+            const float thr = sp.factor * rm[p]; // factor * 1.f == factor where no mask is set
+            const double uu = u ? uv[p] : philox_uniform((uint32_t)tc[p], sp.frame, sp.seed);
+            if (uu < (double)thr) {
+                d[p].x = pi[p];
+                d[p].y = pj[p];
+                d[p].z = 1;
+                if (sp.reset_source)
+                    for (int q = 0; q < sp.n_sources; q++)
+                        if (intro[(size_t)q * N + tc[p]])
+                            d[p].w = q;
+            }
+        }
+        if (live[p])
+            state_store(neu, (size_t)t[p], d[p]);
+        sel[p] = d[p].w == 0 && d[p].z != 0;
+        const int gi = min(max(d[p].x, 0), H - 1), gj = min(max(d[p].y, 0), W - 1);
+        gidx[p] = sel[p] ? (size_t)gi * W + gj : 0;
+    }
+    // --- phase 5: gather of source 0 (reference.py:94-105); pixels not selected keep their previous colour
+    uchar4 px[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        if (C == 4) {
+            px[p] = reinterpret_cast<const uchar4 *>(pixmap)[gidx[p]];
+        } else {
+            const uint8_t *q = pixmap + gidx[p] * 3;
+            px[p] = make_uchar4(q[0], q[1], q[2], 1);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        if (!sel[p]) {
+            px[p] = rgba[tc[p]];
+            if (C == 3)
+                px[p].w = 0;
+        }
+        // --- Layer.render (layer.py:32-34)
+        if (mask_alpha)
+            px[p].w = (unsigned char)(int)(ma[p] * (float)px[p].w);
+        if (live[p])
+            rgba[t[p]] = px[p];
+        // --- Compositor.render over the background (compositor.py:35-39)
+        const uchar4 o = px[p].w != 0 ? px[p] : sp.bg;
+        const int k = (p * BLOCK + threadIdx.x) * 3;
+        s8[k + 0] = o.x;
+        s8[k + 1] = o.y;
+        s8[k + 2] = o.z;
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * (PX * BLOCK) * 3; // multiple of 4
+    const size_t total = (size_t)N * 3;
+    for (int idx = threadIdx.x; idx < PX * BLOCK * 3 / 4; idx += BLOCK) {
+        const size_t b = base + (size_t)idx * 4;
+        if (b + 4 <= total) {
+            *reinterpret_cast<uint32_t *>(image + b) = s_rgb[idx];
+        } else {
+            for (size_t q = b; q < total; q++)
+                image[q] = s8[q - base];
+        }
+    }
+}
+
 __global__ void k_remap_clip_flow(float2 *flow, int W, int H)
 {
     int t = blockIdx.x * BLOCK + threadIdx.x;
@@ -1121,22 +1278,25 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     sp.seed = seed;
     sp.frame = L->frame;
     sp.bg = comp->bg;
-    dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
+    static const int px_per_thread = getenv("TF_REMAP_PX") ? atoi(getenv("TF_REMAP_PX")) : 2;
+    dim3 block(BLOCK);
     auto run = [&](auto *old, auto *neu) {
         using S = typename std::remove_const<typename std::remove_pointer<decltype(old)>::type>::type;
-        if (channels == 4)
-            return launch("remap_step_rgba", k_remap_step<4, S>, grid, block, 0, (const float2 *)flow_dev, old, neu,
+        auto go = [&](auto kernel, const char *name, int px) {
+            return launch(name, kernel, dim3(cdiv((size_t)L->N, (size_t)px * BLOCK)), block, 0, (const float2 *)flow_dev, old, neu,
                           (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
                           (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
                           (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
                           (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
                           L->err.as<int>());
-        return launch("remap_step_rgb", k_remap_step<3, S>, grid, block, 0, (const float2 *)flow_dev, old, neu,
-                      (const uint8_t *)L->mask_src.as<uint8_t>(), (const uint8_t *)L->mask_dst.as<uint8_t>(),
-                      (const double *)uniform_dev, (const float *)L->reset_mask.as<float>(),
-                      (const uint8_t *)L->intro.as<uint8_t>(), L->rgba.as<uchar4>(), (const uint8_t *)pixmap_dev,
-                      (const float *)L->mask_alpha.as<float>(), comp->image.as<uint8_t>(), L->N, L->H, L->W, sp,
-                      L->err.as<int>());
+        };
+        if (px_per_thread >= 4)
+            return channels == 4 ? go(k_remap_step_px<4, S, 4>, "remap_step_rgba", 4)
+                                 : go(k_remap_step_px<3, S, 4>, "remap_step_rgb", 4);
+        if (px_per_thread >= 2)
+            return channels == 4 ? go(k_remap_step_px<4, S, 2>, "remap_step_rgba", 2)
+                                 : go(k_remap_step_px<3, S, 2>, "remap_step_rgb", 2);
+        return channels == 4 ? go(k_remap_step<4, S>, "remap_step_rgba", 1) : go(k_remap_step<3, S>, "remap_step_rgb", 1);
     };
     if (state_can_pack(L)) {
         TF_TRY(state_packed(L));
