@@ -172,3 +172,41 @@ def test_polyexp_is_the_weighted_least_squares_fit():
         coef = np.linalg.lstsq(basis * wgt[:, None], patch * wgt, rcond=None)[0]
         np.testing.assert_allclose(r[i, j], [coef[2], coef[1], coef[4], coef[3], coef[5]], rtol=0, atol=2e-4,
                                    err_msg=f"pixel ({i}, {j})")
+
+
+def test_one_iteration_is_farnebacks_least_squares_displacement():
+    """Farnebäck (2003), eq. 9-12, written down independently in float64: with the two expansions
+    f(x) ~ x'A x + b'x + c, A = (A0 + A1(x + d)) / 2, db = -(b1(x + d) - b0) / 2 + A d, the displacement
+    minimises sum_w |A d - db|^2 over the window: d = (sum A'A)^-1 sum A'db.  The oracle's
+    update_matrices + update_flow_blur against that, from a non-zero prior flow, away from the
+    borders (where OpenCV down-weights and treats R1 as absent).  The oracle adds 1e-3 to the
+    determinant (of sums scaled by 1/winsize^2); so does this."""
+    from scipy import ndimage
+    n, sigma, winsize = 5, 1.2, 15
+    a, b = _texture(120, 150), _texture(120, 150, 1.6, -0.9)
+    r0 = F.polyexp(a.astype(np.float32), n, sigma).astype(np.float64)
+    r1 = F.polyexp(b.astype(np.float32), n, sigma).astype(np.float64)
+    h, w = a.shape
+    rng = np.random.default_rng(2)
+    prior = np.stack([np.full((h, w), 1.3), np.full((h, w), -0.6)], axis=-1) + rng.normal(0, 0.2, (h, w, 2))
+    prior = ndimage.gaussian_filter(prior, (3, 3, 0)).astype(np.float32)      # smooth, non-integer
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    coords = [yy + prior[..., 1], xx + prior[..., 0]]                          # flow = (dx, dy)
+    r1w = np.stack([ndimage.map_coordinates(r1[..., c], coords, order=1, mode="nearest") for c in range(5)], axis=-1)
+    # channel order (by, bx, ayy, axx, axy): A = [[ayy, axy/2], [axy/2, axx]] in (y, x)
+    ayy, axx, axy = (r0[..., 2] + r1w[..., 2]) / 2, (r0[..., 3] + r1w[..., 3]) / 2, (r0[..., 4] + r1w[..., 4]) / 4
+    dby = (r0[..., 0] - r1w[..., 0]) / 2 + ayy * prior[..., 1] + axy * prior[..., 0]
+    dbx = (r0[..., 1] - r1w[..., 1]) / 2 + axy * prior[..., 1] + axx * prior[..., 0]
+    box = lambda v: ndimage.uniform_filter(v, winsize, mode="nearest")        # mean = sum / winsize^2
+    gyy, gyx, gxx = box(ayy * ayy + axy * axy), box((ayy + axx) * axy), box(axx * axx + axy * axy)
+    hy, hx = box(ayy * dby + axy * dbx), box(axy * dby + axx * dbx)
+    det = gyy * gxx - gyx * gyx + 1e-3
+    dx, dy = (gyy * hx - gyx * hy) / det, (gxx * hy - gyx * hx) / det
+    m = F.update_matrices(r0.astype(np.float32), r1.astype(np.float32), prior)
+    got, _ = F.update_flow_blur(r0.astype(np.float32), r1.astype(np.float32), prior, m, winsize, False)
+    pad = 5 + winsize // 2 + 3
+    inner = (slice(pad, -pad), slice(pad, -pad))
+    np.testing.assert_allclose(got[..., 0][inner], dx[inner], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got[..., 1][inner], dy[inner], rtol=0, atol=2e-4)
+    # and the step goes towards the true displacement
+    assert abs(np.median(got[..., 0][inner]) - 1.6) < 0.1 and abs(np.median(got[..., 1][inner]) + 0.9) < 0.1
