@@ -1719,7 +1719,7 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk,
 // ---------------------------------------------------------------------------------
 // A3+A4 fused, roles split inside the workgroup (the default on large levels).  Three waves march a strip
 // of 128 columns together: waves 0-1 are PRODUCERS (one column per lane: they compute row e of M
-// from R0, R1 and the flow -- gather1_issue / gather1_finish, two rows in flight --, keep the window's
+// from R0, R1 and the flow -- gather1_issue / gather1_finish, the next row's loads in flight --, keep the window's
 // 2M+1 rows of their column in an LDS ring, slide the vertical window sum over it in double and
 // publish that sum), wave 2 is the CONSUMER (two columns per lane: it adds the sums across columns
 // -- pair sums through LDS, as k_blur_solve_wave --, solves and writes the flow).  One workgroup
@@ -1737,7 +1737,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 {
     static_assert(M & 1, "the pair-sum window needs an odd half-width");
 #ifndef TF_PC_PF
-#define TF_PC_PF 2
+#define TF_PC_PF 1 // rows of loads in flight per producer: 1 measured best (2: +3 %, 3: +11 %, 4: +4 % time)
 #endif
     constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1, PF = TF_PC_PF;
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
