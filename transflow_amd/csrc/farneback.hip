@@ -1681,7 +1681,7 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk,
 {
     const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
     float r2, r3, r4, r5, r6;
-    if (g.inb) {
+    {
         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         r2 = a00 * g.t[0].x + a01 * g.t[0].y + a10 * g.b[0].x + a11 * g.b[0].y;
         r3 = a00 * g.t[1].x + a01 * g.t[1].y + a10 * g.b[1].x + a11 * g.b[1].y;
@@ -1691,11 +1691,12 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk,
         r4 = (g.r0[2] + r4) * 0.5f;
         r5 = (g.r0[3] + r5) * 0.5f;
         r6 = (g.r0[4] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = g.r0[2];
-        r5 = g.r0[3];
-        r6 = g.r0[4] * 0.5f;
+        const float o6 = g.r0[4] * 0.5f;
+        r2 = g.inb ? r2 : 0.f;
+        r3 = g.inb ? r3 : 0.f;
+        r4 = g.inb ? r4 : g.r0[2];
+        r5 = g.inb ? r5 : g.r0[3];
+        r6 = g.inb ? r6 : o6;
     }
     r2 = (g.r0[0] - r2) * 0.5f;
     r3 = (g.r0[1] - r3) * 0.5f;
