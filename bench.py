@@ -3,18 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload 4k|1080p|1080p-1level] [--batch B]
 
-A "step" is one pass of the hot path over one batch of B synthetic frame pairs
-per GPU: batched Farnebäck over the B pairs, then per pair, in stream order,
-post_process -> moveref update (+reset) -> pixmap gather -> render.  Frames,
-pixmap and masks are resident in HBM before the timed region; output frames
-stay in HBM (the PCIe-inclusive rate is noted in DESIGN.md, never reported as
-`value`).  For N > 1 the driver starts one rank per GPU with
-torch.distributed.run; every rank runs its own shard of frames (independent
-pairs, one remap stream per rank): weak scaling, no data-path
-collective; RCCL carries the rendezvous, the one-off broadcast of the shared
-pixmap/mask and the barrier + max-over-ranks timing.
+The workload is BASELINE.json configs[4] (and configs[3] at N = 1): ONE clip of T = 256 synthetic 4K
+frames, its 255 frame pairs sharded over the N ranks (`shard_range`, one-frame halo).  A "step" is
+one pass of the hot path over one batch of B consecutive pairs of the rank's shard: batched
+Farnebäck over the B pairs, then per pair, in stream order, post_process -> moveref update
+(+ random reset) -> pixmap gather -> render; consecutive steps walk down the shard and start over
+at its end.  The rank's frames, the pixmap and the masks are resident in HBM before the timed
+region; output frames stay in HBM (the PCIe-inclusive rate is noted in DESIGN.md, never `value`).
 
-Rank 0 prints ONE JSON line (see README/DESIGN for the fields).
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (fresh child
+processes, before this process makes any GPU call); under `python -m torch.distributed.run ...
+bench.py --gpus N` the ranks already exist and RANK / LOCAL_RANK / WORLD_SIZE come from the
+environment.  Either way no rank imports torch: the ranks meet through a rendezvous file + TCP star
+(transflow_amd.batch.HostGroup: barrier, max over ranks), the shared pixmap and reset mask come from
+rank 0 through RCCL (tf_batch_broadcast), and the gather of finished frames to rank 0
+(tf_batch_gather) is exercised and timed after the timed region -- results stay per rank in the
+timed region, the path has no data-path collective.  Weak scaling: every rank does
+one batch per step.
+
+Before anything is timed, rank 0 runs the parity gate: two pairs of the first batch through the
+very calls the timed loop makes, against the CPU oracle; no value is printed if it fails.
+
+Rank 0 prints ONE JSON line (README / DESIGN.md §5 describe the fields).
 """
 from __future__ import annotations
 
@@ -24,6 +34,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -39,77 +50,141 @@ WORKLOADS = {
     # configs[3]/[4]: 4K, 5-level pyramid, moveref with random reset through a float mask
     "4k": dict(w=3840, h=2160, levels=5, direction=1, reset=True),
 }
+SEED_U = 20251003          # seed of the on-GPU uniform field of the random reset
+TOL_REL = 1e-4             # north_star: float32 (u, v) within 1e-4 relative
 
 
-def synth_frames(h, w, count, seed):
-    """multi-scale sine texture + noise; frame t is the texture seen
-    through the smooth field t*(u,v)/count, with fresh noise per frame."""
-    rng = np.random.default_rng(seed)
-    a = rng.uniform(0.4, 1.0, 6).astype(np.float32)
-    fx = rng.uniform(0.004, 0.06, 6).astype(np.float32)
-    fy = rng.uniform(0.004, 0.06, 6).astype(np.float32)
-    ph = rng.uniform(0, 2 * np.pi, 6).astype(np.float32)
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    u = (3.0 * np.sin(2 * np.pi * yy / h * 2)).astype(np.float32)
-    v = (2.0 * np.cos(2 * np.pi * xx / w * 3)).astype(np.float32)
-    frames = []
-    for t in range(count):
-        s = np.float32(t / max(1, count - 1))
-        x, y = xx - s * u, yy - s * v
-        val = np.zeros((h, w), np.float32)
+class ClipSynth:
+    """frame t of a clip of `count` frames = a multi-scale sine texture seen through the
+    smooth field s*(u, v), s = t/(count-1), u = 3 sin(4 pi y/h), v = 2 cos(6 pi x/w), plus fresh noise.
+    u depends on y alone and v on x alone, so every sine's argument splits into A(x) + B(y) and the
+    texture is one [h, 12] x [12, w] product per frame.  Frame t depends on (seed, t, count) only:
+    every rank makes exactly the frames of its shard."""
+
+    def __init__(self, h, w, count, seed):
+        self.h, self.w, self.count, self.seed = h, w, count, seed
+        rng = np.random.default_rng(seed)
+        self.a = rng.uniform(0.4, 1.0, 6)
+        self.fx = rng.uniform(0.004, 0.06, 6)
+        self.fy = rng.uniform(0.004, 0.06, 6)
+        self.ph = rng.uniform(0, 2 * np.pi, 6)
+        self.x = np.arange(w, dtype=np.float64)
+        self.y = np.arange(h, dtype=np.float64)
+        self.u = 3.0 * np.sin(2 * np.pi * self.y / h * 2)     # x displacement, a function of y
+        self.v = 2.0 * np.cos(2 * np.pi * self.x / w * 3)     # y displacement, a function of x
+
+    def frame(self, t):
+        s = t / max(1, self.count - 1)
+        two_pi = 2 * np.pi
+        left = np.empty((self.h, 12), np.float32)
+        right = np.empty((12, self.w), np.float32)
         for m in range(6):
-            val += a[m] * np.sin(np.float32(2 * np.pi) * (fx[m] * x + fy[m] * y) + ph[m])
-        noise = np.random.default_rng(seed + 1 + t).standard_normal((h, w), dtype=np.float32) * 6
-        frames.append(np.clip(np.rint(128 + 20 * val + noise), 0, 255).astype(np.uint8))
-    return frames
+            # sin(2 pi (fx (x - s u(y)) + fy (y - s v(x))) + ph) = sin(A(x) + B(y)),  A carries the phase
+            A = two_pi * (self.fx[m] * self.x - self.fy[m] * s * self.v) + self.ph[m]
+            B = two_pi * (self.fy[m] * self.y - self.fx[m] * s * self.u)
+            left[:, 2 * m], left[:, 2 * m + 1] = self.a[m] * np.cos(B), self.a[m] * np.sin(B)
+            right[2 * m], right[2 * m + 1] = np.sin(A), np.cos(A)
+        val = left @ right
+        noise = np.random.default_rng(self.seed + 1 + t).standard_normal((self.h, self.w), dtype=np.float32)
+        val *= 20.0
+        val += 128.0
+        noise *= 6.0
+        val += noise
+        np.rint(val, out=val)
+        np.clip(val, 0, 255, out=val)
+        return val.astype(np.uint8)
+
+    def frames(self, lo, hi):
+        """Frames lo..hi-1, made on a few threads (numpy releases the GIL in the heavy parts)."""
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(8, (os.cpu_count() or 2) // 2, hi - lo))
+        with ThreadPoolExecutor(workers) as ex:
+            return list(ex.map(self.frame, range(lo, hi)))
+
+
+def make_plan(total_frames, batch, rank, world):
+    """Which pairs, frames and passes rank `rank` of `world` owns."""
+    from transflow_amd.batch import batch_starts, frames_needed, shard_range
+    pairs = shard_range(max(0, total_frames - 1), rank, world)
+    frames = frames_needed(pairs)
+    n = pairs[1] - pairs[0]
+    return {"rank": rank, "pairs": list(pairs), "frames": list(frames), "n_pairs": n,
+            "pairs_per_pass": min(batch, n), "pass_starts": batch_starts(n, batch)}
 
 
 class Job:
     """Everything one rank keeps resident for the timed loop."""
 
-    def __init__(self, wl, batch, seed, device, pixmap=None, reset_mask=None):
+    def __init__(self, wl, batch, plan, clip_frames, seed, device, pixmap=None, reset_mask=None, pixmap_dev=None):
         from transflow_amd import _lib
         from transflow_amd.farneback import Farneback
-        from transflow_amd.remap import CompImage, RemapLayer
+        from transflow_amd.remap import CompImage
         self.lib = _lib.load()
         self.check = _lib.check
-        self.wl, self.batch = wl, batch
+        self.wl, self.plan = wl, plan
         w, h = wl["w"], wl["h"]
-        self.fb = Farneback(w, h, levels=wl["levels"], frame_slots=batch + 1, max_pairs=batch, device=device)
-        for i, f in enumerate(synth_frames(h, w, batch + 1, seed)):
+        f0, f1 = plan["frames"]
+        self.batch = plan["pairs_per_pass"]
+        if self.batch < 1:
+            raise SystemExit(f"rank {plan['rank']}: the clip's {clip_frames - 1} pairs do not reach this rank")
+        self.fb = Farneback(w, h, levels=wl["levels"], frame_slots=f1 - f0, max_pairs=self.batch, device=device)
+        self.synth = ClipSynth(h, w, clip_frames, seed)
+        for i, f in enumerate(self.synth.frames(f0, f1)):
             self.fb.set_frame(i, f)
-        rng = np.random.default_rng(1237)
-        self.pixmap = rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if pixmap is None else pixmap
+        self.pixmap = np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8) if pixmap is None else pixmap
+        self.reset_mask = None
         if wl["reset"]:
-            rm = np.random.default_rng(1238).random((h, w), dtype=np.float32) if reset_mask is None else reset_mask
-            self.layer = RemapLayer(h, w, reset_mode="random", reset_random_factor=0.5, reset_mask=rm)
-        else:
-            self.layer = RemapLayer(h, w)
-        self.layer.set_sources([np.ones((h, w), np.uint8)])
-        self.comp = CompImage(h, w, (255, 255, 255))
-        p = C.c_void_p()
-        self.check(self.lib.tf_dev_alloc(C.byref(p), self.pixmap.nbytes))
-        self.pixmap_dev = p.value
-        self.check(self.lib.tf_dev_upload(C.c_void_p(self.pixmap_dev), C.c_void_p(self.pixmap.ctypes.data),
-                                          self.pixmap.nbytes))
-        lo, hi = list(range(batch)), list(range(1, batch + 1))
-        # FORWARD: (prev, next) = (previous, current); BACKWARD: (current, previous)  cv.py:467-472
-        self.prev, self.next = (lo, hi) if wl["direction"] == 0 else (hi, lo)
+            self.reset_mask = (np.random.default_rng(1238).random((h, w), dtype=np.float32)
+                               if reset_mask is None else reset_mask)
+        self.layer = self.make_layer()
+        # pair i of a pass paints its own image: the pass's frames stay in HBM until the next pass (what a
+        # gather to rank 0 would send)
+        self.comps = [CompImage(h, w, (255, 255, 255)) for _ in range(self.batch)]
+        if pixmap_dev is None:
+            p = C.c_void_p()
+            self.check(self.lib.tf_dev_alloc(C.byref(p), self.pixmap.nbytes))
+            pixmap_dev = p.value
+            self.check(self.lib.tf_dev_upload(C.c_void_p(pixmap_dev), C.c_void_p(self.pixmap.ctypes.data),
+                                              self.pixmap.nbytes))
+        self.pixmap_dev = pixmap_dev
+        # slot lists of every pass.  FORWARD: (prev, next) = (frame t, frame t+1); BACKWARD: swapped (cv.py:467-472)
+        self.passes = []
+        for s in plan["pass_starts"]:
+            lo, hi = list(range(s, s + self.batch)), list(range(s + 1, s + self.batch + 1))
+            self.passes.append((lo, hi) if wl["direction"] == 0 else (hi, lo))
+        self.n_steps = 0
         self.flow_ptrs = None
 
-    def step(self):
-        fb, layer, comp, d = self.fb, self.layer, self.comp, self.wl["direction"]
-        fb.calc_slots(self.prev, self.next)
-        base = fb.flow_ptr(0)                    # the result buffer alternates with the call's parity
+    def make_layer(self):
+        from transflow_amd.remap import RemapLayer
+        h, w = self.wl["h"], self.wl["w"]
+        if self.wl["reset"]:
+            layer = RemapLayer(h, w, reset_mode="random", reset_random_factor=0.5, reset_mask=self.reset_mask)
+        else:
+            layer = RemapLayer(h, w)
+        layer.set_sources([np.ones((h, w), np.uint8)])
+        return layer
+
+    def remap_pair(self, layer, comp, i):
+        if self.wl["direction"] == 0:
+            # FORWARD post_process: the scatter pass here, the rest (source.py:359-362) inside the remap kernel
+            layer.step_dev(comp, self.fb.post_process_scatter(i), self.pixmap_dev, 3, clip_flow=2, seed=SEED_U)
+        else:
+            # BACKWARD post_process is the clip alone: folded into the remap kernel
+            layer.step_dev(comp, self.flow_ptrs[i], self.pixmap_dev, 3, clip_flow=True, seed=SEED_U)
+
+    def calc_pass(self, which):
+        prev, nxt = self.passes[which % len(self.passes)]
+        self.fb.calc_slots(prev, nxt)
+        base = self.fb.flow_ptr(0)                    # the result buffer alternates with the call's parity
         if self.flow_ptrs is None or self.flow_ptrs[0] != base:
             self.flow_ptrs = [base + i * self.wl["w"] * self.wl["h"] * 8 for i in range(self.batch)]
+
+    def step(self):
+        self.calc_pass(self.n_steps)
+        self.n_steps += 1
         for i in range(self.batch):
-            if d == 0:
-                # FORWARD post_process: the scatter pass here, the rest (source.py:359-362) inside the remap kernel
-                layer.step_dev(comp, fb.post_process_scatter(i), self.pixmap_dev, 3, clip_flow=2, seed=20251003)
-            else:
-                # BACKWARD post_process is the clip alone: folded into the remap kernel
-                layer.step_dev(comp, self.flow_ptrs[i], self.pixmap_dev, 3, clip_flow=True, seed=20251003)
+            self.remap_pair(self.layer, self.comps[i], i)
 
     def sync(self):
         self.check(self.lib.tf_sync())
@@ -131,57 +206,128 @@ class Job:
         return out
 
 
-def kernel_alg_bytes(name, wl, batch, iterations=3):
-    """Algorithmic bytes one step moves through kernel `name` (all its launches)."""
-    from transflow_amd import roofline as rf
-    sizes = rf.level_sizes(wl["w"], wl["h"], 0.5, wl["levels"])
-    n = [a * b for a, b in sizes]
-    total = 0
-    for k in range(len(n)):
-        nc = n[k + 1] if k + 1 < len(n) else 0
-        mult = 1
-        if name in ("fb_level_rowpass", "fb_level_colpass") and k < 2:   # long blur kernels start at level 2 (pyr_scale 0.5)
-            continue
-        if name == "fb_flow_iter" and not rf.level_is_fused(n[k], batch):
-            continue
-        if name in ("fb_update_matrices", "fb_blur_solve") and rf.level_is_fused(n[k], batch):
-            continue
-        if name == "fb_blur_solve":
-            mult = iterations
-        elif name in ("fb_update_matrices", "fb_flow_iter"):
-            # first launch of a level carries S3 (flow init); the I-1 rebuilds are plain S4 (+S5 when fused)
-            total += (iterations - 1) * batch * (68 if name == "fb_update_matrices" else 96) * n[k]
-        total += mult * rf.kernel_bytes(name, n[0], n[k], nc, batch)
-    return total
+def parity_gate(job, n_check=2):
+    """The calls the timed loop makes (one batched Farnebäck pass over the first batch, shared expansions;
+    then the fused remap step per pair with the uniform drawn on the GPU) against the CPU oracle on the
+    first `n_check` pairs: flow within TOL_REL * max(1, max|ref|); layer state, rgba and frame bit-exact
+    for the GPU's own flow and the very uniform field the kernel drew (tf_remap_uniform_dev).  Returns
+    (report, oracle timings) -- the oracle work doubles as the one-thread CPU baseline sample."""
+    from oracle import farneback as OF
+    from oracle import remap_ref as OR
+    from transflow_amd.device import DevBuffer
+    from transflow_amd.remap import CompImage
+    wl = job.wl
+    w, h = wl["w"], wl["h"]
+    n_check = min(n_check, job.batch)
+    OF.lib()
+    job.calc_pass(0)
+    job.sync()
+    f0 = job.plan["frames"][0]
+    prev, nxt = job.passes[0]
+    layer = job.make_layer()
+    comp = CompImage(h, w, (255, 255, 255))
+    prm = OR.LayerParams(reset_mode="random", reset_random_factor=0.5) if wl["reset"] else OR.LayerParams()
+    ora = OR.MoveRefLayer(h, w, prm, reset_mask=job.reset_mask, introduction_masks=[np.ones((h, w), bool)])
+    white = np.full((h, w, 3), 255, np.uint8)
+    ubuf = DevBuffer(h * w * 8)
+    rep = {"pairs_checked": n_check, "flow_max_abs_err": 0.0, "flow_tol": 0.0, "flow_ok": True, "remap_bit_exact": True,
+           "what": "first pairs of the first batch through the timed loop's own calls vs the CPU oracle"}
+    t_fb = t_rm = 0.0
+    for i in range(n_check):
+        a, b = job.synth.frame(f0 + prev[i]), job.synth.frame(f0 + nxt[i])
+        t0 = time.perf_counter()
+        ref = OF.calc(a, b, levels=wl["levels"])
+        t_fb += time.perf_counter() - t0
+        got = job.fb.get_flow(i)
+        err = float(np.abs(got - ref).max())
+        tol = TOL_REL * max(1.0, float(np.abs(ref).max()))
+        rep["flow_max_abs_err"] = max(rep["flow_max_abs_err"], err)
+        rep["flow_tol"] = max(rep["flow_tol"], tol)
+        rep["flow_ok"] = rep["flow_ok"] and err <= tol
+        # remap: the oracle is fed the GPU's flow and the GPU's uniform field, so every integer must agree
+        layer.uniform_dev(SEED_U, ubuf.ptr)
+        u = ubuf.download((h, w), np.float64)
+        job.remap_pair(layer, comp, i)
+        data, rgba = layer.get_state()
+        frame = comp.download()
+        t0 = time.perf_counter()
+        flow = OR.post_process(got.copy(), wl["direction"])
+        ora.update(flow, [job.pixmap], u)
+        exp = OR.composite(white, [ora.render()])
+        t_rm += time.perf_counter() - t0
+        same = np.array_equal(data, ora.data) and np.array_equal(rgba, ora.rgba) and np.array_equal(frame, exp)
+        rep["remap_bit_exact"] = rep["remap_bit_exact"] and bool(same)
+    rep["out_of_frame"] = bool(layer.out_of_frame())
+    rep["ok"] = bool(rep["flow_ok"] and rep["remap_bit_exact"] and not rep["out_of_frame"])
+    ubuf.close()
+    layer.close()
+    comp.close()
+    return rep, {"pairs": n_check, "farneback_s": t_fb, "remap_s": t_rm}
 
 
-def measured_traffic(name, wl, batch, launches_per_step, iterations=3):
-    """HBM bytes per launch of kernel `name` from the PMC passes recorded in profiles/ (separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, 2*FETCH + WRITE after calibration on this library's
-    access widths -- profiles/README.md).  Bytes per level pixel measured at 4K level 0, scaled to the
-    pixels this workload's launches cover.  None when no measurement exists for the kernel."""
-    from transflow_amd import roofline as rf
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    if name not in table:
-        return None
-    n = [a * b for a, b in rf.level_sizes(wl["w"], wl["h"], 0.5, wl["levels"])]
-    per_level_launches = {"fb_update_matrices": iterations, "fb_blur_solve": iterations,
-                          "fb_flow_iter": iterations}.get(name, 1)
-    if name == "fb_flow_iter":          # runs on the levels of >= 4M pixels over the batch only
-        n = [v for v in n if rf.level_is_fused(v, batch)]
-    images = 2 if name in ("fb_polyexp", "fb_level_image") else 1
-    total = table[name]["bytes_per_px"] * sum(n) * batch * images * per_level_launches
-    return total / max(1.0, launches_per_step)
+def host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cores": usable}
+
+
+def cpu_baseline(job, gate_times):
+    """The CPU side of the same workload on this host: the oracle (scalar C port of OpenCV's CPU path +
+    the numpy remap) on one thread -- the sample is the parity gate's own oracle work -- and the C port on
+    all usable cores (one frame pair per thread: pairs are independent).  cv2 is timed too where it
+    exists.  Checker code, used here only as the reported baseline."""
+    from oracle import farneback as OF
+    wl = job.wl
+    host = host_description()
+    n1 = gate_times["pairs"]
+    one = n1 / (gate_times["farneback_s"] + gate_times["remap_s"])
+    cores = max(1, min(host["usable_cores"], 32))
+    f0 = job.plan["frames"][0]
+    prev, nxt = job.passes[0]
+    n = min(cores, job.batch)
+    fa = [job.synth.frame(f0 + prev[i]) for i in range(n)]
+    fb_ = [job.synth.frame(f0 + nxt[i]) for i in range(n)]
+    t0 = time.perf_counter()
+    OF.calc_batch(fa, fb_, cores, levels=wl["levels"])
+    t_all = time.perf_counter() - t0
+    remap_per_frame = gate_times["remap_s"] / n1
+    out = {"value": one, "unit": "frames/s", "cores": 1, "kind": "port", "host": host,
+           "sample": f"{n1} frame pair(s) of the same workload ({wl['w']}x{wl['h']}, levels={wl['levels']}): C port of "
+                     f"OpenCV Farneback {gate_times['farneback_s'] / n1:.2f} s/frame + numpy remap "
+                     f"{remap_per_frame:.2f} s/frame, one thread",
+           "all_cores": {"value": n / (t_all + n * remap_per_frame), "farneback_only_value": n / t_all, "unit": "frames/s",
+                         "cores": min(cores, n), "kind": "port",
+                         "sample": f"{n} frame pairs, one per OpenMP thread, {t_all:.2f} s for the C port of Farneback; "
+                                   f"the numpy remap ({remap_per_frame:.2f} s/frame, serial: it is a recurrence) added per frame"}}
+    try:
+        import cv2
+    except ImportError:
+        out["opencv"] = "cv2 is not installed on this host"
+    else:
+        res = {}
+        for threads in (1, 0):
+            cv2.setNumThreads(threads)
+            cv2.calcOpticalFlowFarneback(fa[0], fb_[0], None, 0.5, wl["levels"], 15, 3, 5, 1.2, 0)
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                cv2.calcOpticalFlowFarneback(fa[0], fb_[0], None, 0.5, wl["levels"], 15, 3, 5, 1.2, 0)
+            res[f"threads_{cv2.getNumThreads()}"] = reps / (time.perf_counter() - t0)
+        out["opencv"] = {"version": cv2.__version__, "farneback_frames_per_s": res}
+    return out
 
 
 def copy_ceiling(lib, check, nbytes=1 << 30, reps=8):
     """Measured rate (read + write bytes per second) of a 16-byte-per-lane copy kernel over 1 GiB, HIP
-    events on the library stream: the practical HBM ceiling the 8 TB/s spec figure is quoted next to
-    (SURVEY 8d)."""
+    events on the library stream: the practical HBM ceiling the 8 TB/s spec figure is quoted next to."""
     src, dst, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
     check(lib.tf_dev_alloc(C.byref(src), nbytes))
     check(lib.tf_dev_alloc(C.byref(dst), nbytes))
@@ -201,39 +347,53 @@ def copy_ceiling(lib, check, nbytes=1 << 30, reps=8):
     return 2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9
 
 
-def cpu_baseline(wl):
-    """The oracle (a scalar C port of OpenCV's CPU path + the numpy remap), timed on
-    this host on ONE frame pair of the same workload.  Checker code, used here only
-    as the reported CPU baseline."""
-    from oracle import farneback as OF
-    from oracle import remap_ref as OR
-    w, h = wl["w"], wl["h"]
-    f = synth_frames(h, w, 2, 777)
-    a, b = (f[0], f[1]) if wl["direction"] == 0 else (f[1], f[0])
-    OF.lib()
-    rng = np.random.default_rng(3)
-    pixmap = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
-    prm = OR.LayerParams(reset_mode="random", reset_random_factor=0.5) if wl["reset"] else OR.LayerParams()
-    layer = OR.MoveRefLayer(h, w, prm, reset_mask=rng.random((h, w), dtype=np.float32),
-                            introduction_masks=[np.ones((h, w), bool)])
-    white = np.full((h, w, 3), 255, np.uint8)
-    t_fb = t_rm = 0.0
-    n = 0
-    while t_fb + t_rm < 12.0 and n < 64:   # bounded sample: ~12 s of CPU work
-        t0 = time.perf_counter()
-        flow = OF.calc(a, b, levels=wl["levels"])
-        t1 = time.perf_counter()
-        flow = OR.post_process(flow, wl["direction"])
-        layer.update(flow, [pixmap], rng.random((h, w)))
-        OR.composite(white, [layer.render()])
-        t2 = time.perf_counter()
-        t_fb += t1 - t0
-        t_rm += t2 - t1
-        n += 1
-    return {"value": n / (t_fb + t_rm), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frame pair(s) of the same workload ({w}x{h}, levels={wl['levels']}): "
-                      f"C port of OpenCV Farneback {t_fb / n:.2f} s/frame + numpy remap {t_rm / n:.2f} s/frame, "
-                      "single thread; cv2 is not installed on this host"}
+def gather_leg(job, host, rccl, reps=3):
+    """The gather of BASELINE configs[4], outside the timed region: every rank's frames of its last pass
+    (one image per pair) go to rank 0 through tf_batch_gather.  Checked: rank 0 compares the CRC of what
+    arrived from each rank for pair 0 with the CRC that rank computed of its own frame."""
+    from transflow_amd.device import DevBuffer
+    w, h = job.wl["w"], job.wl["h"]
+    nbytes = h * w * 3
+    world, rank = host.world, host.rank
+    recv = DevBuffer(world * job.batch * nbytes) if rank == 0 else None
+    own = zlib.crc32(job.comps[0].download().tobytes())
+    crcs = host.gather(own)
+
+    def once():
+        for i, comp in enumerate(job.comps):
+            rccl.gather_dev(comp.image_ptr(), nbytes, None if recv is None else recv.ptr + i * world * nbytes)
+        job.sync()
+
+    once()
+    ok = None
+    if rank == 0:
+        got = recv.download((world, nbytes), np.uint8)
+        ok = all(zlib.crc32(got[r].tobytes()) == crcs[r] for r in range(world))
+    host.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    host.barrier()
+    dt = host.max_over_ranks(time.perf_counter() - t0) / reps
+    # the rate a step would have with the gather inside it
+    job.sync()
+    host.barrier()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        job.step()
+        for i, comp in enumerate(job.comps):
+            rccl.gather_dev(comp.image_ptr(), nbytes, None if recv is None else recv.ptr + i * world * nbytes)
+    job.sync()
+    host.barrier()
+    dt_in = host.max_over_ranks(time.perf_counter() - t0) / n
+    if recv is not None:
+        recv.close()
+    into_root = (world - 1) * job.batch * nbytes
+    return {"what": "untimed region: each rank's frames of one pass (uint8 RGB, one per pair) to rank 0, tf_batch_gather "
+                    "(RCCL send/recv into the root)", "frames_per_gather": world * job.batch, "bytes_into_root": into_root,
+            "ms": dt * 1e3, "GBs_into_root": into_root / dt / 1e9 if dt > 0 else None, "verified_crc": ok,
+            "frames_per_s_with_gather_every_step": world * job.batch / dt_in}
 
 
 def main():
@@ -242,35 +402,87 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=16, help="frame pairs per pass (per GPU)")
+    ap.add_argument("--clip-frames", type=int, default=256, help="T: frames of the clip that is sharded over the ranks")
     ap.add_argument("--size", default=None, help="WxH: run the chosen workload's configuration at another frame size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed 1080p side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed side measurements")
+    ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (the JSON line says so)")
+    ap.add_argument("--rccl", action="store_true", help="use the RCCL legs (broadcast, gather) even with one rank")
+    ap.add_argument("--dry-run", action="store_true", help="ranks meet, shard the clip and report the plan; no GPU call")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    group = None
-    if world > 1 or args.gpus > 1 or os.environ.get("TF_BENCH_FORCE_DIST"):  # the env var rehearses the RCCL path on 1 GPU
-        if world != args.gpus and not os.environ.get("TF_BENCH_FORCE_DIST"):
-            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run); WORLD_SIZE={world}")
-        from transflow_amd.batch import Group  # imports torch BEFORE libtfhip.so so one HIP runtime is shared
-        group = Group("nccl")
+    from transflow_amd import batch as B
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher above us: start the ranks ourselves, before this process touches the GPU
+        sys.exit(B.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    rank, local_rank, world = B.env_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    host = B.HostGroup(rank, world)
 
     wl = dict(WORKLOADS[args.workload])
     if args.size:
         wl["w"], wl["h"] = (int(v) for v in args.size.lower().split("x"))
-    pixmap = reset_mask = None
-    if group is not None:
+    w, h = wl["w"], wl["h"]
+    if args.clip_frames < 2:
+        raise SystemExit("--clip-frames must be at least 2")
+    plan = make_plan(args.clip_frames, args.batch, rank, world)
+    plans = host.allgather(plan)
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "clip_frames": args.clip_frames, "plans": plans}))
+        host.close()
+        return
+
+    from transflow_amd import _lib
+    lib, check = _lib.load(), _lib.check
+    check(lib.tf_init(local_rank))
+    rccl, rccl_error = None, None
+    pixmap = reset_mask = pixmap_dev = None
+    if world > 1 or args.rccl:
         # shared inputs come from rank 0 over RCCL (one-off broadcast, outside the timed region)
-        rng = np.random.default_rng(1237)
-        pixmap = group.broadcast_bytes(rng.integers(0, 256, (wl["h"], wl["w"], 3), dtype=np.uint8)
-                                       if rank == 0 else np.zeros((wl["h"], wl["w"], 3), np.uint8))
-        if wl["reset"]:
-            reset_mask = group.broadcast_bytes(np.random.default_rng(1238).random((wl["h"], wl["w"]), dtype=np.float32)
-                                               if rank == 0 else np.zeros((wl["h"], wl["w"]), np.float32))
-    job = Job(wl, args.batch, seed=2000 + 17 * rank, device=local_rank, pixmap=pixmap, reset_mask=reset_mask)
+        from transflow_amd.device import DevBuffer
+        try:
+            rccl = B.RcclGroup(host)
+            pix_buf = DevBuffer(h * w * 3)
+            if rank == 0:
+                pix_buf.upload(np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8))
+            rccl.broadcast_dev(pix_buf.ptr, h * w * 3)
+            check(lib.tf_sync())
+            pixmap, pixmap_dev = pix_buf.download((h, w, 3), np.uint8), pix_buf.ptr
+            if wl["reset"]:
+                m_buf = DevBuffer(h * w * 4)
+                if rank == 0:
+                    m_buf.upload(np.random.default_rng(1238).random((h, w), dtype=np.float32))
+                rccl.broadcast_dev(m_buf.ptr, h * w * 4)
+                check(lib.tf_sync())
+                reset_mask = m_buf.download((h, w), np.float32)
+                m_buf.close()
+        except Exception as err:    # the path itself needs no collective: say so loudly and carry on per rank
+            rccl_error = f"{type(err).__name__}: {err}"
+            print(f"[bench] rank {rank}: RCCL leg failed ({rccl_error}); shared inputs generated per rank instead",
+                  file=sys.stderr)
+            rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
+        errs = host.allgather(rccl_error)
+        if any(errs) and rccl is not None:       # all or nothing
+            rccl.close()
+            rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
+        rccl_error = next((e for e in errs if e), None)
+    job = Job(wl, args.batch, plan, args.clip_frames, seed=2000, device=local_rank, pixmap=pixmap, reset_mask=reset_mask,
+              pixmap_dev=pixmap_dev)
+    if pixmap_dev is not None:
+        job.pixmap_buffer = pix_buf     # the job gathers from this buffer: it lives as long as the job
+
+    gate, gate_times = None, None
+    if rank == 0 and not args.no_gate:
+        gate, gate_times = parity_gate(job)
+    gate = host.broadcast(gate)
+    if gate is not None and not gate["ok"]:
+        if rank == 0:
+            print(f"[bench] parity gate FAILED, nothing is reported: {json.dumps(gate)}", file=sys.stderr)
+        host.close()
+        sys.exit(3)
 
     # warmup; the last warmup step is profiled per kernel to find the dominant one (the first step of a
     # process pays one-off costs inside whichever kernel happens to run first)
@@ -289,99 +501,109 @@ def main():
     job.prof_reset()
     job.prof(True, dominant)  # only the dominant kernel is bracketed by events in the timed region
 
-    if group is not None:
-        group.barrier()
     job.sync()
+    host.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
     job.sync()
-    t_sync = time.perf_counter() - t0
-    if group is not None:
-        group.barrier()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("TF_BENCH_DEBUG"):
-        print(f"[bench] rank {rank}: steps done after {t_sync * 1e3:.2f} ms, closing barrier {(elapsed - t_sync) * 1e3:.2f} ms",
-              file=sys.stderr)
-    if group is not None:
-        elapsed = group.max_over_ranks(elapsed)
+    t_rank = time.perf_counter() - t0
+    host.barrier()
+    elapsed = host.max_over_ranks(time.perf_counter() - t0)
     job.prof(False)
     dom_cnt, dom_ms = job.prof_report()[dominant]
+    rank_fps = host.gather(args.steps * job.batch / t_rank)
+    oob = host.gather(bool(job.layer.out_of_frame()))
 
+    gather, rccl_version = None, None
+    if rccl is not None:
+        gather = gather_leg(job, host, rccl)
+        rccl_version = rccl.rccl_version
+        rccl.close()
     if rank != 0:
-        if group is not None:
-            group.close()
+        host.close()
         return
 
     from transflow_amd import roofline as rf
-    frames = args.steps * args.batch * max(1, world)
+    pairs_per_step = sum(p["pairs_per_pass"] for p in plans)
+    frames = args.steps * pairs_per_step
     fps = frames / elapsed
-    alg_dom = kernel_alg_bytes(dominant, wl, args.batch) * args.steps
-    achieved = alg_dom / (dom_ms * 1e-3) / 1e9
-    traffic = measured_traffic(dominant, wl, args.batch, dom_cnt / max(1, args.steps))
-    step_bytes = args.batch * (rf.farneback_bytes(wl["w"], wl["h"], 0.5, wl["levels"], 3)
-                               + rf.remap_bytes(wl["w"], wl["h"], reset_mask=wl["reset"], forward=wl["direction"] == 0))
+    P = job.batch
+    built = rf.built_kernel_bytes(dominant, wl["w"], wl["h"], wl["levels"], P) * args.steps
+    model = rf.model_kernel_bytes(dominant, wl["w"], wl["h"], wl["levels"], P) * args.steps
+    achieved = built / (dom_ms * 1e-3) / 1e9
+    launches_per_step = dom_cnt / max(1, args.steps)
+    traffic = rf.profile_traffic(dominant, wl["w"], wl["h"], wl["levels"], P, launches_per_step)
+    avg_ms = dom_ms / max(1, dom_cnt)
+    step_model = P * (rf.farneback_bytes(w, h, 0.5, wl["levels"], 3)
+                      + rf.remap_bytes(w, h, reset_mask=wl["reset"], forward=wl["direction"] == 0))
+    step_built = rf.built_step_bytes(w, h, wl["levels"], P, reset_mask=wl["reset"], forward=wl["direction"] == 0)
+    per_gpu_s = args.steps / elapsed
     out = {
-        "metric": "frames/sec (Farneback+remap)", "value": fps, "unit": "frames/s", "n_gpus": max(1, world),
+        "metric": "frames/sec (Farneback+remap)", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {wl['w']}x{wl['h']} uint8 frame pairs, Farneback pyr_scale=0.5 "
-                               f"levels={wl['levels']} winsize=15 iterations=3 poly_n=5 poly_sigma=1.2 flags=0, "
-                               f"{'FORWARD' if wl['direction'] == 0 else 'BACKWARD'} post_process, moveref layer "
+        "config": {"workload": f"{args.workload}: one clip of T={args.clip_frames} {w}x{h} uint8 frames sharded over the ranks "
+                               f"(rank r owns pairs shard_range({args.clip_frames - 1}, r, {world}) + a one-frame halo), "
+                               f"Farneback pyr_scale=0.5 levels={wl['levels']} winsize=15 iterations=3 poly_n=5 poly_sigma=1.2 "
+                               f"flags=0, {'FORWARD' if wl['direction'] == 0 else 'BACKWARD'} post_process, moveref layer "
                                f"(reset {'random p=0.5 through a float mask, u drawn on the GPU' if wl['reset'] else 'off'}), "
                                "1 RGB pixmap source, render",
-                   "frame_pairs_per_step_per_gpu": args.batch,
-                   "frames_per_step_per_gpu": args.batch + 1,
+                   "clip_frames": args.clip_frames,
+                   "frame_pairs_per_step_per_gpu": P,
+                   "frames_per_step_per_gpu": P + 1,
+                   "pairs_per_rank": [p["n_pairs"] for p in plans],
                    "frame_expansions": "pairs t and t+1 of a step share frame t+1: its pyramid levels and polynomial "
                                        "expansion (A1+A2, functions of the frame alone) are computed once per step and "
-                                       "read by both; nothing is kept between steps (TF_FB_NO_SHARE=1 expands per pair "
-                                       "and side: other_workloads_untimed_region.unshared_expansions)",
-                   "parallelism": f"frames sharded over {max(1, world)} GPU(s), one remap stream per GPU"},
+                                       "read by both; nothing is kept between steps",
+                   "parallelism": f"frame pairs of one clip sharded over {world} GPU(s), one remap stream per GPU, "
+                                  "no data-path collective"},
+        "rccl_ranks": world if rccl_version is not None else 0, "rccl_version": rccl_version,
+        "per_rank_frames_per_s": rank_fps,
+        "parity_gate": gate if gate is not None else "skipped (--no-gate)",
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / rf.HBM_PEAK_GBS, "traffic": traffic,
-                     "launches": dom_cnt, "avg_launch_ms": dom_ms / max(1, dom_cnt),
-                     "algorithmic_bytes_per_launch": alg_dom / max(1, dom_cnt),
-                     "whole_step": {"algorithmic_bytes": step_bytes,
-                                    "achieved": step_bytes * args.steps / elapsed / 1e9,
-                                    "frac": step_bytes * args.steps / elapsed / 1e9 / rf.HBM_PEAK_GBS}},
+                     "frac": achieved / rf.HBM_PEAK_GBS,
+                     "bytes_model": "bytes the kernel as built must move per launch (DESIGN.md §5): for the one-kernel "
+                                    "iteration R0 20 + R1 20 + flow in 8 + flow out 8 B/px (M never leaves the CU)",
+                     "traffic": traffic, "traffic_source": "profile constant: B/px from the rocprofv3 FETCH_SIZE/WRITE_SIZE "
+                                                           "passes under profiles/ scaled to this workload's launches, "
+                                                           "not a measurement of this run",
+                     "counter_GBs": traffic / (avg_ms * 1e-3) / 1e9 if traffic else None,
+                     "counter_frac": traffic / (avg_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if traffic else None,
+                     "launches": dom_cnt, "avg_launch_ms": avg_ms,
+                     "algorithmic_bytes_per_launch": built / max(1, dom_cnt),
+                     "model_work_rate": {"what": "SURVEY Appendix C stage-once bytes of the reference's stages (96 B/px per "
+                                                 "iteration, M stored and re-read) per second: the reference's work rate, "
+                                                 "not HBM utilisation",
+                                         "bytes_per_launch": model / max(1, dom_cnt),
+                                         "achieved": model / (dom_ms * 1e-3) / 1e9,
+                                         "frac": model / (dom_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS},
+                     "whole_step": {"built_bytes": step_built, "achieved": step_built * per_gpu_s / 1e9,
+                                    "frac": step_built * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS,
+                                    "model_bytes": step_model, "model_work_rate": step_model * per_gpu_s / 1e9,
+                                    "model_frac": step_model * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS}},
         "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
+        "remap_out_of_frame": any(oob),
     }
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl)
+    if rccl_error:
+        out["rccl_error"] = rccl_error
+    if gather is not None:
+        out["gather"] = gather
+    if world == 1 and not args.no_cpu_baseline and gate_times is not None:
+        out["cpu_baseline"] = cpu_baseline(job, gate_times)
     if world == 1 and not args.no_extra:
-        # the same kernel with nothing beside it: a second handle with everything on one stream (in the
-        # timed region above the caller's remap of one call may run beside the next call's kernels)
-        os.environ["TF_FB_NO_OVERLAP"] = "1"
-        try:
-            j = Job(wl, args.batch, seed=2000, device=local_rank)
-        finally:
-            del os.environ["TF_FB_NO_OVERLAP"]
-        for _ in range(2):
-            j.step()
-        j.sync()
-        j.prof_reset()
-        j.prof(True, dominant)
-        n = 5
-        for _ in range(n):
-            j.step()
-        j.sync()
-        j.prof(False)
-        cnt, ms = j.prof_report()[dominant]
-        ach = kernel_alg_bytes(dominant, wl, args.batch) * n / (ms * 1e-3) / 1e9
-        out["roofline"]["measured_copy_ceiling_GBs"] = copy_ceiling(job.lib, job.check)
-        out["roofline"]["exclusive"] = {"what": "same kernel, same workload, TF_FB_NO_OVERLAP=1 (one stream, nothing runs beside it); untimed region",
-                                        "launches": cnt, "avg_launch_ms": ms / max(1, cnt), "achieved": ach,
-                                        "frac": ach / rf.HBM_PEAK_GBS}
-        del j
+        ceiling = copy_ceiling(job.lib, job.check)
+        out["roofline"]["measured_copy_ceiling_GBs"] = ceiling
+        assert achieved <= ceiling * 1.02, f"roofline.achieved {achieved:.0f} GB/s exceeds the measured copy ceiling {ceiling:.0f}"
         extra = {}
         for name in ("1080p", "1080p-1level"):
             if name == args.workload:
                 continue
             w2 = WORKLOADS[name]
             # the same bytes per call as the main workload: more pairs of the smaller frames
-            b2 = max(1, min(64, args.batch * (wl["w"] * wl["h"]) // (w2["w"] * w2["h"])))
-            j = Job(w2, b2, seed=2000, device=local_rank)
+            b2 = max(1, min(64, args.batch * (w * h) // (w2["w"] * w2["h"])))
+            j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=local_rank)
             for _ in range(3):
                 j.step()
             j.sync()
@@ -391,30 +613,13 @@ def main():
                 j.step()
             j.sync()
             dt = time.perf_counter() - t0
-            sb = b2 * (rf.farneback_bytes(w2["w"], w2["h"], 0.5, w2["levels"], 3)
-                       + rf.remap_bytes(w2["w"], w2["h"], reset_mask=w2["reset"], forward=w2["direction"] == 0))
+            sb = rf.built_step_bytes(w2["w"], w2["h"], w2["levels"], b2, reset_mask=w2["reset"], forward=w2["direction"] == 0)
             extra[name] = {"frames_per_s": n * b2 / dt, "frame_pairs_per_step": b2,
-                           "whole_step_frac_of_8TBs": sb * n / dt / 1e9 / 8000.0}
+                           "whole_step_frac_of_8TBs": sb * n / dt / 1e9 / rf.HBM_PEAK_GBS}
             del j
-        # the main workload with one expansion per pair and side, as 16 separate calls would do them
-        os.environ["TF_FB_NO_SHARE"] = "1"
-        try:
-            for _ in range(2):
-                job.step()
-            job.sync()
-            t0 = time.perf_counter()
-            n = 10
-            for _ in range(n):
-                job.step()
-            job.sync()
-            extra["unshared_expansions"] = {"frames_per_s": n * args.batch / (time.perf_counter() - t0),
-                                            "what": f"{args.workload}, TF_FB_NO_SHARE=1"}
-        finally:
-            del os.environ["TF_FB_NO_SHARE"]
         out["other_workloads_untimed_region"] = extra
     print(json.dumps(out))
-    if group is not None:
-        group.close()
+    host.close()
 
 
 if __name__ == "__main__":

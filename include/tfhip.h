@@ -276,6 +276,11 @@ int tf_remap_set_sources(tf_remap *layer, int n_sources, const uint8_t *const *i
    rounded flow vector leaves the frame (state is then unchanged). */
 int tf_remap_update(tf_remap *layer, const float *flow, const double *uniform, uint64_t seed);
 int tf_remap_update_dev(tf_remap *layer, const void *flow_dev, const void *uniform_dev, uint64_t seed);
+/* The float64 [H][W] field the NEXT tf_remap_update(_dev) / tf_remap_step_dev call on this layer would
+   draw for uniform == NULL with this seed (it depends on the seed, the pixel and the layer's frame
+   counter): written to uniform_dev so that a checker can hand the very same field to a CPU statement
+   of reference.py:58-67 -- on-GPU draws are then comparable bit for bit. */
+int tf_remap_uniform_dev(tf_remap *layer, uint64_t seed, void *uniform_dev);
 /* Deferred form of the range check for the resident path: 1 if any update_dev since
    the last call saw an out-of-frame vector (those updates were skipped). */
 int tf_remap_check(tf_remap *layer, int *out_of_frame);
@@ -326,6 +331,32 @@ void tf_comp_destroy(tf_comp *comp);
 int tf_comp_begin(tf_comp *comp);                      /* image = background.copy() (:35) */
 int tf_comp_download(tf_comp *comp, uint8_t *rgb_out); /* uint8 [H][W][3] (:40) */
 int tf_comp_image_ptr(tf_comp *comp, void **dev);
+
+/* ---- batch-of-frames mode over the GPUs of one node ----------------------
+ * With flags == 0 every Farnebäck pair is independent (transflow/flow/sources/cv.py:478-490: the
+ * `flow=` argument is an output buffer only), so ranks take contiguous ranges of pairs and the path
+ * needs no data-path collective.  What is exchanged, through RCCL over xGMI on the library stream:
+ * the shared inputs once (broadcast: the pixmap every rank's compositor gathers from,
+ * compositor/layers/reference.py:93-105, and the reset mask, reference.py:44) and finished frames to
+ * one rank (gather: what Pipeline hands to its output, pipeline.py:518).  One process per GPU; the
+ * communicator binds to the device tf_init selected.  librccl is loaded on the first tf_batch_* call.
+ * The 128-byte id is made on rank 0 and carried to the other ranks by the host (file or socket). */
+#define TF_BATCH_ID_BYTES 128
+typedef struct tf_batch tf_batch;
+int tf_batch_unique_id(uint8_t *id /*[TF_BATCH_ID_BYTES]*/);
+int tf_batch_init(tf_batch **out, int rank, int world, const uint8_t *id);
+void tf_batch_destroy(tf_batch *batch);
+int tf_batch_info(tf_batch *batch, int *rank, int *world, int *rccl_version); /* any pointer may be NULL */
+/* In place: root's `bytes` at dev reach every rank's dev. */
+int tf_batch_broadcast(tf_batch *batch, void *dev, size_t bytes, int root);
+/* Rank r's send_bytes land on root at recv_dev + sum(recv_bytes[0..r)); recv_bytes NULL = every rank
+   sends send_bytes.  recv_dev / recv_bytes are read on root only.  Point-to-point sends into the root
+   (all its inbound links at once), not a ring. */
+int tf_batch_gather(tf_batch *batch, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                    int root);
+/* values[n] (host) := sum (op 0) or max (op 1) over ranks; n <= 63.  Waits for the library stream on
+   every rank: with n = 0 it is the barrier a timed region is bracketed with. */
+int tf_batch_reduce(tf_batch *batch, double *values, int n, int op);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,21 @@ def calc(prev, nxt, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5,
     if rc != 0:
         raise ValueError("fbref_calc: unsupported arguments")
     return flow
+
+
+def calc_batch(prevs, nexts, threads, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0):
+    """n independent pairs, one per OpenMP thread; each result is bit-identical to calc()'s."""
+    prevs = [np.ascontiguousarray(a, np.uint8) for a in prevs]
+    nexts = [np.ascontiguousarray(a, np.uint8) for a in nexts]
+    n = len(prevs)
+    assert n == len(nexts) and n > 0
+    h, w = prevs[0].shape
+    assert all(a.shape == (h, w) for a in prevs + nexts)
+    flows = [np.zeros((h, w, 2), np.float32) for _ in range(n)]
+    arr = lambda xs: (C.c_void_p * n)(*[x.ctypes.data for x in xs])
+    rc = lib().fbref_calc_batch(arr(prevs), arr(nexts), C.c_int(n), C.c_int(int(threads)), C.c_int(w), C.c_int(h),
+                                arr(flows), C.c_double(pyr_scale), C.c_int(levels), C.c_int(winsize), C.c_int(iterations),
+                                C.c_int(poly_n), C.c_double(poly_sigma), C.c_int(flags))
+    if rc != 0:
+        raise ValueError("fbref_calc_batch: unsupported arguments")
+    return flows

@@ -580,3 +580,21 @@ FB_EXPORT int fbref_calc(const uint8_t *prev, const uint8_t *next, int W, int H,
     /* prevFlow == flow0 here; not ours to free */
     return 0;
 }
+
+/*
+ * The same call over n independent frame pairs, one pair per thread (OpenMP): with flags == 0 nothing
+ * crosses pairs (cv.py:478-490), so every pair's result is bit-identical to fbref_calc's.  This is the
+ * "all cores" leg of bench.py's cpu_baseline -- a timing aid, not a second statement of the algorithm.
+ * Returns 0, or -1 if any pair's arguments were refused.
+ */
+FB_EXPORT int fbref_calc_batch(const uint8_t *const *prev, const uint8_t *const *next, int n, int threads, int W, int H,
+                               float *const *flow, double pyr_scale, int levels, int winsize, int iterations, int poly_n,
+                               double poly_sigma, int flags)
+{
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1) reduction(| : bad)
+    for (int i = 0; i < n; i++)
+        bad |= fbref_calc(prev[i], next[i], W, H, flow[i], pyr_scale, levels, winsize, iterations, poly_n, poly_sigma,
+                          flags) != 0;
+    return bad ? -1 : 0;
+}

@@ -471,3 +471,60 @@ def test_flow_presteps_device_path(tf):
     with pytest.raises(ValueError):
         fb.post_process_host_ex(raw.copy(), 0, [("scale", 1.0)] * 9)
     fb.close()
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (2160, 3840)])
+@pytest.mark.parametrize("direction", ["backward", "forward"])
+def test_timed_remap_kernel_at_full_size_with_its_own_uniform(tf, h, w, direction):
+    """What bench.py times for the remap, at the sizes it times it: the one-kernel step
+    (k_remap_step_px<3, int16 state, two pixels per thread>) with the uniform field drawn ON THE GPU
+    (Philox), random reset p = 0.5 through a float mask, three frames.  tf_remap_uniform_dev hands out
+    the very field the kernel is about to draw, so the numpy oracle (reference.py:58-67 with that u)
+    must agree bit for bit on data, rgba and the frame.  backward: raw flow, clip folded in
+    (clip_flow=1, source.py:361-362); forward: the winner map of tf_fb_post_process_scatter, the rest
+    of FORWARD post_process formed in registers (clip_flow=2, source.py:349-362)."""
+    from transflow_amd.device import DevBuffer
+    farneback, remap = tf
+    rng = np.random.default_rng(h + 3 * w + len(direction))
+    rmask = rng.random((h, w), dtype=np.float32)
+    ones = np.ones((h, w), bool)
+    prm = R.LayerParams(reset_mode="random", reset_random_factor=0.5)
+    ora = R.MoveRefLayer(h, w, prm, reset_mask=rmask, introduction_masks=[ones])
+    gpu = remap.RemapLayer(h, w, reset_mode="random", reset_random_factor=0.5, reset_mask=rmask)
+    gpu.set_sources([ones])
+    comp = remap.CompImage(h, w, (255, 255, 255))
+    white = np.full((h, w, 3), 255, np.uint8)
+    pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pm_dev = DevBuffer.from_array(pm)
+    ubuf = DevBuffer(h * w * 8)
+    seed = 20251003
+    fb = farneback.Farneback(w, h, levels=0, frame_slots=2, max_pairs=1) if direction == "forward" else None
+    seen = []
+    for t in range(3):
+        raw = rng.normal(0, 4, (h, w, 2)).astype(np.float32)
+        raw[:8, :8] = 1e4                                    # vectors far outside the frame: the clip must catch them
+        gpu.uniform_dev(seed, ubuf.ptr)
+        u = ubuf.download((h, w), np.float64)
+        assert 0.0 <= u.min() and u.max() < 1.0
+        seen.append(u[::97, ::89].copy())
+        if direction == "backward":
+            flow_dev = DevBuffer.from_array(raw)
+            gpu.step_dev(comp, flow_dev.ptr, pm_dev.ptr, 3, clip_flow=True, seed=seed)
+            flow = R.post_process(raw.copy(), R.BACKWARD)
+        else:
+            # the flow the handle holds for pair 0 is replaced by `raw`, then scattered
+            check_ptr = fb.flow_ptr(0)
+            import ctypes as C
+            from transflow_amd import _lib
+            _lib.check(_lib.load().tf_dev_upload(C.c_void_p(check_ptr), C.c_void_p(raw.ctypes.data), raw.nbytes))
+            gpu.step_dev(comp, fb.post_process_scatter(0), pm_dev.ptr, 3, clip_flow=2, seed=seed)
+            flow = R.post_process(raw.copy(), R.FORWARD)
+        ora.update(flow, [pm], u)
+        data, rgba = gpu.get_state()
+        np.testing.assert_array_equal(data, ora.data, err_msg=f"data t={t}")
+        np.testing.assert_array_equal(rgba, ora.rgba, err_msg=f"rgba t={t}")
+        np.testing.assert_array_equal(comp.download(), R.composite(white, [ora.render()]), err_msg=f"frame t={t}")
+    assert not gpu.out_of_frame()
+    assert not np.array_equal(seen[0], seen[1])              # a new field per frame
+    reset_fraction = float((u < 0.5 * rmask).mean())
+    assert abs(reset_fraction - 0.25) < 0.01

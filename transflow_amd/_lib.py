@@ -101,6 +101,7 @@ PROTOTYPES = {
     "tf_remap_set_sources": (_I, [_P, _I, C.POINTER(C.c_void_p)]),
     "tf_remap_update": (_I, [_P, _P, _P, C.c_uint64]),
     "tf_remap_update_dev": (_I, [_P, _P, _P, C.c_uint64]),
+    "tf_remap_uniform_dev": (_I, [_P, C.c_uint64, _P]),
     "tf_remap_check": (_I, [_P, _PI]),
     "tf_remap_gather": (_I, [_P, _I, _P, _I]),
     "tf_remap_gather_dev": (_I, [_P, _I, _P, _I]),
@@ -124,6 +125,13 @@ PROTOTYPES = {
     "tf_comp_begin": (_I, [_P]),
     "tf_comp_download": (_I, [_P, _P]),
     "tf_comp_image_ptr": (_I, [_P, _PP]),
+    "tf_batch_unique_id": (_I, [_P]),
+    "tf_batch_init": (_I, [_PP, _I, _I, _P]),
+    "tf_batch_destroy": (None, [_P]),
+    "tf_batch_info": (_I, [_P, _PI, _PI, _PI]),
+    "tf_batch_broadcast": (_I, [_P, _P, C.c_size_t, _I]),
+    "tf_batch_gather": (_I, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), _I]),
+    "tf_batch_reduce": (_I, [_P, C.POINTER(C.c_double), _I, _I]),
 }
 
 _lib = None

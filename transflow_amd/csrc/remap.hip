@@ -1110,6 +1110,21 @@ TF_API int tf_remap_check(tf_remap *L, int *out_of_frame)
     return TF_OK;
 }
 
+__global__ void k_remap_uniform(double *__restrict__ u, int N, uint64_t seed, uint64_t frame)
+{
+    int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < N)
+        u[t] = philox_uniform((uint32_t)t, frame, seed);
+}
+
+TF_API int tf_remap_uniform_dev(tf_remap *L, uint64_t seed, void *uniform_dev)
+{
+    TF_REQUIRE(L && (uniform_dev || L->N == 0), "tf_remap_uniform_dev: null pointer");
+    TF_TRY(ensure_init());
+    return launch("remap_uniform", k_remap_uniform, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0, (double *)uniform_dev,
+                  L->N, seed, L->frame);
+}
+
 TF_API int tf_remap_gather_dev(tf_remap *L, int source_index, const void *pixmap_dev, int channels)
 {
     TF_REQUIRE(L && (pixmap_dev || L->N == 0), "tf_remap_gather_dev: null pointer");
@@ -1247,6 +1262,9 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     TF_REQUIRE(L->H == comp->H && L->W == comp->W, "tf_remap_step_dev: layer is %dx%d, compositor %dx%d", L->W, L->H,
                comp->W, comp->H);
     TF_REQUIRE(L->cfg.layer_class == TF_LAYER_MOVEREF, "tf_remap_step_dev: moveref layers only");
+    // reference.py:94-105 loops over every source; this call gathers source 0 alone
+    TF_REQUIRE(L->n_sources == 1, "tf_remap_step_dev: the layer has %d sources; the one-call step serves exactly one "
+               "(use tf_remap_update_dev + tf_remap_gather_dev per source)", L->n_sources);
     TF_TRY(ensure_init());
     if (L->N == 0)
         return TF_OK;

@@ -119,6 +119,10 @@ class RemapLayer:
                                             C.c_void_p(uniform_dev) if uniform_dev else None,
                                             C.c_uint64(seed & (2**64 - 1))))
 
+    def uniform_dev(self, seed: int, out_dev: int) -> None:
+        """The float64 (H, W) field the next update / step_dev with no `uniform` and this seed will draw."""
+        check(self._lib.tf_remap_uniform_dev(self._h, C.c_uint64(seed & (2**64 - 1)), C.c_void_p(out_dev)))
+
     def out_of_frame(self) -> bool:
         v = C.c_int()
         check(self._lib.tf_remap_check(self._h, C.byref(v)))
