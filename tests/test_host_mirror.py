@@ -241,7 +241,8 @@ def test_flow_archive_format_is_the_references(tmp_path):
         sys.path.insert(0, "/root/reference")
     from transflow.flow.sources.archive import ArchiveFlowSource as RefArchive
     from transflow.output.numpy import NumpyOutput as RefNumpyOutput
-    from transflow_amd.archive import ArchiveFlowSource, NumpyOutput, find_unique_path, flow_export_meta
+    from transflow.utils import find_unique_path as ref_unique_path
+    from transflow_amd.archive import ArchiveFlowSource, NumpyOutput, flow_export_meta, unique_path
     rng = np.random.default_rng(3)
     flows = [rng.normal(0, 2, (6, 9, 2)).astype(np.float32) for _ in range(3)]
     ours, theirs = str(tmp_path / "a.flow.zip"), str(tmp_path / "b.flow.zip")
@@ -273,7 +274,16 @@ def test_flow_archive_format_is_the_references(tmp_path):
         src.next()                                   # how an archive ends in the reference
     src.archive.close()
     rb.archive.close()
-    assert find_unique_path(ours) == str(tmp_path / "a.000.flow.zip")
+    assert unique_path(ours) == str(tmp_path / "a.000.flow.zip")
+    # the naming of a taken path agrees with the reference's on every shape of name
+    for name in ("a.flow.zip", "clip.mp4", "x.000.flow.zip", "x.004.map.zip", "noext", "b.7.txt", "c.123", "d.tar.gz"):
+        (tmp_path / "names").mkdir(exist_ok=True)
+        target = tmp_path / "names" / name
+        assert unique_path(str(target)) == ref_unique_path(str(target)) == str(target)      # free: unchanged
+        target.write_bytes(b"")
+        assert unique_path(str(target)) == ref_unique_path(str(target)), name
+        (tmp_path / "names" / os.path.basename(unique_path(str(target)))).write_bytes(b"")
+        assert unique_path(str(target)) == ref_unique_path(str(target)), name
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/transflow"), reason="needs the reference tree (build container only)")

@@ -1,15 +1,17 @@
-"""The on-disk flow format either side of the path: `.flow.zip` archives.
+"""`.flow.zip` flow archives -- the on-disk flow format either side of the path.
 
-  ZipOutput / NumpyOutput   <- transflow/output/zip.py:6-28, transflow/output/numpy.py:6-14
-                               (what Pipeline._setup_flow_export / _update_flow write, pipeline.py:363-377, 505-506)
-  ArchiveFlowSource         <- transflow/flow/sources/archive.py:10-51
-
-An archive holds `meta.json` and one `%09d.npy` per frame; frames written by either implementation
-are read by the other (tests/test_host_mirror.py).  Host-side I/O only; what is read goes through
-FlowSource.post_process on the GPU like any other flow.
+The format, as the reference's files lay it out (written by transflow/output/zip.py:6-28 and
+output/numpy.py:6-14 from pipeline.py:363-377, 505-506; read by flow/sources/archive.py:10-51): a
+deflated zip with one member `meta.json` ({"path", "width", "height", "framerate", "direction",
+"seek_time"}) followed by one `.npy` member per frame named by its nine-digit index.  This module is
+an independent reader / writer of that layout: `FlowArchiveWriter`, `read_archive_meta`,
+`read_archive_frame`, and `ArchiveFlowSource`, whose frames go through FlowSource.post_process on the
+GPU like any other flow.  tests/test_host_mirror.py checks that archives written here are
+byte-identical to the reference's and that each implementation reads the other's.
 """
 from __future__ import annotations
 
+import io
 import json
 import os
 import re
@@ -19,105 +21,121 @@ import numpy as np
 
 from .flow import FlowSource
 
-
-def find_unique_path(path: str) -> str:
-    """utils.py:147-160: path, or path with a .NNN counter before the (.flow/.map) extension."""
-    root, ext = os.path.splitext(path)
-    if root.endswith(".flow") or root.endswith(".map"):
-        root, pre_ext = os.path.splitext(root)
-        ext = pre_ext + ext
-    i = 0
-    m = re.match(r".*\.(\d{3})$", root)
-    if m:
-        i = int(m.group(1)) + 1
-        root = root[:-4]
-    while os.path.isfile(path):
-        path = root + f".{i:03d}" + ext
-        i += 1
-    return path
+META_MEMBER = "meta.json"
 
 
-class ZipOutput:
-    def __init__(self, path: str, replace: bool = False):
-        self.path = path if replace else find_unique_path(path)
-        if os.path.isfile(self.path):
-            os.remove(self.path)
-        self.archive = zipfile.ZipFile(self.path, "w", compression=zipfile.ZIP_DEFLATED)
-
-    def write_meta(self, data: dict):
-        if not data:
-            return
-        with self.archive.open("meta.json", "w") as file:
-            file.write(json.dumps(data).encode())
-
-    def write_object(self, filename: str, obj: object):
-        import pickle
-        with self.archive.open(filename, "w") as file:
-            pickle.dump(obj, file)
-
-    def close(self):
-        self.archive.close()
+def frame_member(index: int) -> str:
+    return "%09d.npy" % index
 
 
-class NumpyOutput(ZipOutput):
-    def __init__(self, path: str, replace: bool = False):
-        ZipOutput.__init__(self, path, replace)
-        self.index = 0
-
-    def write_array(self, array: np.ndarray):
-        with self.archive.open(f"{self.index:09d}.npy", "w") as file:
-            np.save(file, array)
-        self.index += 1
+def unique_path(path: str) -> str:
+    """`path` if nothing is there yet, otherwise the first free `<stem>.NNN<ext>`; a `.flow` / `.map`
+    before the extension belongs to the extension (`a.flow.zip` -> `a.000.flow.zip`), and a stem that
+    already ends in a counter continues from it (utils.find_unique_path's naming, utils.py:147-160)."""
+    if not os.path.isfile(path):
+        return path
+    stem, ext = os.path.splitext(path)
+    for tag in (".flow", ".map"):
+        if stem.endswith(tag):
+            stem, ext = stem[:-len(tag)], tag + ext
+            break
+    counter = re.search(r"\.(\d{3})$", stem)
+    n = 0
+    if counter:
+        stem, n = stem[:counter.start()], int(counter.group(1)) + 1
+    while True:
+        candidate = f"{stem}.{n:03d}{ext}"
+        if not os.path.isfile(candidate):
+            return candidate
+        n += 1
 
 
 def flow_export_meta(flow_path, width: int, height: int, framerate, direction, seek_time=None) -> dict:
-    """The meta.json of pipeline.py:370-377."""
-    return {"path": flow_path, "width": width, "height": height, "framerate": framerate,
-            "direction": FlowSource.Direction.from_arg(direction).value, "seek_time": seek_time}
+    """The six fields pipeline.py:370-377 stores with an exported flow."""
+    return dict(path=flow_path, width=width, height=height, framerate=framerate,
+                direction=FlowSource.Direction.from_arg(direction).value, seek_time=seek_time)
+
+
+class FlowArchiveWriter:
+    """Appends frames to a new archive.  `replace=False` never overwrites: it picks `unique_path(path)`."""
+
+    def __init__(self, path: str, replace: bool = False):
+        self.path = path if replace else unique_path(path)
+        self._zip = zipfile.ZipFile(self.path, mode="w", compression=zipfile.ZIP_DEFLATED)
+        self.index = 0
+
+    def _put(self, member: str, payload: bytes) -> None:
+        with self._zip.open(member, mode="w") as f:
+            f.write(payload)
+
+    def write_meta(self, meta: dict) -> None:
+        if meta:
+            self._put(META_MEMBER, json.dumps(meta).encode())
+
+    def write_array(self, array: np.ndarray) -> None:
+        buf = io.BytesIO()
+        np.save(buf, array)
+        self._put(frame_member(self.index), buf.getvalue())
+        self.index += 1
+
+    def close(self) -> None:
+        self._zip.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+NumpyOutput = FlowArchiveWriter      # the name the reference's pipeline uses for this role (output/numpy.py)
+
+
+def read_archive_meta(zf: zipfile.ZipFile) -> dict:
+    return json.loads(zf.read(META_MEMBER).decode())
+
+
+def read_archive_frame(zf: zipfile.ZipFile, index: int) -> np.ndarray:
+    """Frame `index`; a missing member is zipfile's KeyError -- that is how an archive ends."""
+    return np.load(io.BytesIO(zf.read(frame_member(index))))
 
 
 class ArchiveFlowSource(FlowSource):
+    """Flows replayed from an archive.  Like the reference's (archive.py:22-31) its builder takes
+    geometry, frame rate and direction from meta.json and does no timing arithmetic at all: no seek,
+    duration or repeat for archives, `length` stays None, and iteration ends with the KeyError of the
+    first missing frame (which the pipeline's source process logs and stops on, pipeline.py:90-97)."""
+
     class Builder(FlowSource.Builder):
         def __init__(self, path: str, **kwargs):
-            super().__init__(**kwargs)
-            self.path = path
-            self.archive = None
+            FlowSource.Builder.__init__(self, **kwargs)
+            self.path, self.archive = path, None
 
-        @property
-        def cls(self):
-            return ArchiveFlowSource
+        cls = property(lambda self: ArchiveFlowSource)
 
         def build(self):
             self.archive = zipfile.ZipFile(self.path)
-            with self.archive.open("meta.json") as file:
-                data = json.loads(file.read().decode())
-            # archives without a direction hold forward flows (archive.py:26-27)
-            self.direction = FlowSource.Direction(data.get("direction", FlowSource.Direction.FORWARD.value))
-            self.width = data["width"]
-            self.height = data["height"]
-            self.framerate = data["framerate"]
-            self.base_length = len(self.archive.infolist()) - 1
-            # as in the reference (archive.py:22-31) the base build() is NOT called: no mask / kernel /
-            # filters / seek / duration / repeat for archives, `length` stays None, and the source
-            # ends with the KeyError of the first missing frame (which the pipeline's source process
-            # logs and stops on, pipeline.py:90-97)
+            meta = read_archive_meta(self.archive)
+            self.width, self.height, self.framerate = meta["width"], meta["height"], meta["framerate"]
+            # archives from before the field existed hold forward flows (archive.py:26-27)
+            self.direction = FlowSource.Direction(meta.get("direction", FlowSource.Direction.FORWARD.value))
+            self.base_length = len(self.archive.namelist()) - 1
 
         def args(self):
-            return [self.archive, *FlowSource.Builder.args(self)]
+            return [self.archive] + FlowSource.Builder.args(self)
 
     def __init__(self, archive: zipfile.ZipFile, *args, **kwargs):
         self.archive = archive
         FlowSource.__init__(self, *args, **kwargs)
 
     def validate(self):
-        super().validate()
+        FlowSource.validate(self)
         if not isinstance(self.archive, zipfile.ZipFile):
             raise ValueError(f"Attribute archive has incorrect type {type(self.archive)}")
 
     def next(self):
-        with self.archive.open(f"{self.input_frame_index:09d}.npy") as file:
-            return np.load(file)
+        return read_archive_frame(self.archive, self.input_frame_index)
 
     def close(self):
         self.archive.close()
-        super().close()
+        FlowSource.close(self)

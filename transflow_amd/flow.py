@@ -12,12 +12,11 @@ flow source into a child process (pipeline.py:56-64).
 """
 from __future__ import annotations
 
+import dataclasses
 import enum
 import logging
 import os
 import warnings
-from typing import Callable
-
 import numpy as np
 
 from .config import FlowConfig
@@ -65,8 +64,100 @@ class FlowFilter:
         return cls(text[:i].strip(), args[0] if len(args) == 1 else ":".join(args))
 
 
+def _enum_from_arg(enum_cls, arg, default, what):
+    """The argument forms the reference accepts for its two enums (source.py:24-56): None, a member
+    (ours or the reference's own, matched by name), the integer value, or the lower-case name."""
+    if arg is None:
+        return default
+    if isinstance(arg, enum.Enum):
+        if arg.name in enum_cls.__members__:
+            return enum_cls[arg.name]
+    elif isinstance(arg, int):
+        return enum_cls(arg)
+    elif isinstance(arg, str) and arg.upper() in enum_cls.__members__ and arg == arg.lower():
+        return enum_cls[arg.upper()]
+    raise ValueError(f"Invalid {what}: {arg}")
+
+
+@dataclasses.dataclass
+class Timeline:
+    """What a source's frame range and output length come to (source.py:151-197), as one value."""
+    base_length: int | None     # frames the input holds; None = a stream
+    repeat: int
+    seek_time: float | None
+    start_frame: int
+    end_frame: int
+    length: int | None          # flows the source will yield; None = endless
+    ckpt_start_frame: int       # where the FIRST pass starts when resuming from a checkpoint
+
+    @property
+    def is_stream(self) -> bool:
+        return self.base_length is None
+
+
+def plan_timeline(base_length, framerate, seek_time, duration_time, repeat, seek_ckpt, stay_pairs) -> Timeline:
+    """The seek / duration / repeat / checkpoint arithmetic of FlowSource.Builder.build
+    (source.py:151-197).  A non-positive base length means a stream: it cannot repeat or seek (both
+    are dropped with the reference's warnings).  Every STAY lock adds its duration to the length."""
+    frames = base_length if (base_length is not None and base_length > 0) else None
+    if frames is None:
+        if repeat > 1:
+            warnings.warn("Flow source is a stream, cannot repeat it!")
+            repeat = 1
+        if seek_time is not None and seek_time > 0:
+            warnings.warn("Flow source is a stream, seek time is ignored!")
+            seek_time = None
+    first = 0
+    if frames is not None and seek_time is not None:
+        first = int(seek_time * framerate)
+    last = 0 if frames is None else frames
+    if duration_time is not None:
+        # three decimals before truncating: 0.1 s at 29.97 fps must not lose a frame to 2.9969999
+        last = first + int(round(duration_time * framerate, 3))
+        if frames is not None and last > frames:
+            last = frames
+    if repeat == 0:
+        total = None
+    else:
+        total = last if frames is None else repeat * (last - first)
+        for _, held in (stay_pairs or ()):
+            total += int(held * framerate)
+    resume = first
+    if seek_ckpt is not None:
+        resume = first + seek_ckpt % (last - first)
+    return Timeline(frames, repeat, seek_time, first, last, total, resume)
+
+
+class LockSchedule:
+    """When the source repeats its previous flow instead of reading a new one (source.py:296-311).
+    STAY: (start, duration) pairs in output time; SKIP: a predicate of t (and the input advances)."""
+
+    def __init__(self, mode, stay_pairs, skip_predicate):
+        self.mode, self.pairs, self.predicate = mode, stay_pairs, skip_predicate
+        self.which = 0              # the STAY pair in force or awaited
+        self.since = None           # output time at which the current STAY lock began
+
+    def locked(self, t: float) -> bool:
+        if self.mode == FlowSource.LockMode.SKIP:
+            return bool(self.predicate(t)) if self.predicate is not None else False
+        if self.pairs is None:
+            return False
+        if self.since is not None:
+            if t - self.since < self.pairs[self.which][1]:
+                return True
+            self.since = None
+            self.which += 1
+        # past the last pair this indexes out of range: the reference raises the same IndexError
+        # (source.py:304-307), and the pipeline's source process stops on it (pipeline.py:90-97)
+        if t >= self.pairs[self.which][0]:
+            self.since = t
+            return True
+        return False
+
+
 class FlowSource:
-    """Base class; same constructor, attributes and iteration protocol as the reference's."""
+    """Base class with the reference's constructor, attributes and iteration protocol
+    (transflow/flow/sources/source.py:17-415); the bodies are this package's own."""
 
     @enum.unique
     class Direction(enum.Enum):
@@ -75,17 +166,7 @@ class FlowSource:
 
         @classmethod
         def from_arg(cls, arg):
-            if arg is None:
-                return FlowSource.Direction.FORWARD          # source.py:26-28
-            if isinstance(arg, FlowSource.Direction):
-                return arg
-            if isinstance(arg, enum.Enum) and arg.name in ("FORWARD", "BACKWARD"):
-                return FlowSource.Direction[arg.name]        # the reference's own enum
-            if isinstance(arg, int):
-                return FlowSource.Direction(arg)
-            if arg in ("forward", "backward"):
-                return FlowSource.Direction[arg.upper()]
-            raise ValueError(f"Invalid Flow Direction: {arg}")
+            return _enum_from_arg(cls, arg, cls.FORWARD, "Flow Direction")     # None -> FORWARD, source.py:26-28
 
     @enum.unique
     class LockMode(enum.Enum):
@@ -94,43 +175,29 @@ class FlowSource:
 
         @classmethod
         def from_arg(cls, arg):
-            if arg is None:
-                return FlowSource.LockMode.STAY
-            if isinstance(arg, FlowSource.LockMode):
-                return arg
-            if isinstance(arg, enum.Enum) and arg.name in ("STAY", "SKIP"):
-                return FlowSource.LockMode[arg.name]
-            if isinstance(arg, int):
-                return FlowSource.LockMode(arg)
-            if arg in ("stay", "skip"):
-                return FlowSource.LockMode[arg.upper()]
-            raise ValueError(f"Invalid Lock Mode: {arg}")
+            return _enum_from_arg(cls, arg, cls.STAY, "Lock Mode")
 
     class Builder:
-        """Context manager that resolves timing and instantiates the source
-        (source.py:58-209)."""
+        """Context manager: `build()` resolves the arguments, `__enter__` makes the source
+        (source.py:58-209).  Attribute names are the reference's: its callers and subclasses read them."""
 
         def __init__(self, direction="backward", mask_path=None, kernel_path=None, flow_filters=None,
                      seek_ckpt=None, seek_time=None, duration_time=None, repeat: int = 1, lock_expr=None,
                      lock_mode="stay"):
             self.direction = FlowSource.Direction.from_arg(direction)
-            self.width: int | None = None
-            self.height: int | None = None
-            self.framerate: float = 30
-            self.mask_path, self.mask = mask_path, None
-            self.kernel_path, self.kernel = kernel_path, None
-            self.flow_filters: list = []
-            self.flow_filters_string = flow_filters
-            self.seek_ckpt, self.seek_time, self.duration_time = seek_ckpt, seek_time, duration_time
-            self.is_stream = False
-            self.base_length: int | None = None
-            self.length: int | None = None
-            self.start_frame = self.ckpt_start_frame = self.end_frame = 0
-            self.repeat = repeat
-            self.lock_expr_string = lock_expr
-            self.lock_expr_stay = None
-            self.lock_expr_skip: Callable[[float], bool] | None = None
             self.lock_mode = FlowSource.LockMode.from_arg(lock_mode)
+            self.mask_path, self.kernel_path = mask_path, kernel_path
+            self.flow_filters_string, self.lock_expr_string = flow_filters, lock_expr
+            self.seek_ckpt, self.seek_time, self.duration_time, self.repeat = seek_ckpt, seek_time, duration_time, repeat
+            # filled by build() (subclasses set width / height / framerate / base_length before calling it)
+            self.width = self.height = None
+            self.framerate: float = 30
+            self.base_length = self.length = None
+            self.is_stream = False
+            self.start_frame = self.ckpt_start_frame = self.end_frame = 0
+            self.mask = self.kernel = None
+            self.flow_filters: list = []
+            self.lock_expr_stay = self.lock_expr_skip = None
             self.source: FlowSource | None = None
 
         @property
@@ -138,69 +205,48 @@ class FlowSource:
             return FlowSource
 
         def args(self) -> list:
-            return [self.direction, self.width, self.height, self.framerate, self.length, self.start_frame,
-                    self.ckpt_start_frame, self.end_frame]
+            return [getattr(self, name) for name in ("direction", "width", "height", "framerate", "length",
+                                                     "start_frame", "ckpt_start_frame", "end_frame")]
 
         def kwargs(self) -> dict:
-            return {"mask": self.mask, "kernel": self.kernel, "flow_filters": self.flow_filters,
-                    "lock_mode": self.lock_mode, "lock_expr_stay": self.lock_expr_stay,
-                    "lock_expr_skip": self.lock_expr_skip}
+            return {name: getattr(self, name) for name in ("mask", "kernel", "flow_filters", "lock_mode",
+                                                           "lock_expr_stay", "lock_expr_skip")}
+
+        def _load_inputs(self):
+            if self.mask_path is not None:                       # a float mask, one trailing axis (source.py:127-129)
+                from .masks import load_float_mask
+                self.mask = load_float_mask(self.mask_path)[..., np.newaxis]
+            if self.kernel_path is not None:                     # source.py:131-132
+                self.kernel = np.load(self.kernel_path)
+            if self.flow_filters_string is not None:             # "name=expr; name=expr" (source.py:141-149)
+                self.flow_filters = [FlowFilter.from_string(part) for part in self.flow_filters_string.strip().split(";")]
+            text = self.lock_expr_string
+            if text is None:
+                return
+            if self.lock_mode == FlowSource.LockMode.SKIP:       # a predicate of t (source.py:138-139)
+                self.lock_expr_skip = eval("lambda t: " + text)
+            else:                                                # "a,b" or "(a,b),(c,d)": (start, duration) pairs
+                self.lock_expr_stay = tuple(eval("[" + (text if "(" in text else "(" + text + ")") + ",]"))
 
         def build(self):
-            if self.kernel_path is not None:                                            # source.py:131-132
-                self.kernel = np.load(self.kernel_path)
-            if self.mask_path is not None:                                              # source.py:127-129
-                from .masks import load_float_mask
-                self.mask = load_float_mask(self.mask_path)
-                self.mask = self.mask.reshape((*self.mask.shape, 1))
-            if self.flow_filters_string is not None:                                    # source.py:141-149
-                self.flow_filters = [FlowFilter.from_string(part)
-                                     for part in self.flow_filters_string.strip().split(";")]
-            if self.lock_expr_string is not None:                                       # source.py:133-139
-                if self.lock_mode == FlowSource.LockMode.STAY:
-                    text = self.lock_expr_string if "(" in self.lock_expr_string else f"({self.lock_expr_string})"
-                    self.lock_expr_stay = tuple(eval(f"[{text},]"))
-                else:
-                    self.lock_expr_skip = eval("lambda t: " + self.lock_expr_string)
-            if self.base_length is not None and self.base_length <= 0:                  # :151-152
-                self.base_length = None
-            self.is_stream = self.base_length is None
-            if self.is_stream and self.repeat > 1:
-                warnings.warn("Flow source is a stream, cannot repeat it!")
-                self.repeat = 1
-            if self.is_stream and self.seek_time is not None and self.seek_time > 0:
-                warnings.warn("Flow source is a stream, seek time is ignored!")
-                self.seek_time = None
-            start = int(self.seek_time * self.framerate) if (self.seek_time is not None and not self.is_stream) else 0
-            self.start_frame = start                                                    # :164-168
-            if self.duration_time is not None:                                          # :170-175
-                self.end_frame = start + int(round(self.duration_time * self.framerate, 3))
-                if self.base_length is not None:
-                    self.end_frame = min(self.end_frame, self.base_length)
-            elif self.base_length is not None:
-                self.end_frame = self.base_length
-            if self.repeat == 0:                                                        # :178-183
-                self.length = None
-            elif self.is_stream:
-                self.length = self.end_frame
-            else:
-                self.length = self.repeat * (self.end_frame - self.start_frame)
-            if (self.length is not None and self.lock_mode == FlowSource.LockMode.STAY
-                    and self.lock_expr_stay is not None):                                # :186-188
-                for _, lock_duration in self.lock_expr_stay:
-                    self.length += int(lock_duration * self.framerate)
-            self.ckpt_start_frame = start                                               # :190-197
-            if self.seek_ckpt is not None:
-                self.ckpt_start_frame += self.seek_ckpt % (self.end_frame - self.start_frame)
+            self._load_inputs()
+            plan = plan_timeline(self.base_length, self.framerate, self.seek_time, self.duration_time, self.repeat,
+                                 self.seek_ckpt,
+                                 self.lock_expr_stay if self.lock_mode == FlowSource.LockMode.STAY else None)
+            self.base_length, self.is_stream = plan.base_length, plan.is_stream
+            self.repeat, self.seek_time = plan.repeat, plan.seek_time
+            self.start_frame, self.end_frame, self.length = plan.start_frame, plan.end_frame, plan.length
+            self.ckpt_start_frame = plan.ckpt_start_frame
 
         def __enter__(self):
             self.build()
-            self.source = self.cls(*self.args(), **self.kwargs())
-            self.source.validate()
-            logger.debug("Built '%s'", self.source.__class__.__name__)
-            return self.source
+            source = self.cls(*self.args(), **self.kwargs())
+            source.validate()
+            logger.debug("Built '%s'", type(source).__name__)
+            self.source = source          # what __exit__ closes
+            return source
 
-        def __exit__(self, exc_type, exc_value, exc_traceback):
+        def __exit__(self, *exc):
             if self.source is not None:
                 self.source.close()
 
@@ -209,48 +255,53 @@ class FlowSource:
                  lock_mode=None, lock_expr_stay=None, lock_expr_skip=None):
         self.direction = FlowSource.Direction.from_arg(direction)
         self.width, self.height, self.framerate = width, height, framerate
-        self.length = length
-        self.end_frame = end_frame
+        self.length, self.end_frame = length, end_frame
         self.mask, self.kernel, self.flow_filters = mask, kernel, list(flow_filters)
-        if self.kernel is not None:
+        if kernel is not None:
             from .flowops import kernel_result_type
-            if not isinstance(self.kernel, np.ndarray):
-                raise ValueError(f"Attribute kernel has incorrect type {type(self.kernel)}")   # source.py:281
-            kernel_result_type(self.kernel)   # float32 / float64 results only
-        for f in self.flow_filters:
-            if not isinstance(f, FlowFilter):
-                raise ValueError("flow_filters must be transflow_amd.flow.FlowFilter objects")
+            if not isinstance(kernel, np.ndarray):
+                raise ValueError(f"Attribute kernel has incorrect type {type(kernel)}")   # source.py:281
+            kernel_result_type(kernel)   # float32 / float64 results only
+        if not all(isinstance(f, FlowFilter) for f in self.flow_filters):
+            raise ValueError("flow_filters must be transflow_amd.flow.FlowFilter objects")
         self.lock_mode = FlowSource.LockMode.from_arg(lock_mode)
         self.lock_expr_stay, self.lock_expr_skip = lock_expr_stay, lock_expr_skip
-        self.input_frame_index = 0
+        self._locks = LockSchedule(self.lock_mode, lock_expr_stay, lock_expr_skip)
         self.output_frame_index = 0
         self.prev_flow = None
-        self.lock_start: float | None = None
-        self.lock_expr_stay_index = 0
         self._pp = None  # device handle used by post_process, created on first use
-        self.start_frame = ckpt_start_frame      # source.py:246-248: the first rewind honours a checkpoint seek
-        self.rewind()
-        self.start_frame = start_frame
+        # the first pass starts where a checkpoint left off, later passes at start_frame (source.py:246-248)
+        self.input_frame_index = 0
+        self.start_frame, later_passes = ckpt_start_frame, start_frame
+        self.rewind()                                    # subclasses decode up to start_frame here
+        self.start_frame = later_passes
         # source.py:250-263 builds per-pixel clip tables on the host (a 1.2 s Python loop at
         # 1080p); the kernels derive the bounds from the pixel index instead
+
+    # the STAY bookkeeping under the reference's attribute names (its checkpoints and tests read them)
+    lock_start = property(lambda self: self._locks.since)
+    lock_expr_stay_index = property(lambda self: self._locks.which)
 
     def __len__(self):
         return self.length
 
     def validate(self):
-        checks = (("direction", (FlowSource.Direction,)), ("width", (int,)), ("height", (int,)),
-                  ("framerate", (float,)), ("length", (int, type(None))), ("start_frame", (int,)),
-                  ("end_frame", (int,)), ("flow_filters", (list,)), ("lock_mode", (FlowSource.LockMode,)),
-                  ("lock_expr_stay", (tuple, type(None))))
-        for attr, types in checks:                                                       # source.py:268-284
-            if not isinstance(getattr(self, attr), types):
-                raise ValueError(f"Attribute {attr} has incorrect type {type(getattr(self, attr))}")
+        """source.py:268-284: the constructor arguments have the types the pipeline relies on."""
+        expected = {"direction": FlowSource.Direction, "width": int, "height": int, "framerate": float,
+                    "length": (int, type(None)), "start_frame": int, "end_frame": int, "flow_filters": list,
+                    "lock_mode": FlowSource.LockMode, "lock_expr_stay": (tuple, type(None))}
+        for name, types in expected.items():
+            value = getattr(self, name)
+            if not isinstance(value, types):
+                raise ValueError(f"Attribute {name} has incorrect type {type(value)}")
 
     @property
     def t(self) -> float:
-        return 0 if self.framerate is None else self.output_frame_index / self.framerate
+        """Output time in seconds."""
+        return self.output_frame_index / self.framerate if self.framerate is not None else 0
 
     def read_next_flow(self):
+        """One input flow; the input wraps to start_frame when it reaches end_frame (source.py:286-291)."""
         if self.input_frame_index == self.end_frame:
             self.rewind()
         flow = self.next()
@@ -261,32 +312,18 @@ class FlowSource:
         return self
 
     def __next__(self):
-        """source.py:293-321."""
+        """One output flow (source.py:293-321): a locked source hands out its previous flow again
+        (and, in SKIP mode, still consumes an input flow); everything goes through post_process."""
         if self.length is not None and self.output_frame_index >= self.length:
             raise StopIteration
-        locked = False
-        if self.lock_mode == FlowSource.LockMode.STAY and self.lock_expr_stay is not None:
-            was_locked = self.lock_start is not None
-            if was_locked:
-                locked = (self.t - self.lock_start) < self.lock_expr_stay[self.lock_expr_stay_index][1]
-                if not locked:
-                    self.lock_expr_stay_index += 1
-                    self.lock_start = None
-            if (not was_locked) or (not locked):
-                locked = self.t >= self.lock_expr_stay[self.lock_expr_stay_index][0]
-                if locked:
-                    self.lock_start = self.t
-        elif self.lock_mode == FlowSource.LockMode.SKIP and self.lock_expr_skip is not None:
-            locked = self.lock_expr_skip(self.t)
-        if locked:
+        if self._locks.locked(self.t):
             if self.prev_flow is None:
                 raise RuntimeError("Flow is locked but has not been initialized. Maybe lock the flow later?")
             flow = self.prev_flow
+            if self.lock_mode == FlowSource.LockMode.SKIP:
+                self.read_next_flow()
         else:
-            flow = self.read_next_flow()
-        self.prev_flow = flow
-        if locked and self.lock_mode == FlowSource.LockMode.SKIP:
-            self.read_next_flow()
+            flow = self.prev_flow = self.read_next_flow()
         self.output_frame_index += 1
         return self.post_process(flow)
 
