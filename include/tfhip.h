@@ -43,6 +43,19 @@ int tf_init(int device);
    that point cannot use the GPU: fork first, as transflow/pipeline.py does). */
 int tf_is_initialized(void);
 int tf_device_count(int *count);
+/* Run-time options of the library (process-wide; defaults are the measured best):
+     "fb_fused"       -1  the Farnebäck iteration as one kernel on levels of >= fb_fuse_min_px pixels over the
+                          batch, as two kernels below; 0 = two kernels everywhere, 1 = one kernel wherever it
+                          can run (read by tf_fb_create)
+     "fb_fuse_min_px" 4000000
+     "fb_no_share"    0   1 = pairs of a call that share a frame expand it once each (read per call)
+     "fb_no_overlap"  0   1 = a call's kernels stay on the library stream (read by tf_fb_create)
+     "remap_px"       2   pixels per thread of tf_remap_step_dev's kernel: 1, 2 or 4
+     "remap_no_pack"  0   1 = tf_remap_step_dev keeps the layer state as int32 x 4 between steps
+     "prof_levels"    0   1 = profiler labels carry the pyramid level
+   Unknown names and out-of-range values return TF_ERR_ARG.  The environment is never read. */
+int tf_set_option(const char *name, long value);
+int tf_get_option(const char *name, long *value);
 const char *tf_last_error(void);
 /* Block until everything queued on the library stream has finished. */
 int tf_sync(void);
@@ -210,6 +223,10 @@ int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out 
 int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t stride, int level, float *r_out);
 int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, const float *flow, int w, int h,
                                 float *m_out /*[h][w][5]*/);
+/* A5 then A3 at `level` (0 <= level < K) as the pyramid runs them: coarse_flow [Hc][Wc][2] of level + 1 is
+   upsampled (resize INTER_LINEAR to the level's size, times 1/pyr_scale) inside the matrix kernel. */
+int tf_fb_stage_upsampled_matrices(tf_fb *fb, int level, const float *r0, const float *r1, const float *coarse_flow,
+                                   float *m_out /*[Hk][Wk][5]*/);
 int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out /*[h][w][2]*/);
 int tf_fb_level_count(tf_fb *fb, int *n_scales); /* K+1 */
 int tf_fb_level_size(tf_fb *fb, int level, int *w, int *h);

@@ -32,6 +32,18 @@
  * -ffp-contract=off so no FMA contraction changes the rounding.
  *
  * Supported flags: 0 only (transflow's default, cv.py:281).
+ *
+ * [VERIFY] list -- details of the upstream code that this restatement assumes and that only a live
+ * cv2 can confirm (the cv2-gated tests in tests/test_oracle_farneback.py run wherever cv2 imports):
+ *   1. scales run k = levels..0 (levels + 1 scales), stopping early below 32 px      
+ *   2. poly_n is the RADIUS of the expansion's taps (2n + 1 of them)                
+ *   3. Gaussian taps are computed and normalised in double, then cast to float     
+ *   4. cv::resize(INTER_LINEAR) switches to its INTER_AREA fast path when both scale factors are
+ *      exactly 2 -- level 1 of a 0.5 pyramid over even frame sizes.  That path averages the 2x2
+ *      block; its vector body computes ((a + b) + (c + d)) * 0.25f, which is bit-identical to the
+ *      bilinear statement used here (both fractions are exactly 0.5), but its scalar tail computes
+ *      (((a + b) + c) + d) * 0.25f, which can differ by 1 ulp in the last few columns of a row.
+ *      Not restated: which columns fall to the tail depends on the build's SIMD width.
  */
 #include <float.h>
 #include <math.h>

@@ -11,6 +11,20 @@ from tests.helpers import synth_pair
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture
+def lib_option():
+    """Sets documented run-time options of the library (tf_set_option) and restores them afterwards."""
+    from transflow_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, _lib.get_option(name))
+        _lib.set_option(name, value)
+    yield set_
+    for name, value in saved.items():
+        _lib.set_option(name, value)
+
 TOL = 1e-4
 
 
@@ -72,6 +86,29 @@ def test_update_matrices_bit_exact(FB, shape):
     flow[h // 2, w // 2] = (1e4, -1e4)
     fb = FB(max(w, 32), max(h, 32), levels=0)
     np.testing.assert_array_equal(fb.stage_update_matrices(r0, r1, flow), O.update_matrices(r0, r1, flow))
+    fb.close()
+
+
+@pytest.mark.parametrize("shape,pyr_scale,levels", [((270, 480), 0.5, 2), ((271, 483), 0.5, 2), ((480, 854), 0.7, 3),
+                                                    ((333, 517), 0.8, 4), ((200, 300), 0.37, 1), ((135, 241), 0.9, 5)])
+def test_flow_upsample_then_matrices_bit_exact(FB, shape, pyr_scale, levels):
+    """Stage test of A5 (resize(prevFlow -> level size, INTER_LINEAR), flow *= 1/pyr_scale), which
+    only exists fused into the matrix kernel: at every level below the coarsest, including non-dyadic
+    pyramids and odd sizes, M from (R0, R1, upsampled coarse flow) equals the oracle's resize + scale +
+    FarnebackUpdateMatrices bit for bit -- so the upsampled flow itself is bit-identical."""
+    h, w = shape
+    fb = FB(w, h, pyr_scale=pyr_scale, levels=levels)
+    sizes = fb.level_sizes()
+    assert len(sizes) >= 2
+    rng = np.random.default_rng(55)
+    for k in range(len(sizes) - 1):
+        (wk, hk), (wc, hc) = sizes[k], sizes[k + 1]
+        r0 = rng.normal(0, 3, (hk, wk, 5)).astype(np.float32)
+        r1 = rng.normal(0, 3, (hk, wk, 5)).astype(np.float32)
+        coarse = rng.normal(0, 2, (hc, wc, 2)).astype(np.float32)
+        flow = O.resize_linear(coarse, wk, hk) * np.float32(1.0 / pyr_scale)
+        np.testing.assert_array_equal(fb.stage_upsampled_matrices(k, r0, r1, coarse), O.update_matrices(r0, r1, flow),
+                                      err_msg=f"level {k}: {wc}x{hc} -> {wk}x{hk}")
     fb.close()
 
 
@@ -234,9 +271,9 @@ def test_batch_equals_single(FB):
     fb.close()
 
 
-def test_shared_frames_are_expanded_once_with_identical_results(FB, monkeypatch):
+def test_shared_frames_are_expanded_once_with_identical_results(FB, lib_option):
     """Pairs of a batch that name the same frame slot share its expansion (A1+A2 depend on the frame
-    alone): bit-identical to expanding per pair and side (TF_FB_NO_SHARE=1), whatever the order, with
+    alone): bit-identical to expanding per pair and side (option "fb_no_share" = 1), whatever the order, with
     repeated pairs and a pair of a frame with itself."""
     h, w = 270, 480
     frames = [synth_pair(h, w, seed=90, shift=(0.8 * i, 0.5 * i))[1] for i in range(5)]   # one texture, five displacements
@@ -244,7 +281,7 @@ def test_shared_frames_are_expanded_once_with_identical_results(FB, monkeypatch)
     nxt = [1, 2, 3, 4, 3, 0, 0, 3]
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("TF_FB_NO_SHARE", mode)
+        lib_option("fb_no_share", int(mode))
         fb = FB(w, h, levels=3, max_pairs=len(prev), frame_slots=len(frames))
         for i, f in enumerate(frames):
             fb.set_frame(i, f)
@@ -345,8 +382,8 @@ def test_pipelined_calls_equal_single_calls(FB):
     fb.close()
 
 
-def test_fused_and_two_kernel_iterations_agree(FB, monkeypatch):
-    """The same pyramid with the iteration as one kernel on every level (TF_FB_FUSED=1), as two kernels on
+def test_fused_and_two_kernel_iterations_agree(FB, lib_option):
+    """The same pyramid with the iteration as one kernel on every level (option "fb_fused" = 1), as two kernels on
     every level (=0) and with the default per-level choice: identical algorithm, different summation
     order in the window sums and a different reciprocal -- far inside the path's 1e-4 tolerance, and
     each within tolerance of the oracle."""
@@ -355,10 +392,7 @@ def test_fused_and_two_kernel_iterations_agree(FB, monkeypatch):
     ref = O.calc(a, b, levels=3)
     out = {}
     for mode in ("1", "0", None):
-        if mode is None:
-            monkeypatch.delenv("TF_FB_FUSED", raising=False)
-        else:
-            monkeypatch.setenv("TF_FB_FUSED", mode)      # read when the handle is created
+        lib_option("fb_fused", -1 if mode is None else int(mode))      # read when the handle is created
         fb = FB(w, h, levels=3, max_pairs=12, frame_slots=2)   # 12 pairs: level 0 crosses the 4M-pixel threshold
         fb.set_frame(0, a)
         fb.set_frame(1, b)
@@ -378,10 +412,10 @@ def test_fused_and_two_kernel_iterations_agree(FB, monkeypatch):
     ((33, 2), dict(levels=0)),                              # narrower than one lane pair, shorter than the window
     ((2, 300), dict(levels=0)),
 ])
-def test_full_calc_close_fused_on_every_level(FB, monkeypatch, shape, kw):
-    """The one-kernel iteration forced on every level it supports (TF_FB_FUSED=1; by default only levels of
+def test_full_calc_close_fused_on_every_level(FB, lib_option, shape, kw):
+    """The one-kernel iteration forced on every level it supports (option "fb_fused" = 1; by default only levels of
     >= 4M pixels use it): ragged widths and heights, strips narrower than a workgroup, every window width."""
-    monkeypatch.setenv("TF_FB_FUSED", "1")
+    lib_option("fb_fused", 1)
     h, w = shape
     a, b = synth_pair(h, w, seed=23)
     ref = O.calc(a, b, **kw)
@@ -397,11 +431,11 @@ def test_full_calc_close_fused_on_every_level(FB, monkeypatch, shape, kw):
     fb.close()
 
 
-def test_fused_iteration_on_random_shapes_and_batches(FB, monkeypatch):
-    """The one-kernel iteration forced everywhere (TF_FB_FUSED=1) over random frame shapes, window widths
+def test_fused_iteration_on_random_shapes_and_batches(FB, lib_option):
+    """The one-kernel iteration forced everywhere (option "fb_fused" = 1) over random frame shapes, window widths
     and batch sizes: strips narrower and wider than a workgroup, segments shorter than the window, the last
     strip and the last segment ragged; every pair of the batch against the oracle."""
-    monkeypatch.setenv("TF_FB_FUSED", "1")
+    lib_option("fb_fused", 1)
     rng = np.random.default_rng(606)
     for _ in range(16):
         h, w = int(rng.integers(10, 260)), int(rng.integers(10, 420))

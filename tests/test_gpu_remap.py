@@ -528,3 +528,30 @@ def test_timed_remap_kernel_at_full_size_with_its_own_uniform(tf, h, w, directio
     assert not np.array_equal(seen[0], seen[1])              # a new field per frame
     reset_fraction = float((u < 0.5 * rmask).mean())
     assert abs(reset_fraction - 0.25) < 0.01
+
+
+@pytest.mark.parametrize("layer_class", ["moveref", "sum"])
+def test_float64_flow_is_rounded_in_float64(tf, layer_class):
+    """post_process hands on a float64 flow after a float64 convolution kernel (source.py:344-348); the
+    layers round that array itself (movement.py:21, sum.py:10).  Values a float32 cast would push across
+    a rounding boundary (1.4999999999 -> 1.5 -> 2; -0.0000000001 -> -0. -> floor 0 instead of -1)."""
+    _, remap = tf
+    h, w = 12, 16
+    rng = np.random.default_rng(64)
+    flow = np.zeros((h, w, 2), np.float64)
+    flow[2:10, 2:10, 0] = rng.choice([1.4999999999, -1.4999999999, 0.5000000001, 2.5000000001, -1e-10], (8, 8))
+    flow[2:10, 2:10, 1] = rng.choice([1.4999999999, -0.4999999999, -2.5000000001, -1e-10], (8, 8))
+    assert not np.array_equal(np.rint(flow), np.rint(flow.astype(np.float32)))        # the cast would matter
+    ones = np.ones((h, w), bool)
+    pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if layer_class == "moveref":
+        ora = R.MoveRefLayer(h, w, R.LayerParams(), introduction_masks=[ones])
+    else:
+        ora = R.SumLayer(h, w, R.LayerParams(), introduction_masks=[ones])
+    gpu = remap.RemapLayer(h, w, layer_class=layer_class)
+    gpu.set_sources([ones])
+    for _ in range(2):
+        ora.update(flow, [pm], None)
+        gpu.update(flow)
+        gpu.gather(0, pm)
+        np.testing.assert_array_equal(gpu.get_state()[0], ora.data)

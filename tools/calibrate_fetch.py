@@ -14,6 +14,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transflow_amd._lib import set_option  # noqa: E402
 from transflow_amd.device import sync  # noqa: E402
 from transflow_amd.farneback import BACKWARD, Farneback  # noqa: E402
 from transflow_amd.remap import CompImage, RemapLayer  # noqa: E402
@@ -24,12 +25,12 @@ a = np.zeros((h, w), np.uint8)
 fb.set_frame(0, a)
 fb.set_frame(1, a)
 fb.calc_slots([0], [1])                   # the fused iteration kernel (8.3M pixels >= its threshold)
-os.environ["TF_FB_FUSED"] = "0"
+set_option("fb_fused", 0)
 fb2 = Farneback(w, h, levels=0, frame_slots=2, max_pairs=1)   # the same as two kernels per iteration
 fb2.set_frame(0, a)
 fb2.set_frame(1, a)
 fb2.calc_slots([0], [1])
-del os.environ["TF_FB_FUSED"]
+set_option("fb_fused", -1)
 for _ in range(5):
     fb.post_process(0, BACKWARD)          # k_pp_clip: N*8 read, N*8 written
 layer = RemapLayer(h, w)                   # k_remap_init: N*16 written

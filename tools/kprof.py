@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Per-kernel, per-level timing of one batched Farneback+remap step (HIP events through
-tf_prof_*).  Usage on the GPU box:  TF_PROF_LEVELS=1 python tools/kprof.py [workload] [batch]"""
+tf_prof_*).  Usage on the GPU box:  python tools/kprof.py [workload] [batch] [option=value ...]"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("TF_PROF_LEVELS", "1")
 import bench  # noqa: E402
+from transflow_amd import _lib  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "4k"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-job = bench.Job(bench.WORKLOADS[name], batch, seed=1, device=0)
+_lib.set_option("prof_levels", 1)
+for arg in sys.argv[3:]:
+    k, v = arg.split("=")
+    _lib.set_option(k, int(v))
+job = bench.Job(bench.WORKLOADS[name], batch, bench.make_plan(batch + 1, batch, 0, 1), batch + 1, seed=2000, device=0)
 for _ in range(2):
     job.step()
 job.sync()

@@ -58,6 +58,8 @@ PROTOTYPES = {
     "tf_init": (_I, [_I]),
     "tf_is_initialized": (_I, []),
     "tf_device_count": (_I, [_PI]),
+    "tf_set_option": (_I, [C.c_char_p, C.c_long]),
+    "tf_get_option": (_I, [C.c_char_p, C.POINTER(C.c_long)]),
     "tf_last_error": (C.c_char_p, []),
     "tf_sync": (_I, []),
     "tf_stream": (_I, [_PP]),
@@ -93,6 +95,7 @@ PROTOTYPES = {
     "tf_fb_stage_polyexp": (_I, [_P, _P, _I, _I, _P]),
     "tf_fb_stage_level_polyexp": (_I, [_P, _P, C.c_ssize_t, _I, _P]),
     "tf_fb_stage_update_matrices": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "tf_fb_stage_upsampled_matrices": (_I, [_P, _I, _P, _P, _P, _P]),
     "tf_fb_stage_blur_solve": (_I, [_P, _P, _I, _I, _P]),
     "tf_fb_level_count": (_I, [_P, _PI]),
     "tf_fb_level_size": (_I, [_P, _I, _PI, _PI]),
@@ -159,6 +162,17 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int) -> None:
+    """tf_set_option: a documented run-time option of the library (include/tfhip.h)."""
+    check(load().tf_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_long()
+    check(load().tf_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 class TfError(RuntimeError):

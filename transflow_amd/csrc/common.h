@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,25 @@ hipStream_t stream();      // the stream launches go to: the library stream unle
 hipStream_t main_stream(); // the library stream (tf_stream)
 int side_stream(int which, hipStream_t *out); // 0: background work (lowest priority), 1: a call's kernels (highest)
 int ensure_init();
+
+// Documented run-time options (tf_set_option / tf_get_option, include/tfhip.h).
+enum Opt { OPT_FB_FUSED = 0, OPT_FB_FUSE_MIN_PX, OPT_FB_NO_SHARE, OPT_FB_NO_OVERLAP, OPT_REMAP_PX, OPT_REMAP_NO_PACK,
+           OPT_PROF_LEVELS, OPT_COUNT };
+long option(Opt which);
+
+// Kernel-experiment knobs (tile sizes, segment counts ...) are compile-time constants in the shipped
+// library; a build with -DTF_EXPERIMENT reads them from the environment (tools/build_variant.sh).
+#ifdef TF_EXPERIMENT
+inline long tune(const char *env, long dflt)
+{
+    const char *v = getenv(env);
+    return v ? atol(v) : dflt;
+}
+inline const char *tune_str(const char *env) { return getenv(env); }
+#else
+constexpr long tune(const char *, long dflt) { return dflt; }
+constexpr const char *tune_str(const char *) { return nullptr; }
+#endif
 
 // Routes the launches (and profiler events) of the enclosing scope to another stream.
 struct StreamScope {

@@ -2189,8 +2189,8 @@ struct tf_fb {
     int final_buf = 0; // which lflow buffer holds the level-0 result
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
     // the chip with its 3-wave workgroups, as two kernels (k_update_matrices, k_blur_solve_wave)
-    // otherwise.  TF_FB_FUSED=0 / 1 forces never / always.
-    int fused = getenv("TF_FB_FUSED") ? atoi(getenv("TF_FB_FUSED")) : -1;
+    // otherwise.  Option "fb_fused" = 0 / 1 forces never / always (read at tf_fb_create).
+    int fused = (int)option(OPT_FB_FUSED);
     float *Rk(int k) { return (k <= 0 ? R : lv[k]->R).as<float>(); }
     // where the expansion launches being issued write and which part of the image list they read
     // (tf_fb_calc_slots; zero outside it)
@@ -2218,14 +2218,14 @@ struct tf_fb {
     }
 };
 
-// read when a handle is created: TF_FB_NO_OVERLAP=1 keeps everything on the library stream
-static bool fb_overlap_enabled() { return !(getenv("TF_FB_NO_OVERLAP") && atoi(getenv("TF_FB_NO_OVERLAP")) != 0); }
+// read when a handle is created: option "fb_no_overlap" = 1 keeps everything on the library stream
+static bool fb_overlap_enabled() { return option(OPT_FB_NO_OVERLAP) == 0; }
 
-// Profiler labels: with TF_PROF_LEVELS=1 in the environment every Farneback launch is
+// Profiler labels: with option "prof_levels" = 1 every Farneback launch is
 // labelled with its pyramid level ("fb_polyexp.k2"), otherwise by kernel only.
 static const char *lvl_name(const char *base, int k)
 {
-    static const bool per_level = getenv("TF_PROF_LEVELS") && atoi(getenv("TF_PROF_LEVELS")) != 0;
+    const bool per_level = option(OPT_PROF_LEVELS) != 0;
     if (!per_level || k < 0)
         return base;
     static std::map<std::string, std::string> names;
@@ -2284,8 +2284,8 @@ static int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone = fals
 // apply: short kernels, frame widths that are not a multiple of 4, frames too wide to stage 8 rows).
 static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
 {
-    static const bool off = getenv("TF_IMG_NO_SPLIT") && atoi(getenv("TF_IMG_NO_SPLIT")) != 0;
-    static const int min_ksz = getenv("TF_IMG_SPLIT_MIN_KSZ") ? atoi(getenv("TF_IMG_SPLIT_MIN_KSZ")) : 9;
+    static const bool off = tune("TF_IMG_NO_SPLIT", 0) != 0;
+    static const int min_ksz = (int)tune("TF_IMG_SPLIT_MIN_KSZ", 9);
     if (off || L.ksz < min_ksz || L.ksz <= 5 || (W & 3) != 0 || (L.W == W && L.H == H))
         return false;
     std::vector<int> xo, yo;
@@ -2308,7 +2308,7 @@ static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
     // column pass: CP_TX x THo outputs, rows of the plane in LDS.  Small tiles win (measured at 4K x 16:
     // 16 / 24 / 32 / 40 / 56 KB of LDS -> 100 / 117 / 123 / 144 / 235 us at level 3): as many output rows
     // as fit ~20 KB, a single one where even that does not fit
-    static const size_t cp_cap = (getenv("TF_CP_LDS_KB") ? (size_t)atoi(getenv("TF_CP_LDS_KB")) : 20) * 1024;
+    static const size_t cp_cap = (size_t)tune("TF_CP_LDS_KB", 20) * 1024;
     int best = 0, best_lh = 0;
     for (int tho = 1; tho <= 32; tho++) {
         int worst = 0;
@@ -2350,7 +2350,7 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz, int level)
         return worst;
     };
     int s = std::max(1, (W + Wk - 1) / Wk);
-    static const size_t lds_cap = (getenv("TF_IMG_LDS_KB") ? (size_t)atoi(getenv("TF_IMG_LDS_KB")) : 60) * 1024;
+    static const size_t lds_cap = (size_t)tune("TF_IMG_LDS_KB", 60) * 1024;
     ImgTile t;
     t.same_size = (W == Wk && H == Hk);
     t.scale_x = 1. / ((double)Wk / W);
@@ -2369,7 +2369,7 @@ static ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz, int level)
             t.tw_shift++;
         return (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)ksz * sizeof(float);
     };
-    if (const char *ov = getenv("TF_IMG_TILES")) { // "level:TWo:THo,..." experiment override
+    if (const char *ov = tune_str("TF_IMG_TILES")) { // "level:TWo:THo,..." experiment override
         for (const char *p = ov; p && *p;) {
             int l = 0, a = 0, b = 0;
             if (sscanf(p, "%d:%d:%d", &l, &a, &b) == 3 && l == level && fill(a, b) <= 64 * 1024)
@@ -2437,7 +2437,7 @@ static int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1)
 // (level 0 of every pyramid) and a poly_n the blocked expansion is instantiated for.
 static bool fb_can_fuse_level(tf_fb *fb, int k)
 {
-    static const bool off = getenv("TF_FB_NO_A1A2") && atoi(getenv("TF_FB_NO_A1A2")) != 0;
+    static const bool off = tune("TF_FB_NO_A1A2", 0) != 0;
     const Level &L = *fb->lv[k];
     return !off && L.W == fb->W && L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
 }
@@ -2445,7 +2445,7 @@ static bool fb_can_fuse_level(tf_fb *fb, int k)
 // ... and to a level that is exactly half the frame (k_level1_polyexp_t)
 static bool fb_can_fuse_half_level(tf_fb *fb, int k)
 {
-    static const bool off = getenv("TF_FB_NO_A1A2") && atoi(getenv("TF_FB_NO_A1A2")) != 0;
+    static const bool off = tune("TF_FB_NO_A1A2", 0) != 0;
     const Level &L = *fb->lv[k];
     return !off && 2 * L.W == fb->W && 2 * L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
 }
@@ -2496,12 +2496,12 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, float2 *
     // each segment re-sums its first window (2M+1 rows), so segments should be tall; but the launch
     // should hold a few waves per resident slot (12 per CU) or its tail runs on a half-empty chip
     // (measured at 4K x 16: 4096 / 8192 / 12288 / 16384 waves -> 5.03 / 4.92 / 4.88 / 4.86 ms for all levels)
-    static const long waves_wanted = getenv("TF_BLUR_WAVES") ? atol(getenv("TF_BLUR_WAVES")) : 12288;
+    static const long waves_wanted = tune("TF_BLUR_WAVES", 12288);
     const long seg_min = 8;
     long segs_wanted = std::max(1l, waves_wanted / std::max(1l, (long)strips * n_pairs));
     int seg = (int)std::min<long>(256, std::max<long>(seg_min, (h + segs_wanted - 1) / segs_wanted));
-    if (getenv("TF_BLUR_SEG"))
-        seg = std::max(8, atoi(getenv("TF_BLUR_SEG")));
+    if (tune("TF_BLUR_SEG", 0))
+        seg = std::max(8, (int)tune("TF_BLUR_SEG", 0));
     dim3 grid(strips, cdiv(h, seg), n_pairs);
     return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M.as<float>(),
                   flow_out, w, h, scale, seg);
@@ -2548,7 +2548,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
     // rounds of 768, each as long as a segment plus its 2M+1 warm-up / drain steps.  Pick the segment
     // count that minimises rounds x steps (4K x 16: 4 segments = 2240 workgroups, 2.9 -> 3 rounds).
-    static const long forced = getenv("TF_PC_BLOCKS") ? atol(getenv("TF_PC_BLOCKS")) : 0;
+    static const long forced = tune("TF_PC_BLOCKS", 0);
     const long per_seg = (long)strips * n_pairs, slots = 768;
     long best_segs = 1;
     double best_cost = 1e300;
@@ -2674,7 +2674,7 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
                     return fail(set_error(TF_ERR_HIP, "hipMemcpy failed"));
             }
         }
-        if (getenv("TF_DEBUG_TILES"))
+        if (tune("TF_DEBUG_TILES", 0))
             fprintf(stderr, "level %d: %dx%d ksz=%d tile %dx%d LW=%d LH=%d pitch=%d\n", k, L->W, L->H, L->ksz,
                     L->tile.TWo, L->tile.THo, L->tile.LW, L->tile.LH, L->tile.pitch);
         {
@@ -2827,7 +2827,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     // indices of its two.  TF_FB_NO_SHARE=1: one expansion per pair and side, as separate calls would do.
     // With tf_fb_keep_expansions an image IS its slot and survives the call: only slots written since
     // their last expansion are listed, in runs of consecutive slots (a run = one set of launches).
-    const bool no_share = getenv("TF_FB_NO_SHARE") && atoi(getenv("TF_FB_NO_SHARE")) != 0; // read per call
+    const bool no_share = option(OPT_FB_NO_SHARE) != 0; // read per call
     const int P = fb->max_pairs;
     int *image_slot = reinterpret_cast<int *>(fb->pairs_host); // [4P]: the runs, each padded to an even length
     int2 *rmap_host = fb->pairs_host + 2 * P;
@@ -2957,7 +2957,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             b = 1;
         }
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
-        static const long fuse_min_px = getenv("TF_FB_FUSE_MIN_PX") ? atol(getenv("TF_FB_FUSE_MIN_PX")) : 4000000l; // two 1080p levels (4.15M) are in
+        const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
         const bool fused_here = fusable && L.W >= 10 && L.H >= 10 &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
@@ -3228,6 +3228,37 @@ TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *
     fi.mode = 2;
     fi.src = fb->lflow[0].as<float2>();
     TF_TRY(fb_update_matrices(fb, w, h, 1, fi));
+    return download_planar5(m_out, fb->M.as<float>(), n, fb->scratch);
+}
+
+// A5 + A3 as the pyramid runs them at `level` (< K): the coarser level's flow is upsampled
+// (resize INTER_LINEAR, x 1/pyr_scale) inside the kernel that builds the matrices.
+TF_API int tf_fb_stage_upsampled_matrices(tf_fb *fb, int level, const float *r0, const float *r1, const float *coarse_flow,
+                                          float *m_out)
+{
+    TF_REQUIRE(fb && r0 && r1 && coarse_flow && m_out, "tf_fb_stage_upsampled_matrices: null pointer");
+    TF_REQUIRE(level >= 0 && level < fb->K, "tf_fb_stage_upsampled_matrices: level %d has no coarser level (K = %d)", level,
+               fb->K);
+    TF_TRY(ensure_init());
+    Level &L = *fb->lv[level];
+    Level &C = *fb->lv[level + 1];
+    const size_t n = (size_t)L.W * L.H, nc = (size_t)C.W * C.H;
+    TF_TRY(upload_planar5(fb->Rk(0), r0, n, fb->scratch));
+    TF_HIP(hipStreamSynchronize(stream()));
+    TF_TRY(upload_planar5(fb->Rk(0) + 5 * n, r1, n, fb->scratch));
+    TF_HIP(hipMemcpyAsync(fb->lflow[1].p, coarse_flow, nc * 8, hipMemcpyHostToDevice, stream()));
+    FlowInit fi;
+    memset(&fi, 0, sizeof(fi));
+    fi.mode = 1;
+    fi.src = fb->lflow[1].as<float2>();
+    fi.Wc = C.W;
+    fi.Hc = C.H;
+    fi.xofs = L.flow_lerp.xofs.as<int>();
+    fi.yofs = L.flow_lerp.yofs.as<int>();
+    fi.xfrac = L.flow_lerp.xfrac.as<float>();
+    fi.yfrac = L.flow_lerp.yfrac.as<float>();
+    fi.mul = (float)(1. / fb->prm.pyr_scale);
+    TF_TRY(fb_update_matrices(fb, L.W, L.H, 1, fi));
     return download_planar5(m_out, fb->M.as<float>(), n, fb->scratch);
 }
 

@@ -536,7 +536,7 @@ TF_API int tf_flow_convolve_dev(const void *flow_dev, const void *kernel_dev, in
     const size_t n = (size_t)width * height;
     const size_t tile_bytes = (((size_t)(CV_TW + kw - 1) * (CV_TH + kh - 1) * sizeof(float2) + 15) & ~(size_t)15) +
                               (size_t)kh * kw * (wide ? 8 : 4);
-    static const bool no_tiles = getenv("TF_CONV_NO_TILES") && atoi(getenv("TF_CONV_NO_TILES")) != 0;
+    static const bool no_tiles = tune("TF_CONV_NO_TILES", 0) != 0;
     if (tile_bytes <= 64 * 1024 && !no_tiles && n) {
         dim3 grid(cdiv(width, CV_TW), cdiv(height, CV_TH));
         if (wide)

@@ -843,7 +843,7 @@ static int state_unpacked(tf_remap *L)
 
 static bool state_can_pack(const tf_remap *L)
 {
-    static const bool off = getenv("TF_REMAP_NO_PACK") && atoi(getenv("TF_REMAP_NO_PACK")) != 0;
+    const bool off = option(OPT_REMAP_NO_PACK) != 0;
     return !off && L->state_fits && L->H <= 32767 && L->W <= 32767 && L->n_sources <= 32767;
 }
 
@@ -1296,7 +1296,7 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     sp.seed = seed;
     sp.frame = L->frame;
     sp.bg = comp->bg;
-    static const int px_per_thread = getenv("TF_REMAP_PX") ? atoi(getenv("TF_REMAP_PX")) : 2;
+    const int px_per_thread = (int)option(OPT_REMAP_PX);
     dim3 block(BLOCK);
     auto run = [&](auto *old, auto *neu) {
         using S = typename std::remove_const<typename std::remove_pointer<decltype(old)>::type>::type;

@@ -27,6 +27,22 @@ int set_error(int code, const char *fmt, ...)
     return code;
 }
 
+// ---- options ----------------------------------------------------------------------
+struct OptDef {
+    const char *name;
+    long value, lo, hi;
+};
+static OptDef g_opts[OPT_COUNT] = {
+    {"fb_fused", -1, -1, 1},                   // -1: one-kernel iteration on levels of >= fb_fuse_min_px pixels; 0 never; 1 always
+    {"fb_fuse_min_px", 4000000, 0, 1l << 40},  // pixels of a level over the batch (two 1080p levels, 4.15M, are in)
+    {"fb_no_share", 0, 0, 1},                  // 1: expand per pair and side even when pairs share a frame
+    {"fb_no_overlap", 0, 0, 1},                // 1: a call's work stays on the library stream (read at tf_fb_create)
+    {"remap_px", 2, 1, 4},                     // pixels per thread of the one-kernel remap step: 1, 2 or 4
+    {"remap_no_pack", 0, 0, 1},                // 1: the one-kernel remap step keeps its state as int32 x 4
+    {"prof_levels", 0, 0, 1},                  // 1: profiler labels carry the pyramid level ("fb_polyexp.k2")
+};
+long option(Opt which) { return g_opts[which].value; }
+
 static thread_local hipStream_t g_override = nullptr;
 
 hipStream_t stream() { return g_override ? g_override : g_stream; }
@@ -182,6 +198,29 @@ struct tf_event {
 TF_API int tf_abi_version(void) { return TFHIP_ABI_VERSION; }
 
 TF_API int tf_init(int device) { return init_device(device); }
+
+TF_API int tf_set_option(const char *name, long value)
+{
+    TF_REQUIRE(name, "tf_set_option: null name");
+    for (auto &o : g_opts)
+        if (strcmp(o.name, name) == 0) {
+            TF_REQUIRE(value >= o.lo && value <= o.hi, "tf_set_option: %s takes %ld..%ld, got %ld", name, o.lo, o.hi, value);
+            o.value = value;
+            return TF_OK;
+        }
+    return set_error(TF_ERR_ARG, "tf_set_option: unknown option '%s'", name);
+}
+
+TF_API int tf_get_option(const char *name, long *value)
+{
+    TF_REQUIRE(name && value, "tf_get_option: null argument");
+    for (auto &o : g_opts)
+        if (strcmp(o.name, name) == 0) {
+            *value = o.value;
+            return TF_OK;
+        }
+    return set_error(TF_ERR_ARG, "tf_get_option: unknown option '%s'", name);
+}
 
 TF_API int tf_is_initialized(void) { return g_inited ? 1 : 0; }
 

@@ -197,6 +197,19 @@ class Farneback:
         check(self._lib.tf_fb_stage_update_matrices(self._h, _ptr(r0), _ptr(r1), _ptr(flow), w, h, _ptr(out)))
         return out
 
+    def stage_upsampled_matrices(self, level: int, r0, r1, coarse_flow) -> np.ndarray:
+        """A5 + A3 at `level`: the flow of level + 1 upsampled inside the matrix kernel."""
+        sizes = self.level_sizes()
+        (w, h), (wc, hc) = sizes[level], sizes[level + 1]
+        r0 = np.ascontiguousarray(r0, np.float32)
+        r1 = np.ascontiguousarray(r1, np.float32)
+        cf = np.ascontiguousarray(coarse_flow, np.float32)
+        if r0.shape != (h, w, 5) or r1.shape != (h, w, 5) or cf.shape != (hc, wc, 2):
+            raise ValueError("stage_upsampled_matrices: array shapes do not match the handle's levels")
+        out = np.empty((h, w, 5), np.float32)
+        check(self._lib.tf_fb_stage_upsampled_matrices(self._h, int(level), _ptr(r0), _ptr(r1), _ptr(cf), _ptr(out)))
+        return out
+
     def stage_blur_solve(self, m) -> np.ndarray:
         m = np.ascontiguousarray(m, np.float32)
         h, w, _ = m.shape

@@ -104,6 +104,13 @@ class RemapLayer:
         check(self._lib.tf_remap_set_sources(self._h, len(masks), arr))
 
     def update(self, flow: np.ndarray, uniform: np.ndarray | None = None, seed: int = 0) -> None:
+        flow = np.asarray(flow)
+        if flow.dtype != np.float32 and np.issubdtype(flow.dtype, np.floating):
+            # a float64 flow (post_process after a float64 convolution kernel returns one, source.py:344-348):
+            # the reference rounds THAT array (numpy.round, movement.py:21; numpy.floor, sum.py:10), and a
+            # value like 1.4999999999 rounds differently once cast to float32.  Round in the flow's own
+            # type; the integers that come out are exact in float32 and the kernels' rint / floor keep them.
+            flow = np.floor(flow) if self.layer_class == "sum" else np.rint(flow)
         flow = np.ascontiguousarray(flow, dtype=np.float32)
         if flow.shape != (self.height, self.width, 2):
             raise ValueError(f"flow shape {flow.shape} != {(self.height, self.width, 2)}")
