@@ -539,8 +539,8 @@ def test_float64_flow_is_rounded_in_float64(tf, layer_class):
     h, w = 12, 16
     rng = np.random.default_rng(64)
     flow = np.zeros((h, w, 2), np.float64)
-    flow[2:10, 2:10, 0] = rng.choice([1.4999999999, -1.4999999999, 0.5000000001, 2.5000000001, -1e-10], (8, 8))
-    flow[2:10, 2:10, 1] = rng.choice([1.4999999999, -0.4999999999, -2.5000000001, -1e-10], (8, 8))
+    flow[4:9, 4:12, 0] = rng.choice([1.4999999999, -1.4999999999, 0.5000000001, 2.5000000001, -1e-10], (5, 8))
+    flow[4:9, 4:12, 1] = rng.choice([1.4999999999, -0.4999999999, -2.5000000001, -1e-10], (5, 8))
     assert not np.array_equal(np.rint(flow), np.rint(flow.astype(np.float32)))        # the cast would matter
     ones = np.ones((h, w), bool)
     pm = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
