@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Counters of the LARGEST dispatches of a kernel (by grid size) in rocprofv3 counter_collection CSVs.
+usage: tools/pmc_top.py <dir> <kernel-substring>"""
+import csv, glob, sys, collections
+d, sub = sys.argv[1], sys.argv[2]
+for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
+    rows = [r for r in csv.DictReader(open(f)) if sub in r["Kernel_Name"]]
+    if not rows:
+        continue
+    big = max(int(r["Grid_Size"]) for r in rows)
+    acc, disp = collections.defaultdict(float), set()
+    for r in rows:
+        if int(r["Grid_Size"]) == big:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    print(f"{f.split('/')[-3] if f.count('/') > 2 else f}: {sub} grid {big}: {len(disp)} dispatches")
+    for c, v in sorted(acc.items()):
+        print(f"   {c:30s} {v / len(disp):18.1f}")
