@@ -90,8 +90,12 @@ int tf_dev_stream_copy(void *dst_dev, const void *src_dev, size_t bytes);
 /* ---- Farnebäck dense optical flow ----------------------------------------------
  * Replaces cv2.calcOpticalFlowFarneback as called at
  * transflow/flow/sources/cv.py:479-490; parameter struct = the fb_* fields of
- * CvFlowConfig (cv.py:273-281).  flags: 0 only (transflow's default).
+ * CvFlowConfig (cv.py:273-281).  flags (fb_flags, passed straight through at cv.py:489): 0 (transflow's
+ * default), OPTFLOW_USE_INITIAL_FLOW = 4 (the flow array is read first: cv.py:478 fills it with the
+ * previous output), OPTFLOW_FARNEBACK_GAUSSIAN = 256 (Gaussian instead of box window), or both.
  */
+#define TF_OPTFLOW_USE_INITIAL_FLOW 4
+#define TF_OPTFLOW_FARNEBACK_GAUSSIAN 256
 typedef struct tf_fb_params {
     double pyr_scale;  /* fb_pyr_scale  (0.5)  */
     int levels;        /* fb_levels     (3)    */
@@ -110,7 +114,8 @@ int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params,
 void tf_fb_destroy(tf_fb *fb);
 
 /* One pair, host in / host out: flow_out is float32 [height][width][2] (x=dx, y=dy),
-   exactly the array cv.py:479-490 produces.  Strides in bytes. */
+   exactly the array cv.py:479-490 produces.  Strides in bytes.  With TF_OPTFLOW_USE_INITIAL_FLOW the
+   array is cv2's in/out `flow`: read as the initial flow, then overwritten with the result. */
 int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint8_t *next, ptrdiff_t next_stride,
                float *flow_out);
 
@@ -123,6 +128,11 @@ int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint
    previous result keeps running beside it), so a caller that fills frame slots on the device itself (through tf_fb_frame_ptr) calls tf_sync() before the next tf_fb_calc_slots;
    tf_fb_set_frame already returns with the frame in place. */
 int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t stride);
+/* Resident path with TF_OPTFLOW_USE_INITIAL_FLOW: the initial flow of `pair` for the next tf_fb_calc_slots
+   (float32 [height][width][2]; kept until written again, zero at creation), from the host or -- through
+   its device address -- filled on the GPU (e.g. copied from a previous result). */
+int tf_fb_set_initial_flow(tf_fb *fb, int pair, const float *flow);
+int tf_fb_initial_flow_ptr(tf_fb *fb, int pair, void **dev);
 /* Streaming use (cv.py:460-490 holds prev_gray and reads one new frame per call): with `on`, the
    pyramid levels and polynomial expansion of a slot are kept from call to call and redone only
    after tf_fb_set_frame wrote the slot, so the frame that was "next" in one call costs nothing as
@@ -227,7 +237,12 @@ int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, con
    upsampled (resize INTER_LINEAR to the level's size, times 1/pyr_scale) inside the matrix kernel. */
 int tf_fb_stage_upsampled_matrices(tf_fb *fb, int level, const float *r0, const float *r1, const float *coarse_flow,
                                    float *m_out /*[Hk][Wk][5]*/);
+/* A4: the box window (FarnebackUpdateFlow_Blur) -- or, on a handle with TF_OPTFLOW_FARNEBACK_GAUSSIAN, the
+   Gaussian one (FarnebackUpdateFlow_GaussianBlur) -- and the 2x2 solve. */
 int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out /*[h][w][2]*/);
+/* The first step of TF_OPTFLOW_USE_INITIAL_FLOW: flow [H][W][2] -> [Hc][Wc][2] of the coarsest scale,
+   resize(INTER_AREA) times pyr_scale^K. */
+int tf_fb_stage_initial_flow(tf_fb *fb, const float *flow, float *coarse_out);
 int tf_fb_level_count(tf_fb *fb, int *n_scales); /* K+1 */
 int tf_fb_level_size(tf_fb *fb, int level, int *w, int *h);
 

@@ -125,13 +125,56 @@ def update_flow_blur(r0, r1, flow, m, winsize, update):
     return flow, m
 
 
-def calc(prev, nxt, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0):
-    """Same argument meaning as cv2.calcOpticalFlowFarneback (reference cv.py:479-490)."""
+OPTFLOW_USE_INITIAL_FLOW = 4
+OPTFLOW_FARNEBACK_GAUSSIAN = 256
+
+
+def resize_area(src, dw, dh):
+    """cv2.resize(src, (dw, dh), interpolation=INTER_AREA) for a shrinking float image [H,W,C]."""
+    src = _f32(src)
+    sh, sw, cn = src.shape
+    out = np.zeros((dh, dw, cn), np.float32)
+    lib().fbref_resize_area(_p(src), C.c_int(sw), C.c_int(sh), C.c_int(cn), _p(out), C.c_int(dw), C.c_int(dh))
+    return out
+
+
+def area_tab(ssize, dsize):
+    """computeResizeAreaTab's (source index, destination index, weight) triples for one axis."""
+    si = np.zeros(2 * ssize + 2, np.int32)
+    di = np.zeros(2 * ssize + 2, np.int32)
+    al = np.zeros(2 * ssize + 2, np.float32)
+    n = lib().fbref_area_tab(C.c_int(ssize), C.c_int(dsize), _p(si), _p(di), _p(al))
+    return si[:n].copy(), di[:n].copy(), al[:n].copy()
+
+
+def gaussian_window(m):
+    k = np.zeros(m + 1, np.float32)
+    lib().fbref_gaussian_window(C.c_int(m), _p(k))
+    return k
+
+
+def update_flow_gaussian(r0, r1, flow, m, winsize, update):
+    """FarnebackUpdateFlow_GaussianBlur: returns (new_flow, new_M); inputs are not modified."""
+    r0, r1 = _f32(r0), _f32(r1)
+    flow, m = _f32(flow).copy(), _f32(m).copy()
+    h, w, _ = flow.shape
+    lib().fbref_update_flow_gaussian(_p(r0), _p(r1), _p(flow), _p(m), C.c_int(w), C.c_int(h), C.c_int(winsize),
+                                     C.c_int(1 if update else 0))
+    return flow, m
+
+
+def calc(prev, nxt, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0, flow=None):
+    """Same argument meaning as cv2.calcOpticalFlowFarneback (reference cv.py:479-490); `flow` is the
+    initial flow read when flags has OPTFLOW_USE_INITIAL_FLOW (never modified: a new array is returned)."""
     prev = np.ascontiguousarray(prev, np.uint8)
     nxt = np.ascontiguousarray(nxt, np.uint8)
     assert prev.shape == nxt.shape and prev.ndim == 2
     h, w = prev.shape
-    flow = np.zeros((h, w, 2), np.float32)
+    if flow is not None:
+        flow = np.array(flow, dtype=np.float32, order="C", copy=True)
+        assert flow.shape == (h, w, 2)
+    else:
+        flow = np.zeros((h, w, 2), np.float32)
     rc = lib().fbref_calc(_p(prev), _p(nxt), C.c_int(w), C.c_int(h), _p(flow), C.c_double(pyr_scale), C.c_int(levels),
                           C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n), C.c_double(poly_sigma), C.c_int(flags))
     if rc != 0:

@@ -31,7 +31,13 @@
  * products are float, which accumulators are double); build with
  * -ffp-contract=off so no FMA contraction changes the rounding.
  *
- * Supported flags: 0 only (transflow's default, cv.py:281).
+ * Supported flags (cv.py:281, 489 pass CvFlowConfig.fb_flags straight through): 0 (transflow's default),
+ * OPTFLOW_USE_INITIAL_FLOW (4: the caller's flow, which cv.py:478 fills with the previous output, is
+ * shrunk with resize(INTER_AREA) to the coarsest scale and multiplied by that scale) and
+ * OPTFLOW_FARNEBACK_GAUSSIAN (256: FarnebackUpdateFlow_GaussianBlur, a separable float Gaussian of the
+ * 2x2 systems instead of the box window), alone or together.  Both are restated from the same upstream
+ * file and are as unpinned as the rest; of FarnebackUpdateFlow_GaussianBlur the SCALAR loops are
+ * restated (upstream's SIMD body uses v_muladd, which fuses on FMA builds: a 1-ulp build dependence).
  *
  * [VERIFY] list -- details of the upstream code that this restatement assumes and that only a live
  * cv2 can confirm (the cv2-gated tests in tests/test_oracle_farneback.py run wherever cv2 imports):
@@ -503,6 +509,199 @@ FB_EXPORT void fbref_update_flow_blur(const float *R0, const float *R1, float *f
 }
 
 /* ---------------------------------------------------------------------- */
+/* imgproc: resize(..., INTER_AREA) shrinking a float image with cn        */
+/* channels (what OPTFLOW_USE_INITIAL_FLOW does to the caller's flow).     */
+/* Integer factors: resizeAreaFast_ -- every destination value is the sum  */
+/* of its sy x sx block, four at a time (CV_ENABLE_UNROLLED), times        */
+/* 1/area, float.  Otherwise: resizeArea_ with computeResizeAreaTab's      */
+/* fractional cell coverage (tables in double, weights cast to float),     */
+/* rows accumulated in float: buf = sum_k S*alpha_k, sum = beta0*buf, then  */
+/* sum += beta*buf.                                                        */
+/* ---------------------------------------------------------------------- */
+typedef struct {
+    int si, di;
+    float alpha;
+} area_tab;
+
+static int make_area_tab(int ssize, int dsize, double scale, area_tab *tab)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        sx2 = imin(sx2, ssize - 1);
+        sx1 = imin(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) {
+            tab[k].di = dx;
+            tab[k].si = sx1 - 1;
+            tab[k++].alpha = (float)((sx1 - fsx1) / cell);
+        }
+        for (int sx = sx1; sx < sx2; sx++) {
+            tab[k].di = dx;
+            tab[k].si = sx;
+            tab[k++].alpha = (float)(1.0 / cell);
+        }
+        if (fsx2 - sx2 > 1e-3) {
+            double w = fsx2 - sx2;
+            w = w < 1. ? w : 1.;
+            w = w < cell ? w : cell;
+            tab[k].di = dx;
+            tab[k].si = sx2;
+            tab[k++].alpha = (float)(w / cell);
+        }
+    }
+    return k;
+}
+
+/* Exported so that the tests and the GPU build share one statement of the tables. */
+FB_EXPORT int fbref_area_tab(int ssize, int dsize, int *si, int *di, float *alpha)
+{
+    area_tab *t = (area_tab *)malloc(sizeof(area_tab) * (size_t)(ssize * 2 + 2));
+    int n = make_area_tab(ssize, dsize, (double)ssize / dsize, t);
+    for (int i = 0; i < n; i++) {
+        si[i] = t[i].si;
+        di[i] = t[i].di;
+        alpha[i] = t[i].alpha;
+    }
+    free(t);
+    return n;
+}
+
+FB_EXPORT void fbref_resize_area(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh)
+{
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int ix = (int)lrint(scale_x), iy = (int)lrint(scale_y);
+    if (fabs(scale_x - ix) < DBL_EPSILON && fabs(scale_y - iy) < DBL_EPSILON) {
+        int area = ix * iy;
+        float scale = 1.f / area;
+        int *ofs = (int *)malloc(sizeof(int) * (size_t)area);
+        for (int sy = 0, k = 0; sy < iy; sy++)
+            for (int sx = 0; sx < ix; sx++)
+                ofs[k++] = (sy * sw + sx) * cn;
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    const float *S = src + ((size_t)dy * iy * sw + (size_t)dx * ix) * cn + c;
+                    float sum = 0;
+                    int k = 0;
+                    for (; k <= area - 4; k += 4)
+                        sum += S[ofs[k]] + S[ofs[k + 1]] + S[ofs[k + 2]] + S[ofs[k + 3]];
+                    for (; k < area; k++)
+                        sum += S[ofs[k]];
+                    dst[((size_t)dy * dw + dx) * cn + c] = sum * scale;
+                }
+        free(ofs);
+        return;
+    }
+    area_tab *xt = (area_tab *)malloc(sizeof(area_tab) * (size_t)(sw * 2 + 2));
+    area_tab *yt = (area_tab *)malloc(sizeof(area_tab) * (size_t)(sh * 2 + 2));
+    int nx = make_area_tab(sw, dw, scale_x, xt), ny = make_area_tab(sh, dh, scale_y, yt);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)dw * cn);
+    float *sum = (float *)malloc(sizeof(float) * (size_t)dw * cn);
+    int prev_dy = yt[0].di;
+    for (int i = 0; i < dw * cn; i++)
+        sum[i] = 0;
+    for (int j = 0; j < ny; j++) {
+        float beta = yt[j].alpha;
+        int dy = yt[j].di;
+        const float *S = src + (size_t)yt[j].si * sw * cn;
+        for (int i = 0; i < dw * cn; i++)
+            buf[i] = 0;
+        for (int k = 0; k < nx; k++)
+            for (int c = 0; c < cn; c++)
+                buf[xt[k].di * cn + c] = buf[xt[k].di * cn + c] + S[xt[k].si * cn + c] * xt[k].alpha;
+        if (dy != prev_dy) {
+            float *D = dst + (size_t)prev_dy * dw * cn;
+            for (int i = 0; i < dw * cn; i++) {
+                D[i] = sum[i];
+                sum[i] = beta * buf[i];
+            }
+            prev_dy = dy;
+        } else {
+            for (int i = 0; i < dw * cn; i++)
+                sum[i] += beta * buf[i];
+        }
+    }
+    {
+        float *D = dst + (size_t)prev_dy * dw * cn;
+        for (int i = 0; i < dw * cn; i++)
+            D[i] = sum[i];
+    }
+    free(buf);
+    free(sum);
+    free(xt);
+    free(yt);
+}
+
+/* ---------------------------------------------------------------------- */
+/* A4': FarnebackUpdateFlow_GaussianBlur (OPTFLOW_FARNEBACK_GAUSSIAN):      */
+/* kernel[i] = exp(-i^2 / (2 sigma^2)), sigma = m * 0.3, m = winsize / 2,   */
+/* taps as float, normalised by their double sum; vertical then horizontal */
+/* pass in FLOAT, centre first then pairs outwards, replicate border;      */
+/* 2x2 solve with +1e-3 in double; the same interleaved stripe updates of M.*/
+/* ---------------------------------------------------------------------- */
+FB_EXPORT void fbref_gaussian_window(int m, float *kernel /* m + 1 taps */)
+{
+    double sigma = m * 0.3, s = 1;
+    kernel[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        float t = (float)exp(-i * i / (2 * sigma * sigma));
+        kernel[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++)
+        kernel[i] = (float)(kernel[i] * s);
+}
+
+FB_EXPORT void fbref_update_flow_gaussian(const float *R0, const float *R1, float *flowall, float *M, int W, int H,
+                                          int block_size, int update_matrices)
+{
+    int m = block_size / 2;
+    int y0 = 0, y1;
+    int min_update_stripe = imax((1 << 10) / W, block_size);
+    float *kernel = (float *)malloc(sizeof(float) * (size_t)(m + 1));
+    fbref_gaussian_window(m, kernel);
+    float *vbuf = (float *)malloc(sizeof(float) * (size_t)(W + m * 2 + 2) * 5);
+    float *vsum = vbuf + (m + 1) * 5;
+    float *hsum = (float *)malloc(sizeof(float) * (size_t)W * 5);
+    for (int y = 0; y < H; y++) {
+        float *flow = flowall + (size_t)y * W * 2;
+        for (int x = 0; x < W * 5; x++) {
+            float s0 = M[(size_t)y * W * 5 + x] * kernel[0];
+            for (int i = 1; i <= m; i++)
+                s0 += (M[(size_t)imin(y + i, H - 1) * W * 5 + x] + M[(size_t)imax(y - i, 0) * W * 5 + x]) * kernel[i];
+            vsum[x] = s0;
+        }
+        for (int x = 0; x < m * 5; x++) {
+            vsum[-1 - x] = vsum[4 - x];
+            vsum[W * 5 + x] = vsum[W * 5 + x - 5];
+        }
+        for (int x = 0; x < W * 5; x++) {
+            float sum = vsum[x] * kernel[0];
+            for (int i = 1; i <= m; i++)
+                sum += kernel[i] * (vsum[x - i * 5] + vsum[x + i * 5]);
+            hsum[x] = sum;
+        }
+        for (int x = 0; x < W; x++) {
+            double g11 = hsum[x * 5], g12 = hsum[x * 5 + 1], g22 = hsum[x * 5 + 2], h1 = hsum[x * 5 + 3], h2 = hsum[x * 5 + 4];
+            double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            flow[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        y1 = y == H - 1 ? H : y - block_size;
+        if (update_matrices && (y1 == H || y1 >= y0 + min_update_stripe)) {
+            fbref_update_matrices(R0, R1, flowall, M, W, H, y0, y1);
+            y0 = y1;
+        }
+    }
+    free(hsum);
+    free(vbuf);
+    free(kernel);
+}
+
+/* ---------------------------------------------------------------------- */
 /* A.1 driver: level schedule shared with the tests                        */
 /* ---------------------------------------------------------------------- */
 /* Returns the number K of usable coarse scales (scales are k = K..0). */
@@ -546,13 +745,14 @@ FB_EXPORT void fbref_level_image(const uint8_t *img, int W, int H, double pyr_sc
 }
 
 /*
- * The whole call.  flow: [H][W][2] float32 (x = dx, y = dy), output only
- * (flags == 0: no initial flow, box window).  Returns 0, or -1 on bad args.
+ * The whole call.  flow: [H][W][2] float32 (x = dx, y = dy); read first when flags has
+ * OPTFLOW_USE_INITIAL_FLOW (4), output only otherwise.  OPTFLOW_FARNEBACK_GAUSSIAN (256) selects the
+ * Gaussian window.  Returns 0, or -1 on bad args.
  */
 FB_EXPORT int fbref_calc(const uint8_t *prev, const uint8_t *next, int W, int H, float *flow0, double pyr_scale,
                          int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags)
 {
-    if (flags != 0 || !(pyr_scale < 1) || W <= 0 || H <= 0 || winsize < 1 || poly_n < 1)
+    if ((flags & ~(4 | 256)) != 0 || !(pyr_scale < 1) || W <= 0 || H <= 0 || winsize < 1 || poly_n < 1)
         return -1;
     const uint8_t *img[2] = {prev, next};
     int K = fbref_num_levels(W, H, pyr_scale, levels);
@@ -564,7 +764,19 @@ FB_EXPORT int fbref_calc(const uint8_t *prev, const uint8_t *next, int W, int H,
         size_t nk = (size_t)Wk * Hk;
         float *flow = k > 0 ? (float *)malloc(sizeof(float) * nk * 2) : flow0;
         if (!prevFlow) {
-            memset(flow, 0, sizeof(float) * nk * 2);
+            if (flags & 4) { /* resize(flow0, flow, (Wk, Hk), INTER_AREA); flow *= scale */
+                double scale = 1;
+                for (int i = 0; i < k; i++)
+                    scale *= pyr_scale;
+                float *tmp = k > 0 ? flow : (float *)malloc(sizeof(float) * nk * 2);
+                fbref_resize_area(flow0, W, H, 2, tmp, Wk, Hk);
+                for (size_t i = 0; i < nk * 2; i++)
+                    flow[i] = tmp[i] * (float)scale;
+                if (k == 0)
+                    free(tmp);
+            } else {
+                memset(flow, 0, sizeof(float) * nk * 2);
+            }
         } else {
             fbref_resize_linear(prevFlow, pW, pH, 2, flow, Wk, Hk);
             float mul = (float)(1. / pyr_scale);
@@ -578,8 +790,12 @@ FB_EXPORT int fbref_calc(const uint8_t *prev, const uint8_t *next, int W, int H,
             fbref_polyexp(I, Wk, Hk, poly_n, poly_sigma, R[i]);
         }
         fbref_update_matrices(R[0], R[1], flow, M, Wk, Hk, 0, Hk);
-        for (int i = 0; i < iterations; i++)
-            fbref_update_flow_blur(R[0], R[1], flow, M, Wk, Hk, winsize, i < iterations - 1);
+        for (int i = 0; i < iterations; i++) {
+            if (flags & 256)
+                fbref_update_flow_gaussian(R[0], R[1], flow, M, Wk, Hk, winsize, i < iterations - 1);
+            else
+                fbref_update_flow_blur(R[0], R[1], flow, M, Wk, Hk, winsize, i < iterations - 1);
+        }
         free(R[0]);
         free(R[1]);
         free(I);

@@ -62,6 +62,29 @@ def test_flow_source_matches_oracle(direction):
         pickle.loads(pickle.dumps(flow))   # what pipeline.py:86 puts on the queue
 
 
+def test_flow_source_with_initial_flow_flag_follows_the_reference_recurrence():
+    """fb_flags = OPTFLOW_USE_INITIAL_FLOW: every call starts from a copy of the previous OUTPUT, which __next__ has
+    post-processed in place (cv.py:478 with source.py:312-321), zeros for the first frame."""
+    from transflow_amd.config import FlowConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 120, 160
+    frames = _frames(h, w, 5)
+    builder = HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward",
+                                      cv_config=FlowConfig(fb_flags=4))
+    with builder as source:
+        flows = [f.copy() for f in source]
+    assert len(flows) == 4
+    prev = None
+    for t, flow in enumerate(flows):
+        raw = OF.calc(frames[t + 1], frames[t], flags=4, flow=prev)       # BACKWARD: (current, previous)
+        exp = R.post_process(raw.copy(), R.BACKWARD)
+        assert np.abs(flow - exp).max() <= 1e-4 * max(1.0, float(np.abs(exp).max())), t
+        prev = flow          # the GPU's own previous output, as the reference would feed its own
+    # and it is not the plain recurrence
+    plain = OF.calc(frames[2], frames[1])
+    assert np.abs(flows[1] - R.post_process(plain.copy(), R.BACKWARD)).max() > 1e-3
+
+
 def test_flow_source_repeat_and_seek():
     from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
     h, w = 64, 96

@@ -537,7 +537,13 @@ def test_strided_input_and_errors(FB):
         fb.calc(a[:, :w].astype(np.float32), b[:, :w])
     fb.close()
     with pytest.raises(NotImplementedError):
-        FB(w, h, flags=4)
+        FB(w, h, flags=8)                     # no such flag: only 4 and 256 exist (cv.py:281, 489)
+    with pytest.raises(NotImplementedError):
+        FB(w, h, flags=256, winsize=129)      # the Gaussian window's tile serves winsize <= 63
+    plain = FB(w, h)
+    with pytest.raises(ValueError):
+        plain.set_initial_flow(0, np.zeros((h, w, 2), np.float32))    # handle without OPTFLOW_USE_INITIAL_FLOW
+    plain.close()
     with pytest.raises(ValueError):
         FB(w, h, pyr_scale=1.0)
     with pytest.raises(ValueError):
@@ -553,3 +559,86 @@ def test_against_cv2_when_available(FB):
     got = fb.calc(a, b)
     fb.close()
     assert np.abs(got - ref).max() <= flow_tol(ref)
+
+
+# ---- fb_flags: OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256), cv.py:281, 489 ----------------
+
+@pytest.mark.parametrize("shape,winsize", [((64, 64), 15), ((67, 531), 15), ((270, 480), 15), ((40, 50), 9), ((33, 300), 4),
+                                           ((9, 11), 15), ((130, 70), 31), ((1, 1), 3)])
+def test_gaussian_window_solve_bit_exact(FB, shape, winsize):
+    """FarnebackUpdateFlow_GaussianBlur: float Gaussian of M (vertical, then horizontal, replicated borders) and
+    the 2x2 solve -- the kernel runs optflowgf.cpp's scalar statements, so it equals the oracle bit for bit."""
+    h, w = shape
+    rng = np.random.default_rng(75)
+    r = rng.normal(0, 3, (h, w, 5)).astype(np.float32)
+    m = O.update_matrices(r, rng.normal(0, 3, (h, w, 5)).astype(np.float32), np.zeros((h, w, 2), np.float32))
+    ref, _ = O.update_flow_gaussian(r, r, np.zeros((h, w, 2), np.float32), m, winsize, False)
+    fb = FB(max(w, 32), max(h, 32), levels=0, winsize=winsize, flags=256)
+    np.testing.assert_array_equal(fb.stage_blur_solve(m), ref)
+    fb.close()
+
+
+@pytest.mark.parametrize("shape,pyr_scale,levels", [((256, 384), 0.5, 3), ((270, 480), 0.5, 3), ((480, 854), 0.5, 3),
+                                                    ((1080, 1920), 0.5, 5), ((333, 517), 0.7, 4), ((64, 96), 0.5, 0)])
+def test_initial_flow_shrunk_to_the_coarsest_scale_bit_exact(FB, shape, pyr_scale, levels):
+    """OPTFLOW_USE_INITIAL_FLOW's first step: resize(flow, INTER_AREA) to the coarsest scale, times pyr_scale^K --
+    both of resize's paths (integer factors: 256x384 / 8; fractional cell coverage otherwise; same size: a copy)."""
+    h, w = shape
+    fb = FB(w, h, pyr_scale=pyr_scale, levels=levels, flags=4)
+    wc, hc = fb.level_sizes()[-1]
+    k = len(fb.level_sizes()) - 1
+    rng = np.random.default_rng(76)
+    flow = rng.normal(0, 5, (h, w, 2)).astype(np.float32)
+    scale = 1.0
+    for _ in range(k):
+        scale *= pyr_scale
+    ref = O.resize_area(flow, wc, hc) * np.float32(scale)
+    np.testing.assert_array_equal(fb.stage_initial_flow(flow), ref)
+    fb.close()
+
+
+@pytest.mark.parametrize("shape,kw", [((270, 480), dict()), ((480, 854), dict()), ((135, 241), dict(levels=2, winsize=7)),
+                                      ((200, 300), dict(levels=0)), ((97, 113), dict(levels=1, winsize=11, iterations=2))])
+@pytest.mark.parametrize("flags", [4, 256, 260])
+def test_full_calc_with_flags_close(FB, shape, kw, flags):
+    """The whole call with OPTFLOW_USE_INITIAL_FLOW and / or OPTFLOW_FARNEBACK_GAUSSIAN against the oracle, the
+    initial flow being the previous frame pair's result as cv.py:478 passes it; and the caller's array stays as it is."""
+    h, w = shape
+    a, b = synth_pair(h, w, seed=77)
+    _, c = synth_pair(h, w, seed=77, shift=(4.0, 2.5))
+    first = O.calc(a, b, **kw)
+    ref = O.calc(b, c, flags=flags, flow=first, **kw)
+    fb = FB(w, h, flags=flags, **kw)
+    init = first.copy()
+    got = fb.calc(b, c, flow=init)
+    np.testing.assert_array_equal(init, first)
+    err = np.abs(got - ref).max()
+    assert err <= flow_tol(ref), f"flags={flags}: max|d|={err} tol={flow_tol(ref)}"
+    if flags & 4:       # no flow given = zeros (cv.py:478 before the first frame) = the plain call
+        zero = fb.calc(b, c)
+        plain = O.calc(b, c, flags=flags & 256, **kw)
+        assert np.abs(zero - plain).max() <= flow_tol(plain)
+    fb.close()
+
+
+def test_initial_flows_of_a_batch(FB, lib_option):
+    """Resident path: every pair of a batch starts from its own initial flow (tf_fb_set_initial_flow / the device
+    address), on the two-kernel levels and -- forced -- through the one-kernel iteration at the coarsest scale."""
+    h, w = 135, 241
+    frames = [synth_pair(h, w, seed=78, shift=(0.9 * i, -0.6 * i))[1] for i in range(4)]
+    kw = dict(levels=2, winsize=7)
+    inits = [np.random.default_rng(80 + i).normal(0, 1.5, (h, w, 2)).astype(np.float32) for i in range(3)]
+    refs = [O.calc(frames[i], frames[i + 1], flags=4, flow=inits[i], **kw) for i in range(3)]
+    for fused in (-1, 1):
+        lib_option("fb_fused", fused)
+        fb = FB(w, h, flags=4, max_pairs=3, frame_slots=4, **kw)
+        for i, f in enumerate(frames):
+            fb.set_frame(i, f)
+        for i in range(3):
+            fb.set_initial_flow(i, inits[i])
+        assert fb.initial_flow_ptr(1) - fb.initial_flow_ptr(0) == h * w * 8
+        fb.calc_slots([0, 1, 2], [1, 2, 3])
+        for i in range(3):
+            got = fb.get_flow(i)
+            assert np.abs(got - refs[i]).max() <= flow_tol(refs[i]), (fused, i)
+        fb.close()

@@ -126,7 +126,7 @@ def test_single_scale_and_small_frames():
     fl = F.calc(a[:20, :24].copy(), b[:20, :24].copy(), levels=3)
     assert np.isfinite(fl).all()
     with pytest.raises(ValueError):
-        F.calc(a, b, flags=4)
+        F.calc(a, b, flags=8)          # only OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256) exist
 
 
 def test_against_cv2_when_available():
@@ -210,3 +210,112 @@ def test_one_iteration_is_farnebacks_least_squares_displacement():
     np.testing.assert_allclose(got[..., 1][inner], dy[inner], rtol=0, atol=2e-4)
     # and the step goes towards the true displacement
     assert abs(np.median(got[..., 0][inner]) - 1.6) < 0.1 and abs(np.median(got[..., 1][inner]) + 0.9) < 0.1
+
+
+# ---- fb_flags: OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256) ------------------------------
+
+def _area_weights(ssize, dsize):
+    """Independent statement of INTER_AREA's coverage: destination cell [d*s, (d+1)*s) over unit source cells."""
+    s = ssize / dsize
+    w = np.zeros((dsize, ssize))
+    for d in range(dsize):
+        lo, hi = d * s, min((d + 1) * s, ssize)
+        for x in range(int(np.floor(lo)), int(np.ceil(hi))):
+            w[d, x] = max(0.0, min(hi, x + 1) - max(lo, x))
+        w[d] /= w[d].sum()
+    return w
+
+
+@pytest.mark.parametrize("src,dst", [((64, 96), (32, 48)), ((60, 90), (20, 30)), ((135, 241), (34, 60)), ((67, 53), (9, 7)),
+                                     ((480, 854), (60, 107)), ((40, 40), (40, 40))])
+def test_resize_area_is_the_cell_coverage_average(src, dst):
+    rng = np.random.default_rng(21)
+    x = rng.normal(0, 3, (*src, 2)).astype(np.float32)
+    got = F.resize_area(x, dst[1], dst[0])
+    wy, wx = _area_weights(src[0], dst[0]), _area_weights(src[1], dst[1])
+    ref = np.einsum("ys,sxc->yxc", wy, np.einsum("xs,ysc->yxc", wx, x.astype(np.float64)))
+    np.testing.assert_allclose(got, ref, atol=2e-6 * np.abs(x).max() * 4)
+    if src[0] % dst[0] == 0 and src[1] % dst[1] == 0 and src != dst:
+        fy, fx = src[0] // dst[0], src[1] // dst[1]
+        blocks = x.reshape(dst[0], fy, dst[1], fx, 2).transpose(0, 2, 4, 1, 3).reshape(dst[0], dst[1], 2, fy * fx)
+        acc = np.zeros(blocks.shape[:3], np.float32)                 # resizeAreaFast_: four at a time, float
+        k = 0
+        while k + 4 <= fy * fx:
+            acc = acc + (((blocks[..., k] + blocks[..., k + 1]) + blocks[..., k + 2]) + blocks[..., k + 3])
+            k += 4
+        for j in range(k, fy * fx):
+            acc = acc + blocks[..., j]
+        np.testing.assert_array_equal(got, acc * np.float32(1.0 / (fy * fx)))
+    if src == dst:
+        np.testing.assert_array_equal(got, x)
+
+
+def test_area_tables_cover_every_source_cell_once():
+    for ssize, dsize in [(854, 107), (2160, 68), (100, 7), (33, 32)]:
+        si, di, al = F.area_tab(ssize, dsize)
+        assert (np.diff(di) >= 0).all() and di[0] == 0 and di[-1] == dsize - 1
+        per_dst = np.bincount(di, weights=al.astype(np.float64), minlength=dsize)
+        np.testing.assert_allclose(per_dst, 1.0, atol=1e-6)            # a cell's weights sum to one
+        per_src = np.bincount(si, weights=al.astype(np.float64) * (ssize / dsize), minlength=ssize)
+        np.testing.assert_allclose(per_src, 1.0, atol=1e-5)            # and every source cell is spent exactly once
+
+
+def test_gaussian_window_taps_and_update():
+    for m in (2, 5, 7, 10):
+        k = F.gaussian_window(m)
+        i = np.arange(m + 1)
+        ref = np.exp(-i * i / (2 * (m * 0.3) ** 2))
+        np.testing.assert_allclose(k, ref / (ref[0] + 2 * ref[1:].sum()), rtol=3e-7)
+    from scipy import ndimage
+    rng = np.random.default_rng(22)
+    h, w, win = 37, 53, 15
+    r = rng.normal(0, 3, (h, w, 5)).astype(np.float32)
+    m = F.update_matrices(r, rng.normal(0, 3, (h, w, 5)).astype(np.float32), np.zeros((h, w, 2), np.float32))
+    flow, _ = F.update_flow_gaussian(r, r, np.zeros((h, w, 2), np.float32), m, win, False)
+    k = F.gaussian_window(win // 2).astype(np.float64)
+    taps = np.concatenate([k[:0:-1], k])
+    g = ndimage.correlate1d(ndimage.correlate1d(m.astype(np.float64), taps, axis=0, mode="nearest"), taps, axis=1,
+                            mode="nearest")
+    idet = 1.0 / (g[..., 0] * g[..., 2] - g[..., 1] ** 2 + 1e-3)
+    ref = np.stack([(g[..., 0] * g[..., 4] - g[..., 1] * g[..., 3]) * idet,
+                    (g[..., 2] * g[..., 3] - g[..., 1] * g[..., 4]) * idet], axis=-1)
+    assert np.abs(flow - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())   # float sums vs float64 sums
+
+
+def test_flags_initial_flow_and_gaussian_window():
+    a, b = _texture(160, 224), _texture(160, 224, 2.5, -1.5)
+    base = F.calc(a, b)
+    # a zero initial flow is the plain call, bit for bit (resize of zeros, times the scale)
+    np.testing.assert_array_equal(F.calc(a, b, flags=F.OPTFLOW_USE_INITIAL_FLOW, flow=np.zeros_like(base)), base)
+    np.testing.assert_array_equal(F.calc(a, b, flags=F.OPTFLOW_USE_INITIAL_FLOW), base)
+    # the true displacement as the initial flow keeps the estimate there (interior)
+    truth = np.zeros_like(base)
+    truth[..., 0], truth[..., 1] = 2.5, -1.5
+    warm = F.calc(a, b, flags=F.OPTFLOW_USE_INITIAL_FLOW, flow=truth)
+    assert np.abs(warm[20:-20, 20:-20] - truth[20:-20, 20:-20]).max() < 0.1
+    # with a single scale and a single iteration the start decides: a far-off initial flow is NOT recovered
+    cold = F.calc(a, b, levels=0, iterations=1, flags=F.OPTFLOW_USE_INITIAL_FLOW, flow=truth + 6.0)
+    assert np.abs(cold[20:-20, 20:-20] - truth[20:-20, 20:-20]).mean() > 0.5
+    # the Gaussian window still recovers the translation; it is a different estimator
+    gauss = F.calc(a, b, flags=F.OPTFLOW_FARNEBACK_GAUSSIAN)
+    err = np.abs(gauss[25:-25, 25:-25] - truth[25:-25, 25:-25])      # a narrower window (sigma = 2.1): noisier
+    assert err.mean() < 0.05 and err.max() < 0.6
+    assert not np.array_equal(gauss, base)
+    both = F.calc(a, b, flags=F.OPTFLOW_FARNEBACK_GAUSSIAN | F.OPTFLOW_USE_INITIAL_FLOW, flow=truth)
+    assert np.abs(both[25:-25, 25:-25] - truth[25:-25, 25:-25]).mean() < 0.05
+    # the caller's array is never modified
+    init = truth.copy()
+    F.calc(a, b, flags=F.OPTFLOW_USE_INITIAL_FLOW, flow=init)
+    np.testing.assert_array_equal(init, truth)
+
+
+def test_flag_calls_against_cv2_when_available():
+    cv2 = pytest.importorskip("cv2")
+    a, b = _texture(240, 320), _texture(240, 320, 2.5, -1.5)
+    first = cv2.calcOpticalFlowFarneback(a, b, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+    for flags in (cv2.OPTFLOW_FARNEBACK_GAUSSIAN, cv2.OPTFLOW_USE_INITIAL_FLOW,
+                  cv2.OPTFLOW_FARNEBACK_GAUSSIAN | cv2.OPTFLOW_USE_INITIAL_FLOW):
+        ref = cv2.calcOpticalFlowFarneback(a, b, first.copy(), 0.5, 3, 15, 3, 5, 1.2, flags)
+        got = F.calc(a, b, flags=flags, flow=first)
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= tol, flags

@@ -1876,6 +1876,132 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 }
 
 // ---------------------------------------------------------------------------------
+// A4 with OPTFLOW_FARNEBACK_GAUSSIAN: FarnebackUpdateFlow_GaussianBlur.  The 2x2 systems are smoothed
+// by a separable Gaussian of winsize / 2 taps a side (sigma = 0.3 * winsize / 2) in FLOAT -- vertical
+// pass then horizontal pass, centre tap first, then pairs outwards, replicated borders -- and solved
+// with +1e-3 in double.  One plane of M at a time through an LDS tile (64 x 16 outputs, halo m); the
+// statements are the scalar loops of optflowgf.cpp, so the result is bit-identical to the oracle's.
+// ---------------------------------------------------------------------------------
+#define GS_TW 64
+#define GS_TH 16
+__global__ void __launch_bounds__(256)
+k_gauss_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, int m, const float *__restrict__ taps)
+{
+    extern __shared__ float gs_lds[];
+    const int LW = GS_TW + 2 * m, LH = GS_TH + 2 * m;
+    float *sM = gs_lds;               // [LH][LW] one plane of M with its halo (clamped coordinates)
+    float *sV = gs_lds + LH * LW;     // [GS_TH][LW] vertical pass
+    float *sK = sV + GS_TH * LW;      // [m + 1] taps
+    const int pair = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const int x0 = blockIdx.x * GS_TW, y0 = blockIdx.y * GS_TH;
+    for (int i = threadIdx.x; i <= m; i += 256)
+        sK[i] = taps[i];
+    float h[4][5]; // the thread's four outputs (rows ty, ty + 4, ty + 8, ty + 12 of column tx), five planes
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = 0; c < 5; c++) {
+        const float *src = Min + ((size_t)pair * 5 + c) * Nk;
+        __syncthreads(); // the previous plane's passes are done with sM / sV (and sK is written)
+        for (int idx = threadIdx.x; idx < LH * LW; idx += 256) {
+            const int ry = idx / LW, cx = idx - ry * LW;
+            sM[idx] = src[(size_t)clampi(y0 - m + ry, 0, Hk - 1) * Wk + clampi(x0 - m + cx, 0, Wk - 1)];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < GS_TH * LW; idx += 256) {
+            const int ry = idx / LW, cx = idx - ry * LW;
+            const float *col = sM + (ry + m) * LW + cx;
+            float s0 = col[0] * sK[0];
+            for (int i = 1; i <= m; i++)
+                s0 += (col[i * LW] + col[-i * LW]) * sK[i];
+            sV[idx] = s0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float *row = sV + (ty + 4 * q) * LW + tx + m;
+            float sum = row[0] * sK[0];
+            for (int i = 1; i <= m; i++)
+                sum += sK[i] * (row[-i] + row[i]);
+            h[q][c] = sum;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = x0 + tx, y = y0 + ty + 4 * q;
+        if (x >= Wk || y >= Hk)
+            continue;
+        const double g11 = h[q][0], g12 = h[q][1], g22 = h[q][2], h1 = h[q][3], h2 = h[q][4];
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        flow_out[(size_t)pair * Nk + (size_t)y * Wk + x] =
+            make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// OPTFLOW_USE_INITIAL_FLOW: the caller's full-resolution flow shrunk to the coarsest scale with
+// resize(INTER_AREA) and multiplied by that scale (optflowgf.cpp: `resize(flow0, flow, size, 0, 0,
+// INTER_AREA); flow *= scale`).  Integer factors: the sum of the block, four at a time, times 1/area;
+// otherwise computeResizeAreaTab's weights -- per source row buf = sum_k S * alpha_k, then sum = beta0 *
+// buf and sum += beta * buf over the rows of the cell, all float.  One thread per output pixel.
+// ---------------------------------------------------------------------------------
+struct AreaTabs {
+    const int *xsi, *xstart; // x entries: source column; first entry of every destination column (Wc + 1)
+    const float *xalpha;
+    const int *ysi, *ystart;
+    const float *yalpha;
+    int ix, iy;              // > 0: the integer-factor path
+};
+__global__ void k_flow_area_init(const float2 *__restrict__ init, float2 *__restrict__ out, int W, int H, int Wc, int Hc,
+                                 AreaTabs t, float mul)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, pair = blockIdx.z;
+    if (dx >= Wc)
+        return;
+    const float2 *src = init + (size_t)pair * W * H;
+    float2 r;
+    if (t.ix > 0) {
+        const float2 *S = src + (size_t)dy * t.iy * W + (size_t)dx * t.ix;
+        const int area = t.ix * t.iy;
+        const float scale = 1.f / area;
+        auto at = [&](int k) { return S[(k / t.ix) * W + (k % t.ix)]; };
+        float sx = 0.f, sy = 0.f;
+        int k = 0;
+        for (; k <= area - 4; k += 4) {
+            const float2 a = at(k), b = at(k + 1), c = at(k + 2), d = at(k + 3);
+            sx += a.x + b.x + c.x + d.x;
+            sy += a.y + b.y + c.y + d.y;
+        }
+        for (; k < area; k++) {
+            const float2 a = at(k);
+            sx += a.x;
+            sy += a.y;
+        }
+        r = make_float2(sx * scale, sy * scale);
+    } else {
+        float sumx = 0.f, sumy = 0.f;
+        for (int j = t.ystart[dy]; j < t.ystart[dy + 1]; j++) {
+            const float2 *S = src + (size_t)t.ysi[j] * W;
+            float bx = 0.f, by = 0.f;
+            for (int k = t.xstart[dx]; k < t.xstart[dx + 1]; k++) {
+                const float2 v = S[t.xsi[k]];
+                bx = bx + v.x * t.xalpha[k];
+                by = by + v.y * t.xalpha[k];
+            }
+            const float beta = t.yalpha[j];
+            if (j == t.ystart[dy]) {
+                sumx = beta * bx;
+                sumy = beta * by;
+            } else {
+                sumx += beta * bx;
+                sumy += beta * by;
+            }
+        }
+        r = make_float2(sumx, sumy);
+    }
+    out[(size_t)pair * Wc * Hc + (size_t)dy * Wc + dx] = make_float2(r.x * mul, r.y * mul);
+}
+
+// ---------------------------------------------------------------------------------
 // B1: FlowSource.post_process (source.py:337-363)
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float2 clip_to_frame(float2 f, int i, int j, int W, int H)
@@ -2187,6 +2313,13 @@ struct tf_fb {
     bool pairs_pending = false;
     int last_pairs = 0;
     int final_buf = 0; // which lflow buffer holds the level-0 result
+    // fb_flags: OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256)
+    DevBuf init_flow;            // [P][H][W] float2: the caller's initial flow of every pair (flag 4)
+    DevBuf area_i, area_f;       // resize(INTER_AREA) tables to the coarsest scale: ints, then weights
+    AreaTabs area{};
+    DevBuf gauss_taps;           // winsize / 2 + 1 taps of the Gaussian window (flag 256)
+    bool use_initial() const { return (prm.flags & 4) != 0; }
+    bool gaussian() const { return (prm.flags & 256) != 0; }
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
     // the chip with its 3-wave workgroups, as two kernels (k_update_matrices, k_blur_solve_wave)
     // otherwise.  Option "fb_fused" = 0 / 1 forces never / always (read at tf_fb_create).
@@ -2597,6 +2730,113 @@ static bool fb_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *flo
     }
 }
 
+static int fb_gauss_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, int k = -1)
+{
+    const int m = fb->prm.winsize / 2;
+    const size_t smem = ((size_t)(GS_TH + 2 * m) * (GS_TW + 2 * m) + (size_t)GS_TH * (GS_TW + 2 * m) + m + 1) * sizeof(float);
+    dim3 grid(cdiv(w, GS_TW), cdiv(h, GS_TH), n_pairs);
+    return launch(lvl_name("fb_gauss_solve", k), k_gauss_solve, grid, dim3(256), smem, (const float *)fb->M.as<float>(), flow_out,
+                  w, h, m, (const float *)fb->gauss_taps.as<float>());
+}
+
+// computeResizeAreaTab (imgproc/resize.cpp) for one axis: entries grouped by destination index.
+static void area_axis(int ssize, int dsize, std::vector<int> &si, std::vector<int> &start, std::vector<float> &alpha)
+{
+    const double scale = (double)ssize / dsize;
+    start.assign(dsize + 1, 0);
+    for (int dx = 0; dx < dsize; dx++) {
+        start[dx] = (int)si.size();
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) {
+            si.push_back(sx1 - 1);
+            alpha.push_back((float)((sx1 - fsx1) / cell));
+        }
+        for (int sx = sx1; sx < sx2; sx++) {
+            si.push_back(sx);
+            alpha.push_back((float)(1.0 / cell));
+        }
+        if (fsx2 - sx2 > 1e-3) {
+            si.push_back(sx2);
+            alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell));
+        }
+    }
+    start[dsize] = (int)si.size();
+}
+
+static int fb_setup_flags(tf_fb *fb)
+{
+    if (fb->gaussian()) { // FarnebackUpdateFlow_GaussianBlur's taps: exp in double -> float, normalised by the double sum
+        const int m = fb->prm.winsize / 2;
+        std::vector<float> k(m + 1);
+        const double sigma = m * 0.3;
+        double sum = 1;
+        k[0] = 1.f;
+        for (int i = 1; i <= m; i++) {
+            k[i] = (float)std::exp(-i * i / (2 * sigma * sigma));
+            sum += k[i] * 2;
+        }
+        sum = 1. / sum;
+        for (int i = 0; i <= m; i++)
+            k[i] = (float)(k[i] * sum);
+        TF_TRY(fb->gauss_taps.alloc(k.size() * 4));
+        TF_HIP(hipMemcpy(fb->gauss_taps.p, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (fb->use_initial()) {
+        const size_t N0 = (size_t)fb->W * fb->H;
+        TF_TRY(fb->init_flow.alloc((size_t)fb->max_pairs * N0 * 8));
+        TF_HIP(hipMemset(fb->init_flow.p, 0, (size_t)fb->max_pairs * N0 * 8));
+        const Level &C = *fb->lv[fb->K];
+        const double sx = (double)fb->W / C.W, sy = (double)fb->H / C.H;
+        const int ix = (int)std::lrint(sx), iy = (int)std::lrint(sy);
+        memset(&fb->area, 0, sizeof(fb->area));
+        if (std::fabs(sx - ix) < DBL_EPSILON && std::fabs(sy - iy) < DBL_EPSILON) {
+            fb->area.ix = ix;
+            fb->area.iy = iy;
+        } else {
+            std::vector<int> xsi, xst, ysi, yst;
+            std::vector<float> xa, ya;
+            area_axis(fb->W, C.W, xsi, xst, xa);
+            area_axis(fb->H, C.H, ysi, yst, ya);
+            std::vector<int> ints;
+            ints.insert(ints.end(), xsi.begin(), xsi.end());
+            ints.insert(ints.end(), xst.begin(), xst.end());
+            ints.insert(ints.end(), ysi.begin(), ysi.end());
+            ints.insert(ints.end(), yst.begin(), yst.end());
+            std::vector<float> fl(xa);
+            fl.insert(fl.end(), ya.begin(), ya.end());
+            TF_TRY(fb->area_i.alloc(ints.size() * 4));
+            TF_TRY(fb->area_f.alloc(fl.size() * 4));
+            TF_HIP(hipMemcpy(fb->area_i.p, ints.data(), ints.size() * 4, hipMemcpyHostToDevice));
+            TF_HIP(hipMemcpy(fb->area_f.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice));
+            const int *bi = fb->area_i.as<int>();
+            const float *bf = fb->area_f.as<float>();
+            fb->area.xsi = bi;
+            fb->area.xstart = bi + xsi.size();
+            fb->area.ysi = bi + xsi.size() + xst.size();
+            fb->area.ystart = bi + xsi.size() + xst.size() + ysi.size();
+            fb->area.xalpha = bf;
+            fb->area.yalpha = bf + xa.size();
+        }
+    }
+    return TF_OK;
+}
+
+// The coarsest scale's flow from the pairs' initial flows: resize(INTER_AREA) * scale  (flag 4).
+static int fb_initial_flow(tf_fb *fb, int n_pairs, float2 *out)
+{
+    const Level &C = *fb->lv[fb->K];
+    double scale = 1;
+    for (int i = 0; i < fb->K; i++)
+        scale *= fb->prm.pyr_scale;
+    dim3 block(64), grid(cdiv(C.W, 64), C.H, n_pairs);
+    return launch("fb_initial_flow", k_flow_area_init, grid, block, 0, (const float2 *)fb->init_flow.as<float2>(), out, fb->W,
+                  fb->H, C.W, C.H, fb->area, (float)scale);
+}
+
 static int fb_validate_params(const tf_fb_params *p, int width, int height)
 {
     TF_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 30), "tf_fb_create: bad size %dx%d", width,
@@ -2607,9 +2847,11 @@ static int fb_validate_params(const tf_fb_params *p, int width, int height)
     TF_REQUIRE(p->iterations >= 1, "tf_fb_create: iterations must be >= 1, got %d", p->iterations);
     TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= MAX_POLY_N, "tf_fb_create: poly_n must be in [1,%d], got %d", MAX_POLY_N,
                p->poly_n);
-    if (p->flags != 0)
-        return set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: flags=%d not supported (only 0: box window, no initial flow)",
-                         p->flags);
+    if ((p->flags & ~(4 | 256)) != 0)
+        return set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: flags=%d not supported (OPTFLOW_USE_INITIAL_FLOW = 4 and "
+                                             "OPTFLOW_FARNEBACK_GAUSSIAN = 256 are)", p->flags);
+    if ((p->flags & 256) && p->winsize / 2 > 31)
+        return set_error(TF_ERR_UNSUPPORTED, "tf_fb_create: the Gaussian window serves winsize <= 63, got %d", p->winsize);
     return TF_OK;
 }
 
@@ -2690,6 +2932,8 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         if ((rc = L.flow_lerp.upload_tabs(C.W, C.H, L.W, L.H)))
             return fail(rc);
     }
+    if ((rc = fb_setup_flags(fb)))
+        return fail(rc);
     const size_t N0 = (size_t)width * height, P = (size_t)max_pairs;
     fb->nsets = (fb_overlap_enabled() && fb->K > 0) ? 2 : 1; // a single scale: every launch fills the chip anyway
     if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
@@ -2959,7 +3203,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
-        const bool fused_here = fusable && L.W >= 10 && L.H >= 10 &&
+        const bool fused_here = fusable && !fb->gaussian() && L.W >= 10 && L.H >= 10 &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;
@@ -2971,7 +3215,14 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             const int I = fb->prm.iterations;
             const int p = (k == 0 && overlap) ? out_buf : a, q = (k == 0 && overlap) ? a : b;
             auto buf_of = [&](int i) { return ((I - i) & 1) ? q : p; }; // what iteration i (1..I) writes
-            const float2 *src = nullptr; // zero flow at the coarsest scale (flags == 0)
+            const float2 *src = nullptr; // zero flow at the coarsest scale ...
+            if (k == fb->K && fb->use_initial()) { // ... or the caller's, shrunk to it (a buffer neither p nor q)
+                int c = 0;
+                while (c == p || c == q)
+                    c++;
+                TF_TRY(fb_initial_flow(fb, n_pairs, fb->lflow[c].as<float2>()));
+                src = fb->lflow[c].as<float2>();
+            }
             for (int i = 1; i <= I; i++) {
                 int rc = TF_OK;
                 // the first iteration below the coarsest scale upsamples the coarser level's flow itself
@@ -2983,13 +3234,21 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
             }
             result = p;
         } else {
-            TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, k));
             FlowInit fl;
             memset(&fl, 0, sizeof(fl));
             fl.mode = 2;
             fl.src = fb->lflow[a].as<float2>();
+            if (k == fb->K && fb->use_initial()) { // the caller's flow, shrunk to the coarsest scale, instead of zero
+                TF_TRY(fb_initial_flow(fb, n_pairs, fb->lflow[a].as<float2>()));
+                TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, k));
+            } else {
+                TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fi, k));
+            }
             for (int i = 0; i < fb->prm.iterations; i++) {
-                TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, fb->lflow[a].as<float2>(), k));
+                if (fb->gaussian())
+                    TF_TRY(fb_gauss_solve(fb, L.W, L.H, n_pairs, fb->lflow[a].as<float2>(), k));
+                else
+                    TF_TRY(fb_blur_solve(fb, L.W, L.H, n_pairs, fb->lflow[a].as<float2>(), k));
                 if (i < fb->prm.iterations - 1) // M is a pure function of (R0, R1, flow): rebuild it in place
                     TF_TRY(fb_update_matrices(fb, L.W, L.H, n_pairs, fl, k));
             }
@@ -3027,10 +3286,33 @@ TF_API int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out)
     return TF_OK;
 }
 
+TF_API int tf_fb_set_initial_flow(tf_fb *fb, int pair, const float *flow)
+{
+    TF_REQUIRE(fb && flow, "tf_fb_set_initial_flow: null pointer");
+    TF_REQUIRE(fb->use_initial(), "tf_fb_set_initial_flow: the handle was created without OPTFLOW_USE_INITIAL_FLOW (flags & 4)");
+    TF_REQUIRE(pair >= 0 && pair < fb->max_pairs, "tf_fb_set_initial_flow: pair %d of %d", pair, fb->max_pairs);
+    TF_TRY(ensure_init());
+    const size_t N0 = (size_t)fb->W * fb->H;
+    TF_HIP(hipMemcpyAsync(fb->init_flow.as<float2>() + (size_t)pair * N0, flow, N0 * 8, hipMemcpyHostToDevice, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
+TF_API int tf_fb_initial_flow_ptr(tf_fb *fb, int pair, void **dev)
+{
+    TF_REQUIRE(fb && dev, "tf_fb_initial_flow_ptr: null pointer");
+    TF_REQUIRE(fb->use_initial(), "tf_fb_initial_flow_ptr: the handle was created without OPTFLOW_USE_INITIAL_FLOW (flags & 4)");
+    TF_REQUIRE(pair >= 0 && pair < fb->max_pairs, "tf_fb_initial_flow_ptr: pair %d of %d", pair, fb->max_pairs);
+    *dev = fb->init_flow.as<float2>() + (size_t)pair * fb->W * fb->H;
+    return TF_OK;
+}
+
 TF_API int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint8_t *next, ptrdiff_t next_stride,
                       float *flow_out)
 {
     TF_REQUIRE(fb && prev && next && flow_out, "tf_fb_calc: null pointer");
+    if (fb->use_initial()) // cv2's `flow` is an in/out array: with OPTFLOW_USE_INITIAL_FLOW it is read first
+        TF_TRY(tf_fb_set_initial_flow(fb, 0, flow_out));
     TF_TRY(tf_fb_set_frame(fb, 0, prev, prev_stride));
     TF_TRY(tf_fb_set_frame(fb, 1, next, next_stride));
     int a = 0, b = 1;
@@ -3262,6 +3544,19 @@ TF_API int tf_fb_stage_upsampled_matrices(tf_fb *fb, int level, const float *r0,
     return download_planar5(m_out, fb->M.as<float>(), n, fb->scratch);
 }
 
+// OPTFLOW_USE_INITIAL_FLOW's first step alone: flow [H][W][2] -> the coarsest scale's starting flow
+// [Hc][Wc][2] = resize(flow, INTER_AREA) * pyr_scale^K.
+TF_API int tf_fb_stage_initial_flow(tf_fb *fb, const float *flow, float *coarse_out)
+{
+    TF_REQUIRE(fb && flow && coarse_out, "tf_fb_stage_initial_flow: null pointer");
+    TF_TRY(tf_fb_set_initial_flow(fb, 0, flow));
+    const Level &C = *fb->lv[fb->K];
+    TF_TRY(fb_initial_flow(fb, 1, fb->lflow[0].as<float2>()));
+    TF_HIP(hipMemcpyAsync(coarse_out, fb->lflow[0].p, (size_t)C.W * C.H * 8, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
 TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float *flow_out)
 {
     TF_REQUIRE(fb && m && flow_out, "tf_fb_stage_blur_solve: null pointer");
@@ -3269,7 +3564,10 @@ TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float
     TF_TRY(ensure_init());
     size_t n = (size_t)w * h;
     TF_TRY(upload_planar5(fb->M.as<float>(), m, n, fb->scratch));
-    TF_TRY(fb_blur_solve(fb, w, h, 1, fb->lflow[0].as<float2>()));
+    if (fb->gaussian()) // FarnebackUpdateFlow_GaussianBlur's window on a handle created with flags & 256
+        TF_TRY(fb_gauss_solve(fb, w, h, 1, fb->lflow[0].as<float2>()));
+    else
+        TF_TRY(fb_blur_solve(fb, w, h, 1, fb->lflow[0].as<float2>()));
     TF_HIP(hipMemcpyAsync(flow_out, fb->lflow[0].p, n * 8, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
     return TF_OK;

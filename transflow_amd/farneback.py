@@ -13,6 +13,9 @@ import numpy as np
 from . import _lib
 from ._lib import TfFbParams, TfFlowOp, check
 
+OPTFLOW_USE_INITIAL_FLOW = 4      # cv2.OPTFLOW_USE_INITIAL_FLOW
+OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv2.OPTFLOW_FARNEBACK_GAUSSIAN
+
 FORWARD = 0   # FlowSource.Direction.FORWARD  (flow/sources/source.py:21)
 BACKWARD = 1  # FlowSource.Direction.BACKWARD (flow/sources/source.py:22)
 
@@ -31,6 +34,7 @@ class Farneback:
             check(self._lib.tf_init(int(device)))
         self.width, self.height = int(width), int(height)
         self.frame_slots, self.max_pairs = int(frame_slots), int(max_pairs)
+        self.flags = int(flags)
         prm = TfFbParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
                          float(poly_sigma), int(flags))
         check(self._lib.tf_fb_create(C.byref(self._h), self.width, self.height, C.byref(prm),
@@ -56,9 +60,19 @@ class Farneback:
         return a
 
     # -- one pair, host in / host out -------------------------------------------------
-    def calc(self, prev, nxt) -> np.ndarray:
+    def calc(self, prev, nxt, flow=None) -> np.ndarray:
+        """`flow`: the initial flow, read when the handle has OPTFLOW_USE_INITIAL_FLOW (zeros if None, as
+        cv.py:478 passes before the first frame); never modified, a new array is returned."""
         p, n = self._grey(prev), self._grey(nxt)
-        flow = np.empty((self.height, self.width, 2), np.float32)
+        if self.flags & OPTFLOW_USE_INITIAL_FLOW:
+            if flow is None:
+                flow = np.zeros((self.height, self.width, 2), np.float32)
+            else:
+                flow = np.array(flow, dtype=np.float32, order="C", copy=True)
+                if flow.shape != (self.height, self.width, 2):
+                    raise ValueError(f"initial flow shape {flow.shape} != {(self.height, self.width, 2)}")
+        else:
+            flow = np.empty((self.height, self.width, 2), np.float32)
         check(self._lib.tf_fb_calc(self._h, _ptr(p), p.strides[0], _ptr(n), n.strides[0], _ptr(flow)))
         return flow
 
@@ -66,6 +80,25 @@ class Farneback:
     def set_frame(self, slot: int, frame) -> None:
         a = self._grey(frame)
         check(self._lib.tf_fb_set_frame(self._h, int(slot), _ptr(a), a.strides[0]))
+
+    def set_initial_flow(self, pair: int, flow) -> None:
+        """Resident path, OPTFLOW_USE_INITIAL_FLOW: the initial flow of `pair` for the next calc_slots."""
+        f = np.ascontiguousarray(flow, dtype=np.float32)
+        if f.shape != (self.height, self.width, 2):
+            raise ValueError(f"initial flow shape {f.shape} != {(self.height, self.width, 2)}")
+        check(self._lib.tf_fb_set_initial_flow(self._h, int(pair), _ptr(f)))
+
+    def initial_flow_ptr(self, pair: int) -> int:
+        p = C.c_void_p()
+        check(self._lib.tf_fb_initial_flow_ptr(self._h, int(pair), C.byref(p)))
+        return p.value
+
+    def stage_initial_flow(self, flow) -> np.ndarray:
+        f = np.ascontiguousarray(flow, dtype=np.float32)
+        w, h = self.level_sizes()[-1]
+        out = np.empty((h, w, 2), np.float32)
+        check(self._lib.tf_fb_stage_initial_flow(self._h, _ptr(f), _ptr(out)))
+        return out
 
     def frame_ptr(self, slot: int) -> int:
         p = C.c_void_p()

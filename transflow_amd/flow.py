@@ -543,9 +543,14 @@ class HipFlowSource(FlowSource):
     # the mask and the direction handling, only the new frame goes up and only the final flow comes
     # down -- one transfer each instead of two frames up and the flow down, up and down again.  The
     # public next() / post_process() pair keeps working on host arrays for any other caller.
+    def _uses_initial_flow(self) -> bool:
+        return bool(self.config.fb_flags & 4)      # cv2.OPTFLOW_USE_INITIAL_FLOW
+
     def _resident_ok(self) -> bool:
+        # with OPTFLOW_USE_INITIAL_FLOW every call starts from the previous OUTPUT (cv.py:478 passes a copy of
+        # prev_flow, which __next__ has post-processed in place): that array lives on the host
         return (self.lock_expr_stay is None and self.lock_expr_skip is None and self.kernel is None
-                and not any(f.name == "polar" for f in self.flow_filters))
+                and not self._uses_initial_flow() and not any(f.name == "polar" for f in self.flow_filters))
 
     def read_next_flow(self):
         if not self._resident_ok():
@@ -605,7 +610,10 @@ class HipFlowSource(FlowSource):
             left, right = gray, self.prev_gray
         if left is None or right is None:
             raise ValueError("Missing reference frames")
-        flow = self._handle().calc(left, right)
+        if self._uses_initial_flow():     # cv.py:478: a copy of the previous flow, zeros before the first
+            flow = self._handle().calc(left, right, flow=self.prev_flow)
+        else:
+            flow = self._handle().calc(left, right)
         self.prev_gray = gray
         self._prev_slot = None       # calc() used both frame slots
         return flow
