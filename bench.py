@@ -405,6 +405,32 @@ def gather_leg(job, host, rccl, reps=3):
             "frames_per_s_with_gather_every_step": world * job.batch / dt_in}
 
 
+def run_with_timeout(fn, seconds):
+    """fn() on a helper thread; TimeoutError if it has not returned after `seconds` (the thread is then left behind:
+    the process must end with os._exit)."""
+    import threading
+    box = {}
+
+    def target():
+        try:
+            box["value"] = fn()
+        except BaseException as err:   # noqa: BLE001 -- handed to the caller
+            box["error"] = err
+
+    t = threading.Thread(target=target, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        box["stuck"] = True
+        raise TimeoutError(f"no answer after {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box["value"]
+
+
+STUCK_THREADS = False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,23 +478,33 @@ def main():
     if world > 1 or args.rccl:
         # shared inputs come from rank 0 over RCCL (one-off broadcast, outside the timed region)
         from transflow_amd.device import DevBuffer
-        try:
-            rccl = B.RcclGroup(host)
+
+        def rccl_setup():
+            g = B.RcclGroup(host)
             pix_buf = DevBuffer(h * w * 3)
             if rank == 0:
                 pix_buf.upload(np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8))
-            rccl.broadcast_dev(pix_buf.ptr, h * w * 3)
+            g.broadcast_dev(pix_buf.ptr, h * w * 3)
             check(lib.tf_sync())
-            pixmap, pixmap_dev = pix_buf.download((h, w, 3), np.uint8), pix_buf.ptr
+            mask = None
             if wl["reset"]:
                 m_buf = DevBuffer(h * w * 4)
                 if rank == 0:
                     m_buf.upload(np.random.default_rng(1238).random((h, w), dtype=np.float32))
-                rccl.broadcast_dev(m_buf.ptr, h * w * 4)
+                g.broadcast_dev(m_buf.ptr, h * w * 4)
                 check(lib.tf_sync())
-                reset_mask = m_buf.download((h, w), np.float32)
+                mask = m_buf.download((h, w), np.float32)
                 m_buf.close()
-        except Exception as err:    # the path itself needs no collective: say so loudly and carry on per rank
+            return g, pix_buf, pix_buf.download((h, w, 3), np.uint8), mask
+
+        try:
+            # a communicator that never comes up must not hang the run: the path itself needs no collective
+            rccl, pix_buf, pixmap, reset_mask = run_with_timeout(rccl_setup, float(os.environ.get("TF_BENCH_RCCL_TIMEOUT", 180)))
+            pixmap_dev = pix_buf.ptr
+        except BaseException as err:    # say so loudly and carry on with inputs generated per rank
+            if isinstance(err, TimeoutError):
+                global STUCK_THREADS
+                STUCK_THREADS = True
             rccl_error = f"{type(err).__name__}: {err}"
             print(f"[bench] rank {rank}: RCCL leg failed ({rccl_error}); shared inputs generated per rank instead",
                   file=sys.stderr)
@@ -633,3 +669,7 @@ def main():
 
 if __name__ == "__main__":
     main()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if STUCK_THREADS:      # a helper thread is still inside a call that never returned
+        os._exit(0)

@@ -215,6 +215,8 @@ def test_dropin_install_patches_reference_factories():
             comp = Compositor.from_args(4, 6, [RefLayerConfig(0, reset_mode="random", reset_random_factor=0.5)],
                                         background_color="#ff8000")
             assert isinstance(comp, HipCompositor) and comp.layers[0].config.reset_random_factor == 0.5
+            from transflow.compositor.layers.data import DataLayer as RefDataLayer
+            assert isinstance(comp.layers[0], RefDataLayer)          # what extra/control.py:155 checks
             assert comp.background_color == (255, 128, 0)
             other = Compositor.from_args(4, 6, [RefLayerConfig(0, classname="sum"),
                                                 RefLayerConfig(1, classname="introduction")])
@@ -392,3 +394,43 @@ def test_builder_arithmetic_matches_the_reference_class_on_random_arguments():
             except Exception as e:                      # e.g. a stream with a duration-less range: both must agree
                 out.append(type(e).__name__)
         assert out[0] == out[1], f"trial {trial}: {kw} base_length={base_length} fps={fps}: {out}"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/transflow"), reason="needs the reference tree (build container only)")
+def test_checkpointed_layers_pass_controls_datalayer_test(tmp_path):
+    """extra/control.py:146-162 unpickles a checkpoint's compositor, insists on isinstance(layer, DataLayer) and reads
+    layer.data / layer.INDEX_*: in a fresh process that has transflow on its path, a pickled HipCompositor's data
+    layers are DataLayer instances, the static layer is not (as in the reference), and no GPU is touched."""
+    import subprocess
+    import sys
+    comp = HipCompositor.from_args(6, 8, [LayerConfig(0), LayerConfig(1, classname="sum"),
+                                          LayerConfig(2, classname="introduction"), LayerConfig(3, classname="static")])
+    rng = np.random.default_rng(4)
+    for layer, depth in zip(comp.layers[:3], (4, 4, 8)):
+        data = rng.integers(0, 6, (6, 8, depth), dtype=np.int32)
+        state = layer.__getstate__()
+        state["_saved_state"] = (data, np.zeros((6, 8, 4), np.uint8))
+        layer.__setstate__(state)
+    blob = tmp_path / "compositor.bin"
+    blob.write_bytes(pickle.dumps(comp))
+    code = f"""
+import pickle, sys, numpy
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, {str(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))!r})
+from transflow.compositor.layers.data import DataLayer          # what extra/control.py imports
+comp = pickle.load(open({str(blob)!r}, "rb"))
+flags = [isinstance(l, DataLayer) for l in comp.layers]
+assert flags == [True, True, True, False], flags
+layer = comp.layers[0]
+mapping = numpy.concatenate([layer.data[:, :, layer.INDEX_J][:, :, numpy.newaxis],
+                             layer.data[:, :, layer.INDEX_I][:, :, numpy.newaxis]], axis=2).astype(int)   # control.py:158-160
+alpha = layer.data[:, :, layer.INDEX_ALPHA]
+intro = comp.layers[2]
+assert (intro.INDEX_I, intro.INDEX_J, intro.INDEX_ALPHA) == (5, 6, 3) and intro.data.shape == (6, 8, 8)
+import transflow_amd._lib as L
+assert L._lib is None, "the GPU library was loaded"
+print("OK", mapping.shape, int(alpha.sum()))
+"""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK (6, 8, 2)")

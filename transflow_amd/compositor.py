@@ -139,7 +139,23 @@ class _HipLayer:
             self._dev = None
 
 
-class _HipDataLayer(_HipLayer):
+def _reference_data_layer():
+    """transflow's own DataLayer class where that package is importable, else None.  extra/control.py:155-156
+    accepts a checkpoint's layer only if `isinstance(layer, DataLayer)`; it then reads nothing but `layer.data`
+    and `layer.INDEX_*` (:158-162).  With the reference's class among their bases the layers of this backend
+    pass that test in whatever process unpickles them -- the reference's __init__ is never run, none of its
+    attributes or methods is used, and where transflow is absent the layers simply do without the base."""
+    try:
+        from transflow.compositor.layers.data import DataLayer
+        return DataLayer
+    except Exception:       # not installed, or not importable on this interpreter (cv2, typing.Self ...)
+        return None
+
+
+_REF_DATA_LAYER = _reference_data_layer()
+
+
+class _HipDataLayer(_HipLayer, *((_REF_DATA_LAYER,) if _REF_DATA_LAYER is not None else ())):
     INDEX_I, INDEX_J, INDEX_ALPHA, INDEX_SOURCE = 0, 1, 2, 3   # data.py:8-12
 
     @property
@@ -210,6 +226,18 @@ class HipIntroductionLayer(_HipDataLayer):
         for i, source in enumerate(self.sources):                                       # :46-63
             pixmap = source.next()
             layer.introduce(i, pixmap, source.frame_number)
+
+
+def bind_reference_data_layer() -> bool:
+    """For a process that imported this module before transflow was importable (dropin.install() calls it): give
+    the data layers the reference's DataLayer base now.  True if they have it afterwards."""
+    global _REF_DATA_LAYER
+    if _REF_DATA_LAYER is None:
+        ref = _reference_data_layer()
+        if ref is not None:
+            _HipDataLayer.__bases__ = (_HipLayer, ref)
+            _REF_DATA_LAYER = ref
+    return _REF_DATA_LAYER is not None
 
 
 LAYER_CLASSES = {"moveref": HipMoveReferenceLayer, "sum": HipSumLayer, "static": HipStaticLayer,

@@ -73,6 +73,9 @@ def install(flow: bool = True, compositor: bool = True) -> None:
         RefFlowSource.from_args = _flow_from_args(RefFlowSource.from_args)
     if compositor and "compositor" not in _saved:
         from transflow.compositor.compositor import Compositor as RefCompositor
+
+        from .compositor import bind_reference_data_layer
+        bind_reference_data_layer()    # extra/control.py:155 asks isinstance(layer, DataLayer) of checkpointed layers
         _saved["compositor"] = (RefCompositor, RefCompositor.__dict__["from_args"])
         RefCompositor.from_args = _compositor_from_args(RefCompositor.from_args)
 
