@@ -432,6 +432,7 @@ STUCK_THREADS = False
 
 
 def main():
+    global STUCK_THREADS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -503,15 +504,19 @@ def main():
             pixmap_dev = pix_buf.ptr
         except BaseException as err:    # say so loudly and carry on with inputs generated per rank
             if isinstance(err, TimeoutError):
-                global STUCK_THREADS
                 STUCK_THREADS = True
             rccl_error = f"{type(err).__name__}: {err}"
             print(f"[bench] rank {rank}: RCCL leg failed ({rccl_error}); shared inputs generated per rank instead",
                   file=sys.stderr)
             rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
         errs = host.allgather(rccl_error)
-        if any(errs) and rccl is not None:       # all or nothing
-            rccl.close()
+        if any(errs):                             # all or nothing
+            if any("TimeoutError" in e for e in errs if e):
+                STUCK_THREADS = True              # a peer never answered: the communicator is abandoned, not destroyed
+                if rccl is not None:
+                    rccl.abandon()
+            elif rccl is not None:
+                rccl.close()
             rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
         rccl_error = next((e for e in errs if e), None)
     job = Job(wl, args.batch, plan, args.clip_frames, seed=2000, device=local_rank, pixmap=pixmap, reset_mask=reset_mask,

@@ -243,6 +243,10 @@ class RcclGroup:
             self._lib.tf_batch_destroy(self._h)
             self._h = C.c_void_p()
 
+    def abandon(self) -> None:
+        """Forget the communicator without destroying it (a peer never joined: ncclCommDestroy could wait for it)."""
+        self._h = C.c_void_p()
+
     def __del__(self):
         try:
             self.close()
