@@ -46,6 +46,59 @@ constexpr int MAX_POLY_N = 15;
 
 // two floats at 4-byte alignment: one global_load_dwordx2 (the hardware takes unaligned dwordx2)
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// ---------------------------------------------------------------------------------
+// Layout of R, the polynomial coefficients of one image at one level (Nk pixels, 5 Nk floats, OpenCV's channel
+// order): three planes -- (c0, c1) pairs [Nk][2], (c2, c3) pairs [Nk][2], c4 [Nk].  FarnebackUpdateMatrices pairs
+// the channels exactly so ((c0, c1) feed h, (c2, c3) the diagonal of G, c4 its off-diagonal): the two taps of a
+// bilinear row arrive as ONE 16-byte load per channel pair (x1 and x1 + 1 are adjacent pixels), a pixel's own
+// coefficients as two 8-byte loads and a 4-byte one, and the arithmetic runs on register pairs as they were
+// loaded: 10 instead of 16 loads per pixel and no shuffling between loads and packed math.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ size_t r_off23(size_t Nk) { return 2 * Nk; }
+__device__ __forceinline__ size_t r_off4(size_t Nk) { return 4 * Nk; }
+
+__device__ __forceinline__ void r_load_px(const float *__restrict__ R, size_t Nk, size_t o, float v[5])
+{
+    const float2u a = *reinterpret_cast<const float2u *>(R + 2 * o);
+    const float2u b = *reinterpret_cast<const float2u *>(R + r_off23(Nk) + 2 * o);
+    v[0] = a.x;
+    v[1] = a.y;
+    v[2] = b.x;
+    v[3] = b.y;
+    v[4] = R[r_off4(Nk) + o];
+}
+// the taps at pixels q and q + 1 (row y1) and q + Wk, q + Wk + 1 (row y1 + 1): per channel (left, right)
+__device__ __forceinline__ void r_load_taps(const float *__restrict__ R, size_t Nk, size_t q, int Wk, float2u t[5], float2u b[5])
+{
+    const float4u t01 = *reinterpret_cast<const float4u *>(R + 2 * q), b01 = *reinterpret_cast<const float4u *>(R + 2 * (q + Wk));
+    const float4u t23 = *reinterpret_cast<const float4u *>(R + r_off23(Nk) + 2 * q);
+    const float4u b23 = *reinterpret_cast<const float4u *>(R + r_off23(Nk) + 2 * (q + Wk));
+    const float2u t4 = *reinterpret_cast<const float2u *>(R + r_off4(Nk) + q), b4 = *reinterpret_cast<const float2u *>(R + r_off4(Nk) + q + Wk);
+    t[0] = float2u{t01.x, t01.z};
+    t[1] = float2u{t01.y, t01.w};
+    t[2] = float2u{t23.x, t23.z};
+    t[3] = float2u{t23.y, t23.w};
+    t[4] = t4;
+    b[0] = float2u{b01.x, b01.z};
+    b[1] = float2u{b01.y, b01.w};
+    b[2] = float2u{b23.x, b23.z};
+    b[3] = float2u{b23.y, b23.w};
+    b[4] = b4;
+}
+__device__ __forceinline__ void r_store_px(float *__restrict__ R, size_t Nk, size_t o, const float v[5])
+{
+    *reinterpret_cast<float2u *>(R + 2 * o) = float2u{v[0], v[1]};
+    *reinterpret_cast<float2u *>(R + r_off23(Nk) + 2 * o) = float2u{v[2], v[3]};
+    R[r_off4(Nk) + o] = v[4];
+}
+__device__ __forceinline__ void r_store_px2(float *__restrict__ R, size_t Nk, size_t o, const float v0[5], const float v1[5])
+{
+    *reinterpret_cast<float4u *>(R + 2 * o) = float4u{v0[0], v0[1], v1[0], v1[1]};
+    *reinterpret_cast<float4u *>(R + r_off23(Nk) + 2 * o) = float4u{v0[2], v0[3], v1[2], v1[3]};
+    *reinterpret_cast<float2u *>(R + r_off4(Nk) + o) = float2u{v0[4], v1[4]};
+}
 
 #ifndef BLUR_PREFETCH
 #define BLUR_PREFETCH 3 // rows of M kept in flight per wave in the blur march (2: 1219 us, 3: 1177, 4: 1225 at 4K x16)
@@ -732,11 +785,9 @@ __global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, 
             b5 += (T2[k] + T2[-k]) * g0;
         }
         size_t o = (size_t)y * Wk + x;
-        dst[0 * Nk + o] = (float)(b3 * pc.ig11);
-        dst[1 * Nk + o] = (float)(b2 * pc.ig11);
-        dst[2 * Nk + o] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-        dst[3 * Nk + o] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-        dst[4 * Nk + o] = (float)(b6 * pc.ig55);
+        const float v[5] = {(float)(b3 * pc.ig11), (float)(b2 * pc.ig11), (float)(b1 * pc.ig03 + b5 * pc.ig33),
+                            (float)(b1 * pc.ig03 + b4 * pc.ig33), (float)(b6 * pc.ig55)};
+        r_store_px(dst, Nk, o, v);
     }
 }
 
@@ -837,17 +888,10 @@ k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk
             out[q][4] = (float)(b6 * pc.ig55);
         }
         const size_t o = (size_t)y * Wk + x;
-        if (x + 1 < Wk) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                float2w v2 = {out[0][c], out[1][c]};
-                *reinterpret_cast<float2w *>(dst + c * Nk + o) = v2;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 5; c++)
-                dst[c * Nk + o] = out[0][c];
-        }
+        if (x + 1 < Wk)
+            r_store_px2(dst, Nk, o, out[0], out[1]);
+        else
+            r_store_px(dst, Nk, o, out[0]);
     }
 }
 
@@ -917,17 +961,10 @@ __device__ __forceinline__ void tile_expansion(const float *sI, float (*sT)[TH][
             out[q][4] = (float)(b6 * pc.ig55);
         }
         const size_t o = (size_t)y * W + x;
-        if (x + 1 < W) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                float2w v2 = {out[0][c], out[1][c]};
-                *reinterpret_cast<float2w *>(dst + c * Nk + o) = v2;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 5; c++)
-                dst[c * Nk + o] = out[0][c];
-        }
+        if (x + 1 < W)
+            r_store_px2(dst, Nk, o, out[0], out[1]);
+        else
+            r_store_px(dst, Nk, o, out[0]);
     }
 }
 
@@ -1148,12 +1185,14 @@ __device__ __forceinline__ float border_scale(int x, int y, int W, int H)
 }
 
 // ---------------------------------------------------------------------------------
-// A3: one pixel of FarnebackUpdateMatrices.  R0/R1 planar; out[5] = M.
+// A3: one pixel of FarnebackUpdateMatrices.  R0/R1 in the channel-pair layout; out[5] = M.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, const float *__restrict__ R1, size_t Nk,
                                                  int Wk, int Hk, int x, int y, float dx, float dy, float out[5])
 {
     const size_t o = (size_t)y * Wk + x;
+    float r0[5];
+    r_load_px(R0, Nk, o, r0);
     float fx = x + dx, fy = y + dy;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
@@ -1162,35 +1201,24 @@ __device__ __forceinline__ void update_matrix_px(const float *__restrict__ R0, c
     if ((unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1)) {
         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         size_t q = (size_t)y1 * Wk + x1;
-        // the two horizontal neighbours of each row come with one 8-byte load
-        const float *rp = R1 + q;
-        float2u t0, b0, t1, b1, t2, b2, t3, b3, t4, b4;
-        t0 = *reinterpret_cast<const float2u *>(rp);
-        b0 = *reinterpret_cast<const float2u *>(rp + Wk);
-        t1 = *reinterpret_cast<const float2u *>(rp + Nk);
-        b1 = *reinterpret_cast<const float2u *>(rp + Nk + Wk);
-        t2 = *reinterpret_cast<const float2u *>(rp + 2 * Nk);
-        b2 = *reinterpret_cast<const float2u *>(rp + 2 * Nk + Wk);
-        t3 = *reinterpret_cast<const float2u *>(rp + 3 * Nk);
-        b3 = *reinterpret_cast<const float2u *>(rp + 3 * Nk + Wk);
-        t4 = *reinterpret_cast<const float2u *>(rp + 4 * Nk);
-        b4 = *reinterpret_cast<const float2u *>(rp + 4 * Nk + Wk);
-        r2 = a00 * t0.x + a01 * t0.y + a10 * b0.x + a11 * b0.y;
-        r3 = a00 * t1.x + a01 * t1.y + a10 * b1.x + a11 * b1.y;
-        r4 = a00 * t2.x + a01 * t2.y + a10 * b2.x + a11 * b2.y;
-        r5 = a00 * t3.x + a01 * t3.y + a10 * b3.x + a11 * b3.y;
-        r6 = a00 * t4.x + a01 * t4.y + a10 * b4.x + a11 * b4.y;
-        r4 = (R0[2 * Nk + o] + r4) * 0.5f;
-        r5 = (R0[3 * Nk + o] + r5) * 0.5f;
-        r6 = (R0[4 * Nk + o] + r6) * 0.25f;
+        float2u t[5], b[5];
+        r_load_taps(R1, Nk, q, Wk, t, b);
+        r2 = a00 * t[0].x + a01 * t[0].y + a10 * b[0].x + a11 * b[0].y;
+        r3 = a00 * t[1].x + a01 * t[1].y + a10 * b[1].x + a11 * b[1].y;
+        r4 = a00 * t[2].x + a01 * t[2].y + a10 * b[2].x + a11 * b[2].y;
+        r5 = a00 * t[3].x + a01 * t[3].y + a10 * b[3].x + a11 * b[3].y;
+        r6 = a00 * t[4].x + a01 * t[4].y + a10 * b[4].x + a11 * b[4].y;
+        r4 = (r0[2] + r4) * 0.5f;
+        r5 = (r0[3] + r5) * 0.5f;
+        r6 = (r0[4] + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2 * Nk + o];
-        r5 = R0[3 * Nk + o];
-        r6 = R0[4 * Nk + o] * 0.5f;
+        r4 = r0[2];
+        r5 = r0[3];
+        r6 = r0[4] * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[Nk + o] - r3) * 0.5f;
+    r2 = (r0[0] - r2) * 0.5f;
+    r3 = (r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     {
@@ -1244,9 +1272,14 @@ __device__ __forceinline__ void gather_issue(GatherRegs &g, const float *__restr
     const int xs[2] = {xa, xb};
     const float2 fl[2] = {fa, fb};
     const size_t oa = (size_t)y * Wk + xa, ob = (size_t)y * Wk + xb;
+    {
+        float va[5], vb[5];
+        r_load_px(R0, Nk, oa, va);
+        r_load_px(R0, Nk, ob, vb);
 #pragma unroll
-    for (int c = 0; c < 5; c++)
-        g.r0[c] = make_float2(R0[c * Nk + oa], R0[c * Nk + ob]);
+        for (int c = 0; c < 5; c++)
+            g.r0[c] = make_float2(va[c], vb[c]);
+    }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         float dx = fl[j].x, dy = fl[j].y;
@@ -1262,13 +1295,12 @@ __device__ __forceinline__ void gather_issue(GatherRegs &g, const float *__restr
         // out-of-frame taps load from a clamped (valid) address and are discarded: no branch
         // around the loads, so they all stay in flight together
         int x1c = clampi(x1, 0, Wk - 2), y1c = clampi(y1, 0, Hk - 2);
-        const float *rp = R1 + (size_t)y1c * Wk + x1c;
+        float2u tv[5], bv[5];
+        r_load_taps(R1, Nk, (size_t)y1c * Wk + x1c, Wk, tv, bv);
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            float2u tv = *reinterpret_cast<const float2u *>(rp + c * Nk);
-            float2u bv = *reinterpret_cast<const float2u *>(rp + c * Nk + Wk);
-            g.t[j][c] = make_float2(tv.x, tv.y);
-            g.b[j][c] = make_float2(bv.x, bv.y);
+            g.t[j][c] = make_float2(tv[c].x, tv[c].y);
+            g.b[j][c] = make_float2(bv[c].x, bv[c].y);
         }
     }
 }
@@ -1632,18 +1664,24 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
 // k_flow_iter_pc below.  Same statements as update_matrix_px.
 // ---------------------------------------------------------------------------------
 struct Gather1 {
-    float r0[5];
-    float2 t[5], b[5];
+    float2u r0a, r0b;            // R0 at the pixel: (c0, c1), (c2, c3)
+    float r0c;                   // ... and c4
+    float4u t01, t23, b01, b23;  // R1 on rows y1 / y1 + 1: a channel pair at x1 (.xy) and at x1 + 1 (.zw)
+    float2u t4, b4;              // c4 at x1, x1 + 1
     float dx, dy, fx, fy;
     bool inb;
 };
 
-// The wave-uniform plane bases (R0 + c*Nk, R1 + c*Nk) stay in SGPRs and every load is base + one 32-bit
-// byte offset per lane, so the five planes share the lane's address arithmetic.
+// The wave-uniform plane bases stay in SGPRs and every load is base + one 32-bit byte offset per lane: the
+// pair planes share one offset (8 bytes per pixel), the c4 planes another (4 bytes per pixel).
 struct PlaneBases {
-    const float *r0[5];
-    const float *r1[5];
+    const float *r0_01, *r0_23, *r0_4;
+    const float *r1_01, *r1_23, *r1_4;
 };
+__device__ __forceinline__ PlaneBases plane_bases(const float *R0, const float *R1, size_t Nk)
+{
+    return PlaneBases{R0, R0 + r_off23(Nk), R0 + r_off4(Nk), R1, R1 + r_off23(Nk), R1 + r_off4(Nk)};
+}
 
 __device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
 {
@@ -1653,13 +1691,17 @@ __device__ __forceinline__ float2u ld_f32x2(const float *base, unsigned byte_off
 {
     return *reinterpret_cast<const float2u *>(reinterpret_cast<const char *>(base) + byte_off);
 }
+__device__ __forceinline__ float4u ld_f32x4(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float4u *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 
 __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, int Wk, int Hk, int x, int y, float2 fl)
 {
-    const unsigned o = ((unsigned)y * Wk + x) * 4u;
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-        g.r0[c] = ld_f32(pb.r0[c], o);
+    const unsigned o = (unsigned)y * Wk + x;
+    g.r0a = ld_f32x2(pb.r0_01, o * 8u);
+    g.r0b = ld_f32x2(pb.r0_23, o * 8u);
+    g.r0c = ld_f32(pb.r0_4, o * 4u);
     float fx = x + fl.x, fy = y + fl.y;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     g.dx = fl.x;
@@ -1667,39 +1709,33 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
     g.fx = fx - x1;
     g.fy = fy - y1;
     g.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
-    const unsigned ot = ((unsigned)clampi(y1, 0, Hk - 2) * Wk + clampi(x1, 0, Wk - 2)) * 4u, ob = ot + (unsigned)Wk * 4u;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        float2u tv = ld_f32x2(pb.r1[c], ot);
-        float2u bv = ld_f32x2(pb.r1[c], ob);
-        g.t[c] = make_float2(tv.x, tv.y);
-        g.b[c] = make_float2(bv.x, bv.y);
-    }
+    // out-of-frame taps load from a clamped (valid) address and are discarded: no branch around the loads
+    const unsigned qt = (unsigned)clampi(y1, 0, Hk - 2) * Wk + clampi(x1, 0, Wk - 2), qb = qt + (unsigned)Wk;
+    g.t01 = ld_f32x4(pb.r1_01, qt * 8u);
+    g.b01 = ld_f32x4(pb.r1_01, qb * 8u);
+    g.t23 = ld_f32x4(pb.r1_23, qt * 8u);
+    g.b23 = ld_f32x4(pb.r1_23, qb * 8u);
+    g.t4 = ld_f32x2(pb.r1_4, qt * 4u);
+    g.b4 = ld_f32x2(pb.r1_4, qb * 4u);
 }
 
+// update_matrix_px's statements on the channel pairs as they were loaded: per channel the bilinear sum is
+// ((a00 * t(x1) + a01 * t(x1 + 1)) + a10 * b(x1)) + a11 * b(x1 + 1), two channels per packed instruction.
 __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk, int x, int y, float m[5])
 {
     const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
-    float r2, r3, r4, r5, r6;
-    {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        r2 = a00 * g.t[0].x + a01 * g.t[0].y + a10 * g.b[0].x + a11 * g.b[0].y;
-        r3 = a00 * g.t[1].x + a01 * g.t[1].y + a10 * g.b[1].x + a11 * g.b[1].y;
-        r4 = a00 * g.t[2].x + a01 * g.t[2].y + a10 * g.b[2].x + a11 * g.b[2].y;
-        r5 = a00 * g.t[3].x + a01 * g.t[3].y + a10 * g.b[3].x + a11 * g.b[3].y;
-        r6 = a00 * g.t[4].x + a01 * g.t[4].y + a10 * g.b[4].x + a11 * g.b[4].y;
-        r4 = (g.r0[2] + r4) * 0.5f;
-        r5 = (g.r0[3] + r5) * 0.5f;
-        r6 = (g.r0[4] + r6) * 0.25f;
-        const float o6 = g.r0[4] * 0.5f;
-        r2 = g.inb ? r2 : 0.f;
-        r3 = g.inb ? r3 : 0.f;
-        r4 = g.inb ? r4 : g.r0[2];
-        r5 = g.inb ? r5 : g.r0[3];
-        r6 = g.inb ? r6 : o6;
-    }
-    r2 = (g.r0[0] - r2) * 0.5f;
-    r3 = (g.r0[1] - r3) * 0.5f;
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float2u r23 = a00 * g.t01.xy + a01 * g.t01.zw + a10 * g.b01.xy + a11 * g.b01.zw;
+    float2u r45 = a00 * g.t23.xy + a01 * g.t23.zw + a10 * g.b23.xy + a11 * g.b23.zw;
+    float r6 = a00 * g.t4.x + a01 * g.t4.y + a10 * g.b4.x + a11 * g.b4.y;
+    r45 = (g.r0b + r45) * 0.5f;
+    r6 = (g.r0c + r6) * 0.25f;
+    const float o6 = g.r0c * 0.5f;
+    r23 = g.inb ? r23 : float2u{0.f, 0.f};
+    r45 = g.inb ? r45 : g.r0b;
+    r6 = g.inb ? r6 : o6;
+    r23 = (g.r0a - r23) * 0.5f;
+    float r2 = r23.x, r3 = r23.y, r4 = r45.x, r5 = r45.y;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     {
@@ -1759,13 +1795,8 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     if (wave < 2) {
         const int col = wave * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
-        PlaneBases pb;
         const int2 im = pair_images(fi, pair);
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            pb.r0[c] = R + (size_t)im.x * 5 * Nk + (size_t)c * Nk;
-            pb.r1[c] = R + (size_t)im.y * 5 * Nk + (size_t)c * Nk;
-        }
+        const PlaneBases pb = plane_bases(R + (size_t)im.x * 5 * Nk, R + (size_t)im.y * 5 * Nk, Nk);
         const float2 *fin = FLOW == 1 ? flow_in + (size_t)pair * Nk : nullptr;
         const float2 *coarse = FLOW == 2 ? fi.src + (size_t)pair * fi.Wc * fi.Hc : nullptr;
         int up_sx = 0, up_sx1 = 0;
@@ -2108,6 +2139,25 @@ __global__ void k_interleaved_to_planar5(const float *__restrict__ src, float *_
         return;
     for (int c = 0; c < 5; c++)
         dst[c * n + t] = src[t * 5 + c];
+}
+
+// host [n][5] interleaved <-> the channel-pair layout of R
+__global__ void k_interleaved_to_rpairs(const float *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        r_store_px(dst, n, i, src + i * 5);
+}
+__global__ void k_rpairs_to_interleaved(const float *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float v[5];
+        r_load_px(src, n, i, v);
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            dst[i * 5 + c] = v[c];
+    }
 }
 
 __global__ void k_planar5_to_interleaved(const float *__restrict__ src, float *__restrict__ dst, size_t n)
@@ -3203,7 +3253,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
-        const bool fused_here = fusable && !fb->gaussian() && L.W >= 10 && L.H >= 10 &&
+        const bool fused_here = fusable && !fb->gaussian() && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;
@@ -3455,6 +3505,22 @@ static int upload_planar5(float *dst_planar, const float *host_interleaved, size
                   (const float *)staging.as<float>(), dst_planar, n);
 }
 
+static int upload_rpairs(float *dst_r, const float *host_interleaved, size_t n, DevBuf &staging)
+{
+    TF_HIP(hipMemcpyAsync(staging.p, host_interleaved, n * 20, hipMemcpyHostToDevice, stream()));
+    return launch("stage_to_rpairs", k_interleaved_to_rpairs, dim3(cdiv(n, 256)), dim3(256), 0,
+                  (const float *)staging.as<float>(), dst_r, n);
+}
+
+static int download_rpairs(float *host_interleaved, const float *src_r, size_t n, DevBuf &staging)
+{
+    TF_TRY(launch("stage_from_rpairs", k_rpairs_to_interleaved, dim3(cdiv(n, 256)), dim3(256), 0, src_r,
+                  staging.as<float>(), n));
+    TF_HIP(hipMemcpyAsync(host_interleaved, staging.p, n * 20, hipMemcpyDeviceToHost, stream()));
+    TF_HIP(hipStreamSynchronize(stream()));
+    return TF_OK;
+}
+
 static int download_planar5(float *host_interleaved, const float *src_planar, size_t n, DevBuf &staging)
 {
     TF_TRY(launch("stage_to_interleaved", k_planar5_to_interleaved, dim3(cdiv(n, 256)), dim3(256), 0, src_planar,
@@ -3480,7 +3546,7 @@ TF_API int tf_fb_stage_level_polyexp(tf_fb *fb, const uint8_t *grey, ptrdiff_t s
         TF_TRY(fb_level_image(fb, level, 2, true));
         TF_TRY(fb_polyexp(fb, L.W, L.H, 2, level));
     }
-    return download_planar5(r_out, fb->Rk(level), (size_t)L.W * L.H, fb->scratch);
+    return download_rpairs(r_out, fb->Rk(level), (size_t)L.W * L.H, fb->scratch);
 }
 
 TF_API int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float *r_out)
@@ -3491,7 +3557,7 @@ TF_API int tf_fb_stage_polyexp(tf_fb *fb, const float *img, int w, int h, float 
     size_t n = (size_t)w * h;
     TF_HIP(hipMemcpyAsync(fb->img.p, img, n * 4, hipMemcpyHostToDevice, stream()));
     TF_TRY(fb_polyexp(fb, w, h, 1));
-    return download_planar5(r_out, fb->Rk(0), n, fb->scratch);
+    return download_rpairs(r_out, fb->Rk(0), n, fb->scratch);
 }
 
 TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *r1, const float *flow, int w, int h,
@@ -3501,9 +3567,9 @@ TF_API int tf_fb_stage_update_matrices(tf_fb *fb, const float *r0, const float *
     TF_TRY(check_stage_size(fb, w, h));
     TF_TRY(ensure_init());
     size_t n = (size_t)w * h;
-    TF_TRY(upload_planar5(fb->Rk(0), r0, n, fb->scratch));
+    TF_TRY(upload_rpairs(fb->Rk(0), r0, n, fb->scratch));
     TF_HIP(hipStreamSynchronize(stream()));
-    TF_TRY(upload_planar5(fb->Rk(0) + 5 * n, r1, n, fb->scratch));
+    TF_TRY(upload_rpairs(fb->Rk(0) + 5 * n, r1, n, fb->scratch));
     TF_HIP(hipMemcpyAsync(fb->lflow[0].p, flow, n * 8, hipMemcpyHostToDevice, stream()));
     FlowInit fi;
     memset(&fi, 0, sizeof(fi));
@@ -3525,9 +3591,9 @@ TF_API int tf_fb_stage_upsampled_matrices(tf_fb *fb, int level, const float *r0,
     Level &L = *fb->lv[level];
     Level &C = *fb->lv[level + 1];
     const size_t n = (size_t)L.W * L.H, nc = (size_t)C.W * C.H;
-    TF_TRY(upload_planar5(fb->Rk(0), r0, n, fb->scratch));
+    TF_TRY(upload_rpairs(fb->Rk(0), r0, n, fb->scratch));
     TF_HIP(hipStreamSynchronize(stream()));
-    TF_TRY(upload_planar5(fb->Rk(0) + 5 * n, r1, n, fb->scratch));
+    TF_TRY(upload_rpairs(fb->Rk(0) + 5 * n, r1, n, fb->scratch));
     TF_HIP(hipMemcpyAsync(fb->lflow[1].p, coarse_flow, nc * 8, hipMemcpyHostToDevice, stream()));
     FlowInit fi;
     memset(&fi, 0, sizeof(fi));
