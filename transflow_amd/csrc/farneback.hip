@@ -1721,7 +1721,12 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
 
 // update_matrix_px's statements on the channel pairs as they were loaded: per channel the bilinear sum is
 // ((a00 * t(x1) + a01 * t(x1 + 1)) + a10 * b(x1)) + a11 * b(x1 + 1), two channels per packed instruction.
-__device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk, int x, int y, float m[5])
+// wx, wy: the edge weights of the column and of the row.  FarnebackUpdateMatrices multiplies border[x] (x < 5),
+// border[W-1-x] (x >= W-5), border[y], border[H-1-y]; from 10 x 10 up at most one factor per direction differs
+// from 1 (and a factor of exactly 1 changes nothing), so the product is border(min(x, W-1-x)) * border(min(y,
+// H-1-y)), the column's factor first as in the original: bit-identical, with the column's half a constant of the
+// march and the row's half wave-uniform.
+__device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float wy, float m[5])
 {
     const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -1739,7 +1744,7 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, int Wk, int Hk,
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     {
-        float scale = border_weight(x) * border_weight(Wk - x - 1) * border_weight(y) * border_weight(Hk - y - 1);
+        const float scale = wx * wy;
         r2 *= scale;
         r3 *= scale;
         r4 *= scale;
@@ -1773,10 +1778,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                int Hk, double scale, int seg, FlowInit fi)
 {
     static_assert(M & 1, "the pair-sum window needs an odd half-width");
-#ifndef TF_PC_PF
-#define TF_PC_PF 1 // rows of loads in flight per producer: 1 measured best (2: +3 %, 3: +11 %, 4: +4 % time)
-#endif
-    constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1, PF = TF_PC_PF;
+    constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
     __shared__ double s_p[5][64];         // the consumer's pair sums
@@ -1808,10 +1810,9 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             up_edge = up_sx >= fi.Wc - 1; // resize.cpp: dx >= xmax copies S[sx]
             up_sx1 = min(up_sx + 1, fi.Wc - 1);
         }
-        auto load_flow = [&](int row) {
+        auto load_flow = [&](int row) { // row: already clamped to the level
             if (FLOW == 0)
                 return make_float2(0.f, 0.f);
-            row = clampi(row, 0, Hk - 1);
             if (FLOW == 1) {
                 const unsigned off = ((unsigned)row * Wk + x) * 8u;
                 return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
@@ -1831,40 +1832,37 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             const float b0 = 1.f - fy;
             return make_float2((h0.x * b0 + h1.x * fy) * fi.mul, (h0.y * b0 + h1.y * fy) * fi.mul);
         };
-        Gather1 G[PF];
-#pragma unroll
-        for (int t = 0; t < PF; t++) {
-            const int row = clampi(r0 - M + t, 0, Hk - 1);
-            gather1_issue(G[t], pb, Wk, Hk, x, row, load_flow(row));
-        }
-        float2 F = load_flow(r0 - M + PF);
+        // One row of gathers in flight: those of row e + 1 are issued while row e is finished (two or more
+        // rows ahead were measured slower).  The three clamped rows a step works with (the one being finished,
+        // the one whose gathers are issued, the one whose flow is loaded) move along by one: one clamp per step.
+        const float wx = border_weight(min(x, Wk - 1 - x));
+        Gather1 G;
+        int y_fin = clampi(r0 - M, 0, Hk - 1), y_iss = clampi(r0 - M + 1, 0, Hk - 1);
+        gather1_issue(G, pb, Wk, Hk, x, y_fin, load_flow(y_fin));
+        float2 F = load_flow(y_iss);
         double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
-        for (int sb = 0; sb < nsteps; sb += PF) {
+        for (int s = 0; s < nsteps; s++) {
+            if (s < n_rows) {
+                float m[5];
+                gather1_finish(G, wx, border_weight(min(y_fin, Hk - 1 - y_fin)), m);
+                gather1_issue(G, pb, Wk, Hk, x, y_iss, F);
+                const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
+                F = load_flow(y_flow);
+                y_fin = y_iss;
+                y_iss = y_flow;
+                // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
+                // only this lane ever touches its column of the ring
 #pragma unroll
-            for (int h = 0; h < PF; h++) {
-                const int s = sb + h;
-                if (s >= nsteps)
-                    break;
-                if (s < n_rows) {
-                    const int e = r0 - M + s;
-                    float m[5];
-                    gather1_finish(G[h], Wk, Hk, x, clampi(e, 0, Hk - 1), m);
-                    gather1_issue(G[h], pb, Wk, Hk, x, clampi(e + PF, 0, Hk - 1), F);
-                    F = load_flow(e + PF + 1);
-                    // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
-                    // only this lane ever touches its column of the ring
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        const float old = ring[slot][c][col];
-                        ring[slot][c][col] = m[c];
-                        vs[c] += (double)m[c] - (double)old;
-                        s_v[s & 1][c][col] = vs[c];
-                    }
-                    slot = slot + 1 == WIN ? 0 : slot + 1;
+                for (int c = 0; c < 5; c++) {
+                    const float old = ring[slot][c][col];
+                    ring[slot][c][col] = m[c];
+                    vs[c] += (double)m[c] - (double)old;
+                    s_v[s & 1][c][col] = vs[c];
                 }
-                lds_barrier();
+                slot = slot + 1 == WIN ? 0 : slot + 1;
             }
+            lds_barrier();
         }
     } else {
         const int c0 = (int)bx * OUTC - HALO + 2 * lane;
