@@ -1702,15 +1702,18 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
     g.r0a = ld_f32x2(pb.r0_01, o * 8u);
     g.r0b = ld_f32x2(pb.r0_23, o * 8u);
     g.r0c = ld_f32(pb.r0_4, o * 4u);
-    float fx = x + fl.x, fy = y + fl.y;
-    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    const float fx = x + fl.x, fy = y + fl.y;
+    const float flx = floorf(fx), fly = floorf(fy); // (float)(int)floor(f) == floor(f) wherever the int exists
+    const int x1 = (int)flx, y1 = (int)fly;
     g.dx = fl.x;
     g.dy = fl.y;
-    g.fx = fx - x1;
-    g.fy = fy - y1;
+    g.fx = fx - flx;
+    g.fy = fy - fly;
     g.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
     // out-of-frame taps load from a clamped (valid) address and are discarded: no branch around the loads
-    const unsigned qt = (unsigned)clampi(y1, 0, Hk - 2) * Wk + clampi(x1, 0, Wk - 2), qb = qt + (unsigned)Wk;
+    // (rows and widths are far below 2^24: the 24-bit multiply-add is exact and a single full-rate instruction)
+    const unsigned qt = __umul24((unsigned)clampi(y1, 0, Hk - 2), (unsigned)Wk) + (unsigned)clampi(x1, 0, Wk - 2);
+    const unsigned qb = qt + (unsigned)Wk;
     g.t01 = ld_f32x4(pb.r1_01, qt * 8u);
     g.b01 = ld_f32x4(pb.r1_01, qb * 8u);
     g.t23 = ld_f32x4(pb.r1_23, qt * 8u);
@@ -3251,7 +3254,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
-        const bool fused_here = fusable && !fb->gaussian() && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) &&
+        const bool fused_here = fusable && !fb->gaussian() && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;
