@@ -143,13 +143,13 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-// 1/d for a positive, normal double: hardware estimate, two Newton steps and the residual correction --
-// the compiler's own IEEE division sequence for a numerator of 1 without its scaling and fix-up of
-// denormal / infinite operands (~25 instructions), which determinants that carry +1e-3 never are.
+// 1/d for a positive, normal double: the hardware estimate (good to 2^-26 or better) and two Newton steps, each of
+// which squares the error: 2^-52 after the first, rounding-limited after the second -- a relative error of a few
+// 1e-16 in a quantity the path needs to 1e-4.  (The compiler's IEEE division adds a residual correction and the
+// scaling / fix-up of denormal and infinite operands, ~25 instructions; determinants that carry +1e-3 are never those.)
 __device__ __forceinline__ double fast_recip(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
@@ -1870,6 +1870,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     } else {
         const int c0 = (int)bx * OUTC - HALO + 2 * lane;
         const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
+        const double eps = 1e-3 / (scale * scale);
         for (int s = 0; s < nsteps; s++) {
             const int y = r0 + (s - 1) - 2 * M; // the row whose window the producers completed in step s - 1
             if (y >= r0) {                      // wave-uniform
@@ -1888,11 +1889,13 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 #pragma unroll
                         for (int j = -hh + 1; j <= hh; j++)
                             common += s_p[c][lane + j];
-                        g0[c] = (sv[c][2 * (lane - kk) + 1] + common) * scale;
-                        g1[c] = (common + sv[c][2 * (lane + kk)]) * scale;
+                        g0[c] = sv[c][2 * (lane - kk) + 1] + common;
+                        g1[c] = common + sv[c][2 * (lane + kk)];
                     }
-                    const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + 1e-3);
-                    const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + 1e-3);
+                    // the solve on the unscaled sums G = g / scale: g0 g2 - g1^2 + 1e-3 = scale^2 (G0 G2 - G1^2 +
+                    // 1e-3 / scale^2) and the flow's scale^2 cancels -- ten multiplies less, the same value to 1e-16
+                    const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + eps);
+                    const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + eps);
                     float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
                     o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
                                        (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
