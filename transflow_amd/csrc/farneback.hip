@@ -1813,27 +1813,43 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             up_edge = up_sx >= fi.Wc - 1; // resize.cpp: dx >= xmax copies S[sx]
             up_sx1 = min(up_sx + 1, fi.Wc - 1);
         }
+        // The flow of a row arrives in two halves: the loads (issued a step ahead, behind that step's gathers) and,
+        // for A5 on the fly, the two lerps -- done at the top of the NEXT step, when the four coarse values have
+        // had a whole step to arrive (done at once they would be waited for in the step that issued them).
+        struct FlowRaw {
+            float2 a, b, d, e; // FLOW == 2: the coarse flow at (sx, sy0), (sx + 1, sy0), (sx, sy1), (sx + 1, sy1); else a = the flow
+            float fy;
+        };
         auto load_flow = [&](int row) { // row: already clamped to the level
-            if (FLOW == 0)
-                return make_float2(0.f, 0.f);
+            FlowRaw r;
+            r.a = r.b = r.d = r.e = make_float2(0.f, 0.f);
+            r.fy = 0.f;
             if (FLOW == 1) {
                 const unsigned off = ((unsigned)row * Wk + x) * 8u;
-                return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
+                r.a = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
+            } else if (FLOW == 2) {
+                const int sy = fi.yofs[row];
+                r.fy = fi.yfrac[row];
+                const int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
+                r.a = coarse[sy0 * fi.Wc + up_sx];
+                r.b = coarse[sy0 * fi.Wc + up_sx1];
+                r.d = coarse[sy1 * fi.Wc + up_sx];
+                r.e = coarse[sy1 * fi.Wc + up_sx1];
             }
-            const int sy = fi.yofs[row];
-            const float fy = fi.yfrac[row];
-            const int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
-            const float2 a = coarse[sy0 * fi.Wc + up_sx], b = coarse[sy0 * fi.Wc + up_sx1];
-            const float2 d = coarse[sy1 * fi.Wc + up_sx], e2 = coarse[sy1 * fi.Wc + up_sx1];
+            return r;
+        };
+        auto flow_of = [&](const FlowRaw &r) {
+            if (FLOW != 2)
+                return r.a;
             const float a0 = 1.f - up_fx;
-            float2 h0 = make_float2(a.x * a0 + b.x * up_fx, a.y * a0 + b.y * up_fx);
-            float2 h1 = make_float2(d.x * a0 + e2.x * up_fx, d.y * a0 + e2.y * up_fx);
+            float2 h0 = make_float2(r.a.x * a0 + r.b.x * up_fx, r.a.y * a0 + r.b.y * up_fx);
+            float2 h1 = make_float2(r.d.x * a0 + r.e.x * up_fx, r.d.y * a0 + r.e.y * up_fx);
             if (up_edge) {
-                h0 = a;
-                h1 = d;
+                h0 = r.a;
+                h1 = r.d;
             }
-            const float b0 = 1.f - fy;
-            return make_float2((h0.x * b0 + h1.x * fy) * fi.mul, (h0.y * b0 + h1.y * fy) * fi.mul);
+            const float b0 = 1.f - r.fy;
+            return make_float2((h0.x * b0 + h1.x * r.fy) * fi.mul, (h0.y * b0 + h1.y * r.fy) * fi.mul);
         };
         // One row of gathers in flight: those of row e + 1 are issued while row e is finished (two or more
         // rows ahead were measured slower).  The three clamped rows a step works with (the one being finished,
@@ -1841,15 +1857,15 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const float wx = border_weight(min(x, Wk - 1 - x));
         Gather1 G;
         int y_fin = clampi(r0 - M, 0, Hk - 1), y_iss = clampi(r0 - M + 1, 0, Hk - 1);
-        gather1_issue(G, pb, Wk, Hk, x, y_fin, load_flow(y_fin));
-        float2 F = load_flow(y_iss);
+        gather1_issue(G, pb, Wk, Hk, x, y_fin, flow_of(load_flow(y_fin)));
+        FlowRaw F = load_flow(y_iss);
         double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
         for (int s = 0; s < nsteps; s++) {
             if (s < n_rows) {
                 float m[5];
                 gather1_finish(G, wx, border_weight(min(y_fin, Hk - 1 - y_fin)), m);
-                gather1_issue(G, pb, Wk, Hk, x, y_iss, F);
+                gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
                 const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
                 F = load_flow(y_flow);
                 y_fin = y_iss;
