@@ -438,7 +438,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=16, help="frame pairs per pass (per GPU)")
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs per pass (per GPU); 32 = a rank's whole shard of the clip at 8 GPUs")
     ap.add_argument("--clip-frames", type=int, default=256, help="T: frames of the clip that is sharded over the ranks")
     ap.add_argument("--size", default=None, help="WxH: run the chosen workload's configuration at another frame size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
