@@ -648,68 +648,57 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
     }
 }
 
-// tile of CP_TX x THo outputs; LDS holds the rows of the row-pass plane their column sums touch
-constexpr int CP_TX = 32;
-
 __global__ void __launch_bounds__(256)
 k_level_colpass(const float *__restrict__ rowf, float *__restrict__ img, int W, int H, int Wk, int Hk, int NC,
                 const float *__restrict__ kern, int ksz, const int *__restrict__ xofs, const float *__restrict__ xfrac,
-                const int *__restrict__ yofs, const float *__restrict__ yfrac, int THo, int LH)
+                const int *__restrict__ yofs, const float *__restrict__ yfrac)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_cp[];
-    constexpr int ST = 2 * CP_TX;
-    float *sR = reinterpret_cast<float *>(s_cp);          // [LH][ST]
-    float *sK = sR + (size_t)LH * ST;                     // [ksz]
+    // One thread per level pixel, straight from the row-pass plane (round 2; the LDS-tiled form spent its time on
+    // LDS reads, one per multiply-add): a pixel's two source columns sit side by side in the plane (one 8-byte
+    // load per row, consecutive lanes consecutive pairs) and its two source rows sy, sy + 1 are one row apart, so
+    // the taps of the second are the first's shifted by one: tap i of row sy needs rows sy + i and sy - i, tap i
+    // of row sy + 1 needs sy + i + 1 and sy - i + 1 -- the upper one is loaded for the next tap of row sy anyway,
+    // the lower one was the previous tap's.  Two loads and six packed operations per tap; the statements and
+    // their order are k_level_image's (centre first, then pairs outwards; both lerps).
+    extern __shared__ float s_taps[]; // [ksz]
     const int r = ksz >> 1;
-    const int pi = blockIdx.z;
-    const int dx0 = blockIdx.x * CP_TX, dy0 = blockIdx.y * THo;
-    const int ndx = min(CP_TX, Wk - dx0), ndy = min(THo, Hk - dy0);
     for (int i = threadIdx.x; i < ksz; i += 256)
-        sK[i] = kern[i];
-    const int y_lo = clampi(yofs[dy0], 0, H - 1) - r, y_hi = clampi(yofs[dy0 + ndy - 1] + 1, 0, H - 1) + r;
-    const int nrows = y_hi - y_lo + 1;
-    const float *plane = rowf + (size_t)pi * H * NC + 2 * dx0;
-    for (int idx = threadIdx.x; idx < nrows * ndx; idx += 256) {
-        const int j = idx / ndx, c = idx - j * ndx;
-        const float2 v = *reinterpret_cast<const float2 *>(plane + (size_t)reflect101(y_lo + j, H) * NC + 2 * c);
-        *reinterpret_cast<float2 *>(sR + j * ST + 2 * c) = v;
-    }
+        s_taps[i] = kern[i];
     __syncthreads();
-    const float kc = sK[r];
-    float *dst = img + (size_t)pi * Wk * Hk;
-    for (int idx = threadIdx.x; idx < ndy * CP_TX; idx += 256) {
-        const int ty = idx / CP_TX, tx = idx - ty * CP_TX;
-        if (tx >= ndx)
-            continue;
-        const int dx = dx0 + tx, dy = dy0 + ty;
-        const int sy = yofs[dy];
-        const int row0 = clampi(sy, 0, H - 1) - y_lo, row1 = clampi(sy + 1, 0, H - 1) - y_lo;
-        const float *c0 = sR + row0 * ST + 2 * tx, *c1 = sR + row1 * ST + 2 * tx;
-        float v00 = kc * c0[0], v01 = kc * c0[1];
-        for (int i = 1; i <= r; i++) {
-            v00 += sK[r + i] * (c0[i * ST] + c0[-i * ST]);
-            v01 += sK[r + i] * (c0[i * ST + 1] + c0[-i * ST + 1]);
-        }
-        float v10 = v00, v11 = v01;
-        if (row1 != row0) {
-            v10 = kc * c1[0];
-            v11 = kc * c1[1];
-            for (int i = 1; i <= r; i++) {
-                v10 += sK[r + i] * (c1[i * ST] + c1[-i * ST]);
-                v11 += sK[r + i] * (c1[i * ST + 1] + c1[-i * ST + 1]);
-            }
-        }
-        const float fx = xfrac[dx], fy = yfrac[dy];
-        float h0, h1;
-        if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
-            h0 = v00;
-            h1 = v10;
-        } else {
-            h0 = v00 * (1.f - fx) + v01 * fx;
-            h1 = v10 * (1.f - fx) + v11 * fx;
-        }
-        dst[(size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
+    const int pi = blockIdx.z;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= Wk || dy >= Hk)
+        return;
+    const float *plane = rowf + (size_t)pi * H * NC + 2 * dx;
+    auto row = [&](int y) { return *reinterpret_cast<const float2u *>(plane + (size_t)reflect101(y, H) * NC); };
+    const int sy = yofs[dy];
+    const int row0 = clampi(sy, 0, H - 1), row1 = clampi(sy + 1, 0, H - 1);
+    const float kc = s_taps[r];
+    const float2u c0 = row(row0);
+    float2u up = row(row0 + 1);   // U[1]
+    float2u down_prev = c0;       // D[0]
+    float2u v0 = kc * c0, v1 = kc * up; // row1 == row0 + 1 wherever v1 is used: its centre is U[1]
+    for (int i = 1; i <= r; i++) {
+        const float k = s_taps[r + i];
+        const float2u down = row(row0 - i);     // D[i]
+        const float2u up_next = row(row0 + i + 1); // U[i + 1]
+        v0 += k * (up + down);
+        v1 += k * (up_next + down_prev);
+        up = up_next;
+        down_prev = down;
     }
+    if (row1 == row0) // both source rows clamp to the same frame row (above the first / below the last)
+        v1 = v0;
+    const float fx = xfrac[dx], fy = yfrac[dy];
+    float h0, h1;
+    if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+        h0 = v0.x;
+        h1 = v1.x;
+    } else {
+        h0 = v0.x * (1.f - fx) + v0.y * fx;
+        h1 = v1.x * (1.f - fx) + v1.y * fx;
+    }
+    img[(size_t)pi * Wk * Hk + (size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2353,7 +2342,7 @@ struct Level {
     // long blur kernels: row pass over whole frame rows, then column pass + lerps (k_level_rowpass / _colpass)
     bool split = false;
     DevBuf colsrc;          // source column of each of the NC = 2*W row-pass columns
-    int NC = 0, rp_rshift = 0, cp_THo = 0, cp_LH = 0;
+    int NC = 0, rp_rshift = 0;
     size_t rowf_off = 0;    // this level's plane inside tf_fb::rowf (floats)
     LerpDev flow_lerp; // level k+1 -> this level
 };
@@ -2467,13 +2456,11 @@ static int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone = fals
                           fb->image_list(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
                           fb->rp_rmax));
         }
-        const size_t smem_cp = ((size_t)L.cp_LH * 2 * CP_TX + L.ksz) * sizeof(float);
-        return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, CP_TX), cdiv(L.H, L.cp_THo), n_images),
-                      dim3(256), smem_cp, (const float *)(fb->rowf.as<float>() + L.rowf_off), fb->imgk(k), fb->W, fb->H, L.W,
-                      L.H, L.NC,
-                      (const float *)L.kern.as<float>(), L.ksz, (const int *)L.img_lerp.xofs.as<int>(),
+        return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, 64), cdiv(L.H, 4), n_images), dim3(256),
+                      (size_t)L.ksz * sizeof(float), (const float *)(fb->rowf.as<float>() + L.rowf_off), fb->imgk(k), fb->W, fb->H,
+                      L.W, L.H, L.NC, (const float *)L.kern.as<float>(), L.ksz, (const int *)L.img_lerp.xofs.as<int>(),
                       (const float *)L.img_lerp.xfrac.as<float>(), (const int *)L.img_lerp.yofs.as<int>(),
-                      (const float *)L.img_lerp.yfrac.as<float>(), L.cp_THo, L.cp_LH);
+                      (const float *)L.img_lerp.yfrac.as<float>());
     }
     const ImgTile &t = L.tile;
     dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_images);
@@ -2495,7 +2482,6 @@ static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
     std::vector<float> fr;
     make_lerp(W, L.W, true, xo, fr);
     make_lerp(H, L.H, false, yo, fr);
-    const int r = L.ksz / 2;
     L.NC = 2 * L.W;
     colsrc.resize((size_t)L.NC);
     for (int x = 0; x < L.W; x++) {
@@ -2508,28 +2494,6 @@ static bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
     while ((1 << rshift) < std::min(8, std::max(2, s_ / 2)))
         rshift++;
     L.rp_rshift = rshift;
-    // column pass: CP_TX x THo outputs, rows of the plane in LDS.  Small tiles win (measured at 4K x 16:
-    // 16 / 24 / 32 / 40 / 56 KB of LDS -> 100 / 117 / 123 / 144 / 235 us at level 3): as many output rows
-    // as fit ~20 KB, a single one where even that does not fit
-    static const size_t cp_cap = (size_t)tune("TF_CP_LDS_KB", 20) * 1024;
-    int best = 0, best_lh = 0;
-    for (int tho = 1; tho <= 32; tho++) {
-        int worst = 0;
-        for (int d0 = 0; d0 < L.H; d0 += tho) {
-            const int d1 = std::min(L.H, d0 + tho) - 1;
-            const int lo = std::max(0, std::min(yo[d0], H - 1)) - r, hi = std::max(0, std::min(yo[d1] + 1, H - 1)) + r;
-            worst = std::max(worst, hi - lo + 1);
-        }
-        const size_t bytes = ((size_t)worst * 2 * CP_TX + L.ksz) * sizeof(float);
-        if (bytes <= cp_cap || (tho == 1 && bytes <= 56 * 1024)) {
-            best = tho;
-            best_lh = worst;
-        }
-    }
-    if (!best)
-        return false;
-    L.cp_THo = best;
-    L.cp_LH = best_lh;
     return true;
 }
 
