@@ -1751,21 +1751,25 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float
 }
 
 // ---------------------------------------------------------------------------------
-// A3+A4 fused, roles split inside the workgroup (the default on large levels).  Three waves march a strip
+// A3+A4 fused, roles split inside the workgroup (the default on large levels).  Four waves march a strip
 // of 128 columns together: waves 0-1 are PRODUCERS (one column per lane: they compute row e of M
 // from R0, R1 and the flow -- gather1_issue / gather1_finish, the next row's loads in flight --, keep the window's
 // 2M+1 rows of their column in an LDS ring, slide the vertical window sum over it in double and
-// publish that sum), wave 2 is the CONSUMER (two columns per lane: it adds the sums across columns
-// -- pair sums through LDS, as k_blur_solve_wave --, solves and writes the flow).  One workgroup
-// barrier per row: in step s the producers publish row s while the consumer works on the sums of
-// step s-1 (double-buffered).  M is never stored: the window costs 38 KB of LDS per 112 output
-// columns, 50 KB per workgroup, 3 workgroups = 9 waves per CU.
+// publish that sum), waves 2-3 are CONSUMERS taking turns by row (two columns per lane: a consumer adds
+// the sums across columns -- pair sums through LDS, as k_blur_solve_wave --, solves and writes the
+// flow; it copies what it needs of a row's sums out of s_v before the step's barrier and then has two
+// steps for the rest, so the producers set the pace).  One workgroup barrier per row, sums double-buffered
+// by step parity.  M is never stored: the window costs 38 KB of LDS per 112 output columns, 53.8 KB
+// per workgroup, 3 workgroups = 12 waves per CU.
 // ---------------------------------------------------------------------------------
 // FLOW: where the iteration's input flow comes from -- 0: zero (coarsest scale), 1: flow_in, 2: A5 on the
 // fly, resize(coarser flow, INTER_LINEAR) * 1/pyr_scale through `fi` (the statements of k_flow_upsample;
 // the column's table entries are loaded once per lane, the row's are the same address for all lanes).
+#ifndef TF_PC_CONS
+#define TF_PC_CONS 2 // consumer waves per workgroup: they take turns by row (1: 1701, 2: 1723 frames/s at 4K x 32)
+#endif
 template <int M, int FLOW>
-__global__ void __launch_bounds__(192)
+__global__ void __launch_bounds__(128 + 64 * TF_PC_CONS)
 k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
                int Hk, double scale, int seg, FlowInit fi)
 {
@@ -1773,7 +1777,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
-    __shared__ double s_p[5][64];         // the consumer's pair sums
+    __shared__ double s_p[TF_PC_CONS][5][64]; // each consumer's pair sums
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
     xcd_tile(bx, by);
@@ -1783,7 +1787,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     // step s: producers make entering row e = r0 - M + s (s < n_rows) and its window sums; the consumer
     // turns the sums of step s - 1 into the flow of row r0 + (s - 1) - 2M
     const int n_rows = (r1 - r0) + 2 * M, nsteps = n_rows + 1;
-    for (int i = threadIdx.x; i < WIN * 5 * 128; i += 192)
+    for (int i = threadIdx.x; i < WIN * 5 * 128; i += 128 + 64 * TF_PC_CONS)
         (&ring[0][0][0])[i] = 0.f; // rows "above" the first window count as zero: the warm-up subtracts them
     __syncthreads();
     if (wave < 2) {
@@ -1873,32 +1877,48 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             lds_barrier();
         }
     } else {
+        // The consumers take turns: wave 2 + k serves the steps with s % TF_PC_CONS == k.  In its step a consumer first
+        // copies what it needs of the row's sums out of s_v (its two columns and one single column at each end of
+        // the window) -- that much must be done before the step's barrier, after which the producers overwrite the
+        // buffer -- and then has until its next turn for the exchange of pair sums, the solve and the store.
+        const int who = wave - 2;
+        double(*sp)[64] = s_p[who];
         const int c0 = (int)bx * OUTC - HALO + 2 * lane;
         const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
         const double eps = 1e-3 / (scale * scale);
+        constexpr int hh = (M - 1) / 2, kk = (M + 1) / 2;
+        const int lo = max(lane - kk, 0), hi = min(lane + kk, 63);
         for (int s = 0; s < nsteps; s++) {
             const int y = r0 + (s - 1) - 2 * M; // the row whose window the producers completed in step s - 1
-            if (y >= r0) {                      // wave-uniform
+            const bool mine = (s % TF_PC_CONS) == who && y >= r0; // wave-uniform
+            double a[5], bb[5], left[5], right[5];
+            if (mine) {
                 const double(*sv)[128] = s_v[(s - 1) & 1];
 #pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    a[c] = sv[c][2 * lane];
+                    bb[c] = sv[c][2 * lane + 1];
+                    left[c] = sv[c][2 * lo + 1];
+                    right[c] = sv[c][2 * hi];
+                }
+            }
+            lds_barrier();
+            if (mine) {
+#pragma unroll
                 for (int c = 0; c < 5; c++)
-                    s_p[c][lane] = sv[c][2 * lane] + sv[c][2 * lane + 1];
-                lds_wave_sync(); // one wave writes and reads s_p: no workgroup barrier
+                    sp[c][lane] = a[c] + bb[c];
+                lds_wave_sync();
                 if (is_out) {
                     double g0[5], g1[5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        // windows of columns 2l and 2l+1 as M whole pairs plus one single column at each end
-                        constexpr int hh = (M - 1) / 2, kk = (M + 1) / 2;
-                        double common = s_p[c][lane - hh];
+                        double common = sp[c][lane - hh];
 #pragma unroll
                         for (int j = -hh + 1; j <= hh; j++)
-                            common += s_p[c][lane + j];
-                        g0[c] = sv[c][2 * (lane - kk) + 1] + common;
-                        g1[c] = common + sv[c][2 * (lane + kk)];
+                            common += sp[c][lane + j];
+                        g0[c] = left[c] + common;
+                        g1[c] = common + right[c];
                     }
-                    // the solve on the unscaled sums G = g / scale: g0 g2 - g1^2 + 1e-3 = scale^2 (G0 G2 - G1^2 +
-                    // 1e-3 / scale^2) and the flow's scale^2 cancels -- ten multiplies less, the same value to 1e-16
                     const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + eps);
                     const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + eps);
                     float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
@@ -1910,7 +1930,6 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 }
                 lds_wave_sync();
             }
-            lds_barrier();
         }
     }
 }
@@ -2040,7 +2059,6 @@ __global__ void k_flow_area_init(const float2 *__restrict__ init, float2 *__rest
     }
     out[(size_t)pair * Wc * Hc + (size_t)dy * Wc + dx] = make_float2(r.x * mul, r.y * mul);
 }
-
 // ---------------------------------------------------------------------------------
 // B1: FlowSource.post_process (source.py:337-363)
 // ---------------------------------------------------------------------------------
@@ -2740,13 +2758,13 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     if (up) {
         FlowInit f = *up;
         f.rmap = fb->rmap_dev;
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(128 + 64 * TF_PC_CONS), 0, R, flow_in, flow_out, w, h, scale,
                       seg, f);
     }
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(128 + 64 * TF_PC_CONS), 0, R, flow_in, flow_out, w, h, scale,
                       seg, none);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(192), 0, R, flow_in, flow_out, w, h, scale,
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(128 + 64 * TF_PC_CONS), 0, R, flow_in, flow_out, w, h, scale,
                   seg, none);
 }
 
