@@ -1720,6 +1720,11 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
 // march and the row's half wave-uniform.
 __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float wy, float m[5])
 {
+    // The one place where this library lets the compiler contract a * b + c into fused multiply-adds (the file is
+    // built with -ffp-contract=off): 10 vector instructions less per producer row, +1.8 % frames/s at 4K.  The
+    // values of M then differ from k_update_matrices' in the last bit (each fused operation rounds once instead of
+    // twice); the one-kernel iteration is held to the path's 1e-4 tolerance, not to bit-identity.
+#pragma clang fp contract(fast)
     const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     float2u r23 = a00 * g.t01.xy + a01 * g.t01.zw + a10 * g.b01.xy + a11 * g.b01.zw;
