@@ -1650,7 +1650,7 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
 // ---------------------------------------------------------------------------------
 // One pixel of A3 split into "issue the loads" and "finish the arithmetic" (one column per lane),
 // so a marching wave can keep the gathers of later rows in flight: used by the producers of
-// k_flow_iter_pc below.  Same statements as update_matrix_px.
+// k_flow_iter_pc below.  Same statements as update_matrix_px, with the multiply-adds fused (see gather1_finish).
 // ---------------------------------------------------------------------------------
 struct Gather1 {
     float2u r0a, r0b;            // R0 at the pixel: (c0, c1), (c2, c3)
