@@ -143,16 +143,14 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-// 1/d for a positive, normal double: the hardware estimate (good to 2^-26 or better) and two Newton steps, each of
-// which squares the error: 2^-52 after the first, rounding-limited after the second -- a relative error of a few
-// 1e-16 in a quantity the path needs to 1e-4.  (The compiler's IEEE division adds a residual correction and the
-// scaling / fix-up of denormal and infinite operands, ~25 instructions; determinants that carry +1e-3 are never those.)
+// 1/d for a positive, normal double: the hardware estimate (good to 2^-26 or better) and one Newton step, which
+// squares the error: 2^-52, in a quantity that leaves the kernel as a float and that the path needs to 1e-4.  (The
+// compiler's IEEE division adds a second step, a residual correction and the scaling / fix-up of denormal and
+// infinite operands, ~25 instructions; determinants that carry +1e-3 are never those.)
 __device__ __forceinline__ double fast_recip(double d)
 {
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
 }
 
 __device__ __forceinline__ void lds_wave_sync()
@@ -1924,14 +1922,20 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                         g0[c] = left[c] + common;
                         g1[c] = common + right[c];
                     }
-                    const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + eps);
-                    const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + eps);
                     float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
-                    o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
-                                       (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
-                    if (c0 + 1 < Wk)
-                        o[1] = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
-                                           (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+                    {
+                        // the solve with its multiply-adds fused and one Newton step on v_rcp_f64 (a float leaves here):
+                        // 10 fp64 instructions less per row, +1 % frames/s; k_blur_solve_wave keeps the separate
+                        // operations and the second step
+#pragma clang fp contract(fast)
+                        const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + eps);
+                        const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + eps);
+                        o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
+                                           (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
+                        if (c0 + 1 < Wk)
+                            o[1] = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
+                                               (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+                    }
                 }
                 lds_wave_sync();
             }
