@@ -120,6 +120,13 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// the same for lo <= hi as one v_med3_i32
+__device__ __forceinline__ int med3i(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
+    return r;
+}
 
 // Blocks are dealt round-robin over the 8 XCDs, each with its own L2 (MI355X_MICROARCH.md, dispatch):
 // renumber the blocks of a 2-D grid so that one XCD walks a contiguous raster range of tiles and
@@ -1664,10 +1671,12 @@ struct Gather1 {
 struct PlaneBases {
     const float *r0_01, *r0_23, *r0_4;
     const float *r1_01, *r1_23, *r1_4;
+    const float *r1_01b, *r1_23b, *r1_4b; // the same planes one row down: the bilinear bottom row shares the top row's offset
 };
-__device__ __forceinline__ PlaneBases plane_bases(const float *R0, const float *R1, size_t Nk)
+__device__ __forceinline__ PlaneBases plane_bases(const float *R0, const float *R1, size_t Nk, int Wk)
 {
-    return PlaneBases{R0, R0 + r_off23(Nk), R0 + r_off4(Nk), R1, R1 + r_off23(Nk), R1 + r_off4(Nk)};
+    return PlaneBases{R0, R0 + r_off23(Nk), R0 + r_off4(Nk), R1, R1 + r_off23(Nk), R1 + r_off4(Nk),
+                      R1 + 2 * Wk, R1 + r_off23(Nk) + 2 * Wk, R1 + r_off4(Nk) + Wk};
 }
 
 __device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
@@ -1699,14 +1708,13 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
     g.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
     // out-of-frame taps load from a clamped (valid) address and are discarded: no branch around the loads
     // (rows and widths are far below 2^24: the 24-bit multiply-add is exact and a single full-rate instruction)
-    const unsigned qt = __umul24((unsigned)clampi(y1, 0, Hk - 2), (unsigned)Wk) + (unsigned)clampi(x1, 0, Wk - 2);
-    const unsigned qb = qt + (unsigned)Wk;
+    const unsigned qt = __umul24((unsigned)med3i(y1, 0, Hk - 2), (unsigned)Wk) + (unsigned)med3i(x1, 0, Wk - 2);
     g.t01 = ld_f32x4(pb.r1_01, qt * 8u);
-    g.b01 = ld_f32x4(pb.r1_01, qb * 8u);
+    g.b01 = ld_f32x4(pb.r1_01b, qt * 8u);
     g.t23 = ld_f32x4(pb.r1_23, qt * 8u);
-    g.b23 = ld_f32x4(pb.r1_23, qb * 8u);
+    g.b23 = ld_f32x4(pb.r1_23b, qt * 8u);
     g.t4 = ld_f32x2(pb.r1_4, qt * 4u);
-    g.b4 = ld_f32x2(pb.r1_4, qb * 4u);
+    g.b4 = ld_f32x2(pb.r1_4b, qt * 4u);
 }
 
 // update_matrix_px's statements on the channel pairs as they were loaded: per channel the bilinear sum is
@@ -1797,7 +1805,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const int col = wave * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
         const int2 im = pair_images(fi, pair);
-        const PlaneBases pb = plane_bases(R + (size_t)im.x * 5 * Nk, R + (size_t)im.y * 5 * Nk, Nk);
+        const PlaneBases pb = plane_bases(R + (size_t)im.x * 5 * Nk, R + (size_t)im.y * 5 * Nk, Nk, Wk);
         const float2 *fin = FLOW == 1 ? flow_in + (size_t)pair * Nk : nullptr;
         const float2 *coarse = FLOW == 2 ? fi.src + (size_t)pair * fi.Wc * fi.Hc : nullptr;
         int up_sx = 0, up_sx1 = 0;
@@ -1860,7 +1868,10 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         for (int s = 0; s < nsteps; s++) {
             if (s < n_rows) {
                 float m[5];
-                gather1_finish(G, wx, border_weight(min(y_fin, Hk - 1 - y_fin)), m);
+                // the row's edge weight is wave-uniform: border_weight() as scalar selects on the floats' bits (0.14f, 0.4472f, 1.f)
+                const int dyb = min(y_fin, Hk - 1 - y_fin);
+                const unsigned wyb = dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u);
+                gather1_finish(G, wx, __uint_as_float(wyb), m);
                 gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
                 const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
                 F = load_flow(y_flow);
