@@ -1892,7 +1892,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         }
     } else {
         // The consumers take turns: wave 2 + k serves the steps with s % TF_PC_CONS == k.  In its step a consumer first
-        // copies what it needs of the row's sums out of s_v (its two columns and one single column at each end of
+        // takes what it needs of the row's sums out of s_v (the sum of its two columns and one single column at each end of
         // the window) -- that much must be done before the step's barrier, after which the producers overwrite the
         // buffer -- and then has until its next turn for the exchange of pair sums, the solve and the store.
         const int who = wave - 2;
@@ -1900,36 +1900,55 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const int c0 = (int)bx * OUTC - HALO + 2 * lane;
         const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
         const double eps = 1e-3 / (scale * scale);
-        constexpr int hh = (M - 1) / 2, kk = (M + 1) / 2;
+        constexpr int kk = (M + 1) / 2;
         const int lo = max(lane - kk, 0), hi = min(lane + kk, 63);
         for (int s = 0; s < nsteps; s++) {
             const int y = r0 + (s - 1) - 2 * M; // the row whose window the producers completed in step s - 1
             const bool mine = (s % TF_PC_CONS) == who && y >= r0; // wave-uniform
-            double a[5], bb[5], left[5], right[5];
+            double p[5], left[5], right[5];
             if (mine) {
                 const double(*sv)[128] = s_v[(s - 1) & 1];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    a[c] = sv[c][2 * lane];
-                    bb[c] = sv[c][2 * lane + 1];
+                    p[c] = sv[c][2 * lane] + sv[c][2 * lane + 1];
                     left[c] = sv[c][2 * lo + 1];
                     right[c] = sv[c][2 * hi];
                 }
             }
             lds_barrier();
             if (mine) {
+                // The M pair sums of a window through sums of three: T[l] = P[l-1] + P[l] + P[l+1] replaces P in
+                // LDS (a lane keeps its own P), and the window is T[l] (M = 3), T[l-1] + T[l+1] - P[l] (M = 5) or
+                // T[l-2] + P[l] + T[l+2] (M = 7): four LDS accesses and four additions per channel instead of
+                // eight and six.  T of lanes 0 and 63 is not a sum of three and no output lane reads it.
+                static_assert(M == 3 || M == 5 || M == 7, "window sums from sums of three");
+                double t[5];
 #pragma unroll
                 for (int c = 0; c < 5; c++)
-                    sp[c][lane] = a[c] + bb[c];
+                    sp[c][lane] = p[c];
                 lds_wave_sync();
+                const int lm = max(lane - 1, 0), lp = min(lane + 1, 63);
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    t[c] = (sp[c][lm] + p[c]) + sp[c][lp];
+                if (M > 3) {
+                    lds_wave_sync();
+#pragma unroll
+                    for (int c = 0; c < 5; c++)
+                        sp[c][lane] = t[c];
+                    lds_wave_sync();
+                }
                 if (is_out) {
                     double g0[5], g1[5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        double common = sp[c][lane - hh];
-#pragma unroll
-                        for (int j = -hh + 1; j <= hh; j++)
-                            common += sp[c][lane + j];
+                        double common;
+                        if (M == 3)
+                            common = t[c];
+                        else if (M == 5)
+                            common = (sp[c][lane - 1] + sp[c][lane + 1]) - p[c];
+                        else
+                            common = (sp[c][lane - 2] + p[c]) + sp[c][lane + 2];
                         g0[c] = left[c] + common;
                         g1[c] = common + right[c];
                     }
