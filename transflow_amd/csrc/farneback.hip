@@ -1960,11 +1960,14 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 #pragma clang fp contract(fast)
                         const double idet0 = fast_recip(g0[0] * g0[2] - g0[1] * g0[1] + eps);
                         const double idet1 = fast_recip(g1[0] * g1[2] - g1[1] * g1[1] + eps);
-                        o[0] = make_float2((float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
-                                           (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0));
-                        if (c0 + 1 < Wk)
-                            o[1] = make_float2((float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
-                                               (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1));
+                        const float4u f = {(float)((g0[0] * g0[4] - g0[1] * g0[3]) * idet0),
+                                           (float)((g0[2] * g0[3] - g0[1] * g0[4]) * idet0),
+                                           (float)((g1[0] * g1[4] - g1[1] * g1[3]) * idet1),
+                                           (float)((g1[2] * g1[3] - g1[1] * g1[4]) * idet1)};
+                        if (c0 + 1 < Wk) // both columns in one 16-byte store (8-byte aligned where the level's width is odd)
+                            *reinterpret_cast<float4u *>(o) = f;
+                        else
+                            o[0] = make_float2(f.x, f.y);
                     }
                 }
                 lds_wave_sync();
