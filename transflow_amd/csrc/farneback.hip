@@ -1692,29 +1692,53 @@ __device__ __forceinline__ float4u ld_f32x4(const float *base, unsigned byte_off
     return *reinterpret_cast<const float4u *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-__device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, int Wk, int Hk, int x, int y, float2 fl)
+// The addresses and weights of one pixel's gathers (everything that depends on the flow), apart from the loads.
+struct GatherPrep {
+    unsigned o8, o4, q8, q4; // byte offsets: the pixel in an 8-byte / 4-byte plane of R0, the top-left tap in R1's
+    float dx, dy, fx, fy;
+    bool inb;
+};
+__device__ __forceinline__ GatherPrep gather1_prep(int Wk, int Hk, int x, int y, float2 fl)
 {
+    GatherPrep p;
     const unsigned o = (unsigned)y * Wk + x;
-    g.r0a = ld_f32x2(pb.r0_01, o * 8u);
-    g.r0b = ld_f32x2(pb.r0_23, o * 8u);
-    g.r0c = ld_f32(pb.r0_4, o * 4u);
+    p.o8 = o * 8u;
+    p.o4 = o * 4u;
     const float fx = x + fl.x, fy = y + fl.y;
     const float flx = floorf(fx), fly = floorf(fy); // (float)(int)floor(f) == floor(f) wherever the int exists
     const int x1 = (int)flx, y1 = (int)fly;
-    g.dx = fl.x;
-    g.dy = fl.y;
-    g.fx = fx - flx;
-    g.fy = fy - fly;
-    g.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
+    p.dx = fl.x;
+    p.dy = fl.y;
+    p.fx = fx - flx;
+    p.fy = fy - fly;
+    p.inb = (unsigned)x1 < (unsigned)(Wk - 1) && (unsigned)y1 < (unsigned)(Hk - 1);
     // out-of-frame taps load from a clamped (valid) address and are discarded: no branch around the loads
     // (rows and widths are far below 2^24: the 24-bit multiply-add is exact and a single full-rate instruction)
     const unsigned qt = __umul24((unsigned)med3i(y1, 0, Hk - 2), (unsigned)Wk) + (unsigned)med3i(x1, 0, Wk - 2);
-    g.t01 = ld_f32x4(pb.r1_01, qt * 8u);
-    g.b01 = ld_f32x4(pb.r1_01b, qt * 8u);
-    g.t23 = ld_f32x4(pb.r1_23, qt * 8u);
-    g.b23 = ld_f32x4(pb.r1_23b, qt * 8u);
-    g.t4 = ld_f32x2(pb.r1_4, qt * 4u);
-    g.b4 = ld_f32x2(pb.r1_4b, qt * 4u);
+    p.q8 = qt * 8u;
+    p.q4 = qt * 4u;
+    return p;
+}
+__device__ __forceinline__ void gather1_load(Gather1 &g, const PlaneBases &pb, const GatherPrep &p)
+{
+    g.r0a = ld_f32x2(pb.r0_01, p.o8);
+    g.r0b = ld_f32x2(pb.r0_23, p.o8);
+    g.r0c = ld_f32(pb.r0_4, p.o4);
+    g.dx = p.dx;
+    g.dy = p.dy;
+    g.fx = p.fx;
+    g.fy = p.fy;
+    g.inb = p.inb;
+    g.t01 = ld_f32x4(pb.r1_01, p.q8);
+    g.b01 = ld_f32x4(pb.r1_01b, p.q8);
+    g.t23 = ld_f32x4(pb.r1_23, p.q8);
+    g.b23 = ld_f32x4(pb.r1_23b, p.q8);
+    g.t4 = ld_f32x2(pb.r1_4, p.q4);
+    g.b4 = ld_f32x2(pb.r1_4b, p.q4);
+}
+__device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, int Wk, int Hk, int x, int y, float2 fl)
+{
+    gather1_load(g, pb, gather1_prep(Wk, Hk, x, y, fl));
 }
 
 // update_matrix_px's statements on the channel pairs as they were loaded: per channel the bilinear sum is
@@ -1776,11 +1800,12 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float
 // FLOW: where the iteration's input flow comes from -- 0: zero (coarsest scale), 1: flow_in, 2: A5 on the
 // fly, resize(coarser flow, INTER_LINEAR) * 1/pyr_scale through `fi` (the statements of k_flow_upsample;
 // the column's table entries are loaded once per lane, the row's are the same address for all lanes).
+#define TF_PC_THREADS (128 + 64 * TF_PC_CONS)
 #ifndef TF_PC_CONS
 #define TF_PC_CONS 2 // consumer waves per workgroup: they take turns by row (1: 1701, 2: 1723 frames/s at 4K x 32)
 #endif
 template <int M, int FLOW>
-__global__ void __launch_bounds__(128 + 64 * TF_PC_CONS)
+__global__ void __launch_bounds__(TF_PC_THREADS)
 k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
                int Hk, double scale, int seg, FlowInit fi)
 {
@@ -1798,11 +1823,11 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     // step s: producers make entering row e = r0 - M + s (s < n_rows) and its window sums; the consumer
     // turns the sums of step s - 1 into the flow of row r0 + (s - 1) - 2M
     const int n_rows = (r1 - r0) + 2 * M, nsteps = n_rows + 1;
-    for (int i = threadIdx.x; i < WIN * 5 * 128; i += 128 + 64 * TF_PC_CONS)
+    for (int i = threadIdx.x; i < WIN * 5 * 128; i += TF_PC_THREADS)
         (&ring[0][0][0])[i] = 0.f; // rows "above" the first window count as zero: the warm-up subtracts them
     __syncthreads();
     if (wave < 2) {
-        const int col = wave * 64 + lane;
+        const int col = (wave & 1) * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
         const int2 im = pair_images(fi, pair);
         const PlaneBases pb = plane_bases(R + (size_t)im.x * 5 * Nk, R + (size_t)im.y * 5 * Nk, Nk, Wk);
@@ -1855,10 +1880,10 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             const float b0 = 1.f - r.fy;
             return make_float2((h0.x * b0 + h1.x * r.fy) * fi.mul, (h0.y * b0 + h1.y * r.fy) * fi.mul);
         };
+        const float wx = border_weight(min(x, Wk - 1 - x));
         // One row of gathers in flight: those of row e + 1 are issued while row e is finished (two or more
         // rows ahead were measured slower).  The three clamped rows a step works with (the one being finished,
         // the one whose gathers are issued, the one whose flow is loaded) move along by one: one clamp per step.
-        const float wx = border_weight(min(x, Wk - 1 - x));
         Gather1 G;
         int y_fin = clampi(r0 - M, 0, Hk - 1), y_iss = clampi(r0 - M + 1, 0, Hk - 1);
         gather1_issue(G, pb, Wk, Hk, x, y_fin, flow_of(load_flow(y_fin)));
@@ -2800,13 +2825,13 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     if (up) {
         FlowInit f = *up;
         f.rmap = fb->rmap_dev;
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(128 + 64 * TF_PC_CONS), 0, R, flow_in, flow_out, w, h, scale,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
                       seg, f);
     }
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(128 + 64 * TF_PC_CONS), 0, R, flow_in, flow_out, w, h, scale,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
                       seg, none);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(128 + 64 * TF_PC_CONS), 0, R, flow_in, flow_out, w, h, scale,
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
                   seg, none);
 }
 
