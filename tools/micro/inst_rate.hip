@@ -10,6 +10,7 @@ __global__ void __launch_bounds__(64) k_rate(float *out, int n, float seed)
 {
     float f[8];
     double d[8];
+    int sc[8] = {0, 1, 2, 3, 4, 5, 6, 7};
     for (int i = 0; i < 8; i++) {
         f[i] = seed + i + threadIdx.x;
         d[i] = seed * 3 + i;
@@ -29,11 +30,14 @@ __global__ void __launch_bounds__(64) k_rate(float *out, int n, float seed)
             if (MODE == 9) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
             if (MODE == 10) asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(f[i]) : "v"(f[(i + 1) & 7]));
             if (MODE == 11) asm volatile("v_mad_u32_u24 %0, %1, %1, %0" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(f[(i + 1) & 7]) : "vcc");
+            if (MODE == 14) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc[i]));
         }
     }
     float s = 0;
     for (int i = 0; i < 8; i++)
-        s += f[i] + (float)d[i];
+        s += f[i] + (float)d[i] + sc[i];
     out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
@@ -52,7 +56,7 @@ int run(const char *name, float *out, int waves_per_simd)
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     // cycles per wave instruction per SIMD at 2.4 GHz (the clock is not read: compare rows with each other)
-    printf("%-16s waves/SIMD %d: %.3f ms  %.2f cycles per wave instruction at 2.4 GHz\n", name, waves_per_simd, ms,
+    printf("%-20s waves/SIMD %d: %.3f ms  %.2f cycles per wave instruction at 2.4 GHz\n", name, waves_per_simd, ms,
            ms * 1e-3 * 2.4e9 / ((double)n * 8 * waves_per_simd));
     return 0;
 }
@@ -61,7 +65,7 @@ int main()
 {
     float *out;
     CHECK(hipMalloc(&out, 256 * 4 * 4 * 64 * sizeof(float)));
-    for (int w = 1; w <= 2; w++) {
+    for (int w = 1; w <= 4; w++) {
         run<0>("v_add_f32", out, w);
         run<1>("v_add_f64", out, w);
         run<9>("v_mul_f64", out, w);
@@ -74,6 +78,9 @@ int main()
         run<8>("v_cvt_i32_f32", out, w);
         run<10>("v_lshlrev_b32", out, w);
         run<11>("v_mad_u32_u24", out, w);
+        run<12>("v_add_f32 (2 regs)", out, w);
+        run<13>("v_cndmask_b32", out, w);
+        run<14>("s_add_u32", out, w);
     }
     return 0;
 }
