@@ -213,6 +213,7 @@ __device__ __forceinline__ int lerp_coord(int d, double scale, int src, bool zer
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W,
@@ -976,12 +977,14 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
     constexpr int SW = ((LW + 2 + 3 + 3) + 3) & ~3, SH = LH + 2; // staged bytes: one more pixel all round, dword slack
     // LDS: the staged bytes and the row-pass values are dead once the blurred tile exists, so the
     // three planes of the expansion's vertical pass reuse their space
-    constexpr int BYTES_A = SH * SW + SH * LW * 4, BYTES_T = 3 * TH * LW * 4;
+    constexpr int RS = (LW + 3) & ~3; // row stride of the row-pass values: whole groups of four columns
+    static_assert(SW >= RS + 4 + 4 && (SH * SW) % 16 == 0, "a group's three dwords stay inside its staged row; sRow 16-byte aligned");
+    constexpr int BYTES_A = SH * SW + SH * RS * 4, BYTES_T = 3 * TH * LW * 4;
     constexpr int BYTES_U = ((BYTES_A > BYTES_T ? BYTES_A : BYTES_T) + 15) & ~15;
     __shared__ __attribute__((aligned(16))) uint8_t s_u[BYTES_U];
     __shared__ float sI[LH * LW]; // blurred level image, indexed by real coordinate offsets
     uint8_t *sS = s_u;                                          // [SH][SW] staged bytes
-    float *sRow = reinterpret_cast<float *>(s_u + SH * SW);     // [SH][LW] row-pass values, rows yr0-1 .. yr1+1
+    float *sRow = reinterpret_cast<float *>(s_u + SH * SW);     // [SH][RS] row-pass values, rows yr0-1 .. yr1+1
     float(*sT)[TH][LW] = reinterpret_cast<float(*)[TH][LW]>(s_u); // [3][TH][LW], after the blur
     const int pi = blockIdx.z;
     const int2 pr = pairs[pi >> 1];
@@ -1039,24 +1042,32 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
         }
     }
     __syncthreads();
-    // row pass (tap order of k_level_image, ksz == 3)
-    for (int idx = threadIdx.x; idx < (ny + 2) * LW; idx += 256) {
-        int ry = idx / LW, cx = idx - ry * LW;
-        if (cx < nx) {
-            const uint8_t *p = sS + ry * SW + off + cx + 1;
-            sRow[idx] = (float)p[0] * kc + ((float)p[-1] + (float)p[1]) * k1;
-        }
+    // row pass (tap order of k_level_image, ksz == 3), four adjacent pixels per item: their six bytes come out of
+    // three aligned dwords (the staged row starts on a dword; `off` is the same for the whole tile)
+    for (int idx = threadIdx.x; idx < (ny + 2) * (RS / 4); idx += 256) {
+        const int ry = idx / (RS / 4), cx = 4 * (idx - ry * (RS / 4));
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(sS + ry * SW + cx); // bytes off + cx .. are pixels cx-1 ..
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, off), hi = __builtin_amdgcn_alignbyte(d2, d1, off);
+        const float b0 = (float)(lo & 0xff), b1 = (float)((lo >> 8) & 0xff), b2 = (float)((lo >> 16) & 0xff),
+                    b3 = (float)(lo >> 24), b4 = (float)(hi & 0xff), b5 = (float)((hi >> 8) & 0xff);
+        float *o = sRow + ry * RS + cx;
+        *reinterpret_cast<f32x2 *>(o) = f32x2{b1 * kc + (b0 + b2) * k1, b2 * kc + (b1 + b3) * k1};
+        *reinterpret_cast<f32x2 *>(o + 2) = f32x2{b3 * kc + (b2 + b4) * k1, b4 * kc + (b3 + b5) * k1};
     }
     __syncthreads();
-    // column pass -> blurred image at real coordinates (xr0 + cx, yr0 + ry)
-    for (int idx = threadIdx.x; idx < ny * LW; idx += 256) {
-        int ry = idx / LW, cx = idx - ry * LW;
-        if (cx < nx) {
-            const float *c = sRow + (ry + 1) * LW + cx;
-            float v = kc * c[0];
-            v += k1 * (c[LW] + c[-LW]);
-            sI[idx] = v;
-        }
+    // column pass -> blurred image at real coordinates (xr0 + cx, yr0 + ry), four columns per item
+    for (int idx = threadIdx.x; idx < ny * (RS / 4); idx += 256) {
+        const int ry = idx / (RS / 4), cx = 4 * (idx - ry * (RS / 4));
+        const float *c = sRow + (ry + 1) * RS + cx;
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(c), dn = *reinterpret_cast<const f32x4 *>(c + RS),
+                    up = *reinterpret_cast<const f32x4 *>(c - RS);
+        f32x4 v = kc * m;
+        v += k1 * (dn + up);
+        float *o = sI + ry * LW + cx;
+        *reinterpret_cast<f32x2 *>(o) = f32x2{v.x, v.y};
+        if (cx + 2 < LW)
+            *reinterpret_cast<f32x2 *>(o + 2) = f32x2{v.z, v.w};
     }
     __syncthreads();
     tile_expansion<N, TW, TH>(sI, sT, x0, y0, xr0, yr0, W, H, pc, R + (size_t)pi * 5 * Nk, Nk);
