@@ -995,7 +995,7 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
     // real image region the tile's (clamped) reads touch
     const int xr0 = max(x0 - N, 0), xr1 = min(x0 + TW - 1 + N, W - 1);
     const int yr0 = max(y0 - N, 0), yr1 = min(y0 + TH - 1 + N, H - 1);
-    const int nx = xr1 - xr0 + 1, ny = yr1 - yr0 + 1;
+    const int ny = yr1 - yr0 + 1; // (columns past xr1 are computed from whatever was staged and never read)
     // stage bytes for columns xr0-1 .. xr1+1, rows yr0-1 .. yr1+1 (reflected outside the image);
     // the staged columns start at a multiple of 4 so interior tiles copy dwords
     const int xs = (xr0 - 1) & ~3, off = xr0 - 1 - xs; // column xr0-1 sits at byte `off` of a staged row
