@@ -1101,7 +1101,7 @@ k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int xr0 = max(x0 - N, 0), xr1 = min(x0 + TW - 1 + N, Wk - 1);
     const int yr0 = max(y0 - N, 0), yr1 = min(y0 + TH - 1 + N, Hk - 1);
-    const int nx = xr1 - xr0 + 1, ny = yr1 - yr0 + 1;
+    const int ny = yr1 - yr0 + 1;
     // frame bytes: columns 2*xr0-1 .. 2*xr1+2, rows 2*yr0-1 .. 2*yr1+2 (REFLECT_101 outside the frame)
     const int cfirst = 2 * xr0 - 1, rfirst = 2 * yr0 - 1, nrows = 2 * ny + 2;
     const int xs = cfirst >= 0 ? (cfirst & ~3) : cfirst, off = cfirst - xs;
@@ -1148,28 +1148,43 @@ k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
         }
     }
     __syncthreads();
-    // level pixel (xr0 + cx, yr0 + ry): frame rows 2Y-1 .. 2Y+2 are staged rows 2*ry .. 2*ry+3, frame
-    // columns 2X-1 .. 2X+2 staged bytes off + 2*cx .. +3
-    for (int idx = threadIdx.x; idx < ny * LW; idx += 256) {
-        const int ry = idx / LW, cx = idx - ry * LW;
-        if (cx >= nx)
-            continue;
-        const uint8_t *p = sS + (2 * ry) * SW + off + 2 * cx;
-        float r[4][2];
+    // Level pixel (xr0 + cx, yr0 + ry): frame rows 2Y-1 .. 2Y+2 are staged rows 2*ry .. 2*ry+3, frame columns
+    // 2X-1 .. 2X+2 staged bytes off + 2*cx .. +3.  An item is a 2 x 2 block of level pixels: six staged rows, six
+    // bytes of each out of three aligned dwords (`off` is the tile's), 24 row-pass values instead of 32.  Rows and
+    // columns past the tile's real region are computed from whatever was staged and never read.
+    static_assert(LW % 2 == 0 && SW >= 2 * LW + 8, "2 x 2 blocks; a block's three dwords stay inside its staged row");
+    for (int idx = threadIdx.x; idx < ((ny + 1) >> 1) * (LW / 2); idx += 256) {
+        const int by2 = idx / (LW / 2), ry = 2 * by2, cx = 2 * (idx - by2 * (LW / 2));
+        float rp[6][4];
 #pragma unroll
-        for (int dy = 0; dy < 4; dy++) {
-            const uint8_t *q = p + dy * SW;
-            const float b0 = (float)q[0], b1 = (float)q[1], b2 = (float)q[2], b3 = (float)q[3];
-            r[dy][0] = b1 * kc + (b0 + b2) * k1; // row pass at frame column 2X
-            r[dy][1] = b2 * kc + (b1 + b3) * k1; //                         2X+1
+        for (int dy = 0; dy < 6; dy++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(sS + (2 * ry + dy) * SW + 2 * cx);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, off), hi = __builtin_amdgcn_alignbyte(d2, d1, off);
+            const float b0 = (float)(lo & 0xff), b1 = (float)((lo >> 8) & 0xff), b2 = (float)((lo >> 16) & 0xff),
+                        b3 = (float)(lo >> 24), b4 = (float)(hi & 0xff), b5 = (float)((hi >> 8) & 0xff);
+            rp[dy][0] = b1 * kc + (b0 + b2) * k1; // row pass at frame columns 2X, 2X+1 (this pixel), 2X+2, 2X+3 (the next)
+            rp[dy][1] = b2 * kc + (b1 + b3) * k1;
+            rp[dy][2] = b3 * kc + (b2 + b4) * k1;
+            rp[dy][3] = b4 * kc + (b3 + b5) * k1;
         }
-        float v00 = kc * r[1][0], v01 = kc * r[1][1], v10 = kc * r[2][0], v11 = kc * r[2][1];
-        v00 += k1 * (r[2][0] + r[0][0]); // column pass at frame row 2Y: centre, then (row+1 + row-1)
-        v01 += k1 * (r[2][1] + r[0][1]);
-        v10 += k1 * (r[3][0] + r[1][0]); //                          2Y+1
-        v11 += k1 * (r[3][1] + r[1][1]);
-        const float h0 = v00 * (1.f - 0.5f) + v01 * 0.5f, h1 = v10 * (1.f - 0.5f) + v11 * 0.5f;
-        sI[idx] = h0 * (1.f - 0.5f) + h1 * 0.5f;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            float out[2];
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                float v00 = kc * rp[2 * a + 1][2 * b], v01 = kc * rp[2 * a + 1][2 * b + 1];
+                float v10 = kc * rp[2 * a + 2][2 * b], v11 = kc * rp[2 * a + 2][2 * b + 1];
+                v00 += k1 * (rp[2 * a + 2][2 * b] + rp[2 * a][2 * b]); // column pass at frame row 2Y: centre, then (row+1 + row-1)
+                v01 += k1 * (rp[2 * a + 2][2 * b + 1] + rp[2 * a][2 * b + 1]);
+                v10 += k1 * (rp[2 * a + 3][2 * b] + rp[2 * a + 1][2 * b]); //                          2Y+1
+                v11 += k1 * (rp[2 * a + 3][2 * b + 1] + rp[2 * a + 1][2 * b + 1]);
+                const float h0 = v00 * (1.f - 0.5f) + v01 * 0.5f, h1 = v10 * (1.f - 0.5f) + v11 * 0.5f;
+                out[b] = h0 * (1.f - 0.5f) + h1 * 0.5f;
+            }
+            if (ry + a < ny)
+                *reinterpret_cast<f32x2 *>(sI + (ry + a) * LW + cx) = f32x2{out[0], out[1]};
+        }
     }
     __syncthreads();
     tile_expansion<N, TW, TH>(sI, sT, x0, y0, xr0, yr0, Wk, Hk, pc, R + (size_t)pi * 5 * Nk, Nk);
