@@ -120,8 +120,8 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
     for r, p in enumerate(d["plans"]):
         assert p["rank"] == r
         assert tuple(p["frames"]) == (p["pairs"][0], p["pairs"][1] + 1)        # the halo frame
-        assert p["pairs_per_pass"] == 16
-        assert p["pass_starts"] == batch_starts(p["n_pairs"], 16)
+        assert p["pairs_per_pass"] == min(32, p["n_pairs"])                        # bench.py's default --batch
+        assert p["pass_starts"] == batch_starts(p["n_pairs"], 32)
 
 
 def test_bench_refuses_a_world_that_is_not_its_gpus():
