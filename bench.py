@@ -446,6 +446,8 @@ def main():
     ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (the JSON line says so)")
     ap.add_argument("--rccl", action="store_true", help="use the RCCL legs (broadcast, gather) even with one rank")
     ap.add_argument("--dry-run", action="store_true", help="ranks meet, shard the clip and report the plan; no GPU call")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a run-time option of the library (tf_set_option; include/tfhip.h) for A/B runs; recorded in the JSON line")
     args = ap.parse_args()
 
     from transflow_amd import batch as B
@@ -474,6 +476,11 @@ def main():
     from transflow_amd import _lib
     lib, check = _lib.load(), _lib.check
     check(lib.tf_init(local_rank))
+    options = {}
+    for item in args.option:
+        name, _, value = item.partition("=")
+        _lib.set_option(name, int(value))
+        options[name] = int(value)
     rccl, rccl_error = None, None
     pixmap = reset_mask = pixmap_dev = None
     if world > 1 or args.rccl:
@@ -638,6 +645,8 @@ def main():
     }
     if rccl_error:
         out["rccl_error"] = rccl_error
+    if options:
+        out["library_options"] = options   # not the defaults: an A/B run
     if gather is not None:
         out["gather"] = gather
     if world == 1 and not args.no_cpu_baseline and gate_times is not None:

@@ -50,7 +50,7 @@ int tf_device_count(int *count);
      "fb_fuse_min_px" 4000000
      "fb_no_share"    0   1 = pairs of a call that share a frame expand it once each (read per call)
      "fb_no_overlap"  0   1 = a call's kernels stay on the library stream (read by tf_fb_create)
-     "remap_px"       2   pixels per thread of tf_remap_step_dev's kernel: 1, 2 or 4
+     "remap_px"       4   pixels per thread of tf_remap_step_dev's kernel: 1, 2 or 4
      "remap_no_pack"  0   1 = tf_remap_step_dev keeps the layer state as int32 x 4 between steps
      "prof_levels"    0   1 = profiler labels carry the pyramid level
    Unknown names and out-of-range values return TF_ERR_ARG.  The environment is never read. */

@@ -17,3 +17,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def lib_option():
+    """Sets documented run-time options of the library (tf_set_option) and restores them afterwards."""
+    from transflow_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, _lib.get_option(name))
+        _lib.set_option(name, value)
+    yield set_
+    for name, value in saved.items():
+        _lib.set_option(name, value)

@@ -12,19 +12,6 @@ from tests.helpers import synth_pair
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def lib_option():
-    """Sets documented run-time options of the library (tf_set_option) and restores them afterwards."""
-    from transflow_amd import _lib
-    saved = {}
-
-    def set_(name, value):
-        saved.setdefault(name, _lib.get_option(name))
-        _lib.set_option(name, value)
-    yield set_
-    for name, value in saved.items():
-        _lib.set_option(name, value)
-
 TOL = 1e-4
 
 

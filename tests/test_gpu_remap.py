@@ -270,15 +270,18 @@ def test_argument_errors(tf):
     assert empty.get_state()[0].shape == (0, 0, 4)
 
 
+@pytest.mark.parametrize("px", [4, 2, 1])
 @pytest.mark.parametrize("path", layer_case_files(), ids=lambda p: os.path.basename(p)[12:-4])
-def test_fused_step_matches_golden(tf, path):
+def test_fused_step_matches_golden(tf, lib_option, path, px):
     """tf_remap_step_dev (one kernel when the layer allows it, the separate kernels otherwise)
-    on the reference's vectors: single-source cases, flow/pixmap/u resident in HBM."""
+    on the reference's vectors: single-source cases, flow/pixmap/u resident in HBM; every form of the one
+    kernel (option "remap_px": 4, 2 or 1 pixels per thread)."""
     from transflow_amd.device import DevBuffer
     _, remap = tf
     z = np.load(path)
     if int(z["nsources"]) != 1:
         pytest.skip("the fused step serves one source")
+    lib_option("remap_px", px)
     h, w = int(z["h"]), int(z["w"])
     layer = _make_layer(remap, h, w, case_cfg(z), z)
     layer.set_sources([z["intro_0"]])
@@ -473,11 +476,11 @@ def test_flow_presteps_device_path(tf):
     fb.close()
 
 
-@pytest.mark.parametrize("h,w", [(1080, 1920), (2160, 3840)])
+@pytest.mark.parametrize("h,w,px", [(1080, 1920, 4), (2160, 3840, 4), (1080, 1920, 2), (1079, 1918, 4), (1080, 1920, 1)])
 @pytest.mark.parametrize("direction", ["backward", "forward"])
-def test_timed_remap_kernel_at_full_size_with_its_own_uniform(tf, h, w, direction):
+def test_timed_remap_kernel_at_full_size_with_its_own_uniform(tf, lib_option, h, w, px, direction):
     """What bench.py times for the remap, at the sizes it times it: the one-kernel step
-    (k_remap_step_px<3, int16 state, two pixels per thread>) with the uniform field drawn ON THE GPU
+    (k_remap_step_px<3, int16 state, `px` pixels per thread: option "remap_px", 4 by default) with the uniform field drawn ON THE GPU
     (Philox), random reset p = 0.5 through a float mask, three frames.  tf_remap_uniform_dev hands out
     the very field the kernel is about to draw, so the numpy oracle (reference.py:58-67 with that u)
     must agree bit for bit on data, rgba and the frame.  backward: raw flow, clip folded in
@@ -485,6 +488,7 @@ def test_timed_remap_kernel_at_full_size_with_its_own_uniform(tf, h, w, directio
     of FORWARD post_process formed in registers (clip_flow=2, source.py:349-362)."""
     from transflow_amd.device import DevBuffer
     farneback, remap = tf
+    lib_option("remap_px", px)
     rng = np.random.default_rng(h + 3 * w + len(direction))
     rmask = rng.random((h, w), dtype=np.float32)
     ones = np.ones((h, w), bool)

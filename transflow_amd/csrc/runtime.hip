@@ -37,7 +37,7 @@ static OptDef g_opts[OPT_COUNT] = {
     {"fb_fuse_min_px", 4000000, 0, 1l << 40},  // pixels of a level over the batch (two 1080p levels, 4.15M, are in)
     {"fb_no_share", 0, 0, 1},                  // 1: expand per pair and side even when pairs share a frame
     {"fb_no_overlap", 0, 0, 1},                // 1: a call's work stays on the library stream (read at tf_fb_create)
-    {"remap_px", 2, 1, 4},                     // pixels per thread of the one-kernel remap step: 1, 2 or 4
+    {"remap_px", 4, 1, 4},                     // pixels per thread of the one-kernel remap step: 1, 2 or 4 (4: 1.98 ms per 32 4K frames, 2: 2.04, 1: 2.45)
     {"remap_no_pack", 0, 0, 1},                // 1: the one-kernel remap step keeps its state as int32 x 4
     {"prof_levels", 0, 0, 1},                  // 1: profiler labels carry the pyramid level ("fb_polyexp.k2")
 };
