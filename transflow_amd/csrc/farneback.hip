@@ -963,8 +963,13 @@ __device__ __forceinline__ void tile_expansion(const float *sI, float (*sT)[TH][
     }
 }
 
-#ifndef TF_EXP_TH
-#define TF_EXP_TH 20 // rows of a tile of the fused expansion kernels (4K x 33 frames, both kernels: 16: 2.49 ms, 20: 2.30, 24: 2.36, 28: 2.61, 32: 2.46)
+// rows of a tile of the fused expansion kernels (4K x 33 frames: level 0 with 12 / 16 / 20 rows 2.43 / 2.10 / 2.18 ms,
+// level 1 with 16 / 20 / 24 / 32 rows 1.31 (before its 2 x 2 blocks) / 0.87 / 0.95 / 1.05 ms)
+#ifndef TF_EXP_TH0
+#define TF_EXP_TH0 16
+#endif
+#ifndef TF_EXP_TH1
+#define TF_EXP_TH1 20
 #endif
 // A1+A2 fused for the full-resolution level (resize is a copy, the blur has 3 taps): the level
 // image never leaves the CU.  Stages the u8 region by REAL image coordinates (REFLECT_101 ring of
@@ -976,7 +981,7 @@ __global__ void __launch_bounds__(256)
 k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ R, int W,
                    int H, float kc, float k1, PolyConst pc)
 {
-    constexpr int TW = 64, TH = TF_EXP_TH, LW = TW + 2 * N, LH = TH + 2 * N; // blurred tile (virtual extent)
+    constexpr int TW = 64, TH = TF_EXP_TH0, LW = TW + 2 * N, LH = TH + 2 * N; // blurred tile (virtual extent)
     constexpr int SW = ((LW + 2 + 3 + 3) + 3) & ~3, SH = LH + 2; // staged bytes: one more pixel all round, dword slack
     // LDS: the staged bytes and the row-pass values are dead once the blurred tile exists, so the
     // three planes of the expansion's vertical pass reuse their space
@@ -1087,7 +1092,7 @@ __global__ void __launch_bounds__(256)
 k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ R, int W,
                    int H, float kc, float k1, PolyConst pc)
 {
-    constexpr int TW = 64, TH = TF_EXP_TH, LW = TW + 2 * N, LH = TH + 2 * N;
+    constexpr int TW = 64, TH = TF_EXP_TH1, LW = TW + 2 * N, LH = TH + 2 * N;
     constexpr int SW = ((2 * LW + 2 + 3 + 3) + 3) & ~3, SH = 2 * LH + 2; // staged bytes: 2 per level pixel + 1 all round
     constexpr int BYTES_A = SH * SW, BYTES_T = 3 * TH * LW * 4;
     constexpr int BYTES_U = ((BYTES_A > BYTES_T ? BYTES_A : BYTES_T) + 15) & ~15;
@@ -2734,7 +2739,7 @@ static bool fb_can_fuse_half_level(tf_fb *fb, int k)
 static int fb_level1_polyexp(tf_fb *fb, int k, int n_images)
 {
     Level &L = *fb->lv[k];
-    dim3 grid(cdiv(L.W, 64), cdiv(L.H, TF_EXP_TH), n_images);
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, TF_EXP_TH1), n_images);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), 0,
@@ -2748,7 +2753,7 @@ static int fb_level1_polyexp(tf_fb *fb, int k, int n_images)
 static int fb_level0_polyexp(tf_fb *fb, int k, int n_images)
 {
     Level &L = *fb->lv[k];
-    dim3 grid(cdiv(L.W, 64), cdiv(L.H, TF_EXP_TH), n_images);
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, TF_EXP_TH0), n_images);
     const float kc = L.kern_host[1], k1 = L.kern_host[2];
     if (fb->pc.n == 5)
         return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
