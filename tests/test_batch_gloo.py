@@ -124,6 +124,21 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
         assert p["pass_starts"] == batch_starts(p["n_pairs"], 32)
 
 
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`: the ranks exist already, find each other through the agent's pid + MASTER_PORT (no torch import
+    in bench.py) and shard the clip; --dry-run stops before any GPU call."""
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TF_BATCH_RDZV")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and [tuple(p["pairs"]) for p in d["plans"]] == [shard_range(255, r, 2) for r in range(2)]
+
+
 def test_bench_refuses_a_world_that_is_not_its_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=env,
