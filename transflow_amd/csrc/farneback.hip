@@ -1930,10 +1930,13 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 // the row's edge weight is wave-uniform: border_weight() as scalar selects on the floats' bits (0.14f, 0.4472f, 1.f)
                 const int dyb = min(y_fin, Hk - 1 - y_fin);
                 const unsigned wyb = dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u);
+                // the flow of the row after next is the first load of the step: when the step ends by moving it into
+                // place the wave waits for a load a whole step old, not for one it has just issued
+                const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
+                const FlowRaw Fn = load_flow(y_flow);
                 gather1_finish(G, wx, __uint_as_float(wyb), m);
                 gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
-                const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
-                F = load_flow(y_flow);
+                F = Fn;
                 y_fin = y_iss;
                 y_iss = y_flow;
                 // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
