@@ -1883,7 +1883,17 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
             float2 a, b, d, e; // FLOW == 2: the coarse flow at (sx, sy0), (sx + 1, sy0), (sx, sy1), (sx + 1, sy1); else a = the flow
             float fy;
         };
-        auto load_flow = [&](int row) { // row: already clamped to the level
+        // (FLOW == 2: the row's entries of the upsampling tables -- scalar loads -- are fetched a step before the
+        // flow loads that need them: sy_q, fy_q hold those of the row whose flow is loaded next)
+        int sy_q = 0;
+        float fy_q = 0.f;
+        auto fetch_row_entries = [&](int row) {
+            if (FLOW == 2) {
+                sy_q = fi.yofs[row];
+                fy_q = fi.yfrac[row];
+            }
+        };
+        auto load_flow = [&](int row) { // row: already clamped to the level; FLOW == 2: its table entries in sy_q, fy_q
             FlowRaw r;
             r.a = r.b = r.d = r.e = make_float2(0.f, 0.f);
             r.fy = 0.f;
@@ -1891,8 +1901,8 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 const unsigned off = ((unsigned)row * Wk + x) * 8u;
                 r.a = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
             } else if (FLOW == 2) {
-                const int sy = fi.yofs[row];
-                r.fy = fi.yfrac[row];
+                const int sy = sy_q;
+                r.fy = fy_q;
                 const int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
                 r.a = coarse[sy0 * fi.Wc + up_sx];
                 r.b = coarse[sy0 * fi.Wc + up_sx1];
@@ -1920,8 +1930,11 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         // the one whose gathers are issued, the one whose flow is loaded) move along by one: one clamp per step.
         Gather1 G;
         int y_fin = clampi(r0 - M, 0, Hk - 1), y_iss = clampi(r0 - M + 1, 0, Hk - 1);
+        fetch_row_entries(y_fin);
         gather1_issue(G, pb, Wk, Hk, x, y_fin, flow_of(load_flow(y_fin)));
+        fetch_row_entries(y_iss);
         FlowRaw F = load_flow(y_iss);
+        fetch_row_entries(clampi(r0 - M + 2, 0, Hk - 1));
         double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
         for (int s = 0; s < nsteps; s++) {
@@ -1934,6 +1947,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 // place the wave waits for a load a whole step old, not for one it has just issued
                 const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
                 const FlowRaw Fn = load_flow(y_flow);
+                fetch_row_entries(clampi(r0 - M + s + 3, 0, Hk - 1));
                 gather1_finish(G, wx, __uint_as_float(wyb), m);
                 gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
                 F = Fn;
