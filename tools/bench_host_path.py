@@ -18,7 +18,8 @@ from transflow_amd.flow import ArrayFrameProvider, HipFlowSource  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "1080p"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 w, h = {"1080p": (1920, 1080), "4k": (3840, 2160)}[name]
-frames = bench.synth_frames(h, w, n + 1, 2000)
+clip = bench.ClipSynth(h, w, n + 1, 2000)
+frames = [clip.frame(t) for t in range(n + 1)]
 pix = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
 
 
