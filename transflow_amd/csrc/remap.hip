@@ -454,10 +454,20 @@ k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *_
         else
             f[p] = flow[tc[p]];
         me[p] = state_load(old, (size_t)tc[p]);
-        mdv[p] = mdst ? mdst[tc[p]] : (uint8_t)1;
         rm[p] = (sp.reset_random && reset_mask) ? reset_mask[tc[p]] : 1.f;
         uv[p] = (sp.reset_random && u) ? u[tc[p]] : 0.0;
         ma[p] = mask_alpha ? mask_alpha[tc[p]] : 0.f;
+    }
+    // (an optional mask is one uniform branch around the loads of all PX pixels: taken per pixel, each load would be
+    // waited for before the next pixel's loads were issued)
+    if (mdst) {
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+            mdv[p] = mdst[tc[p]];
+    } else {
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+            mdv[p] = 1;
     }
     // --- phase 2: the source pixel of the move (movement.py:20-48)
     int pi[PX], pj[PX], sidx[PX];
@@ -491,9 +501,16 @@ k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *_
     int4 so[PX];
     uint8_t msv[PX];
 #pragma unroll
-    for (int p = 0; p < PX; p++) {
+    for (int p = 0; p < PX; p++)
         so[p] = state_load(old, (size_t)sidx[p]);
-        msv[p] = msrc ? msrc[sidx[p]] : (uint8_t)1;
+    if (msrc) {
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+            msv[p] = msrc[sidx[p]];
+    } else {
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+            msv[p] = 1;
     }
     // --- phase 4: the new state (move, then the random reset of reference.py:58-67), the gather address
     int4 d[PX];
