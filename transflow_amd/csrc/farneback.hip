@@ -169,6 +169,9 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // REFLECT_101 when the overshoot is known to be smaller than the image (one reflection suffices)
 __device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
+// REFLECT_101 for an index at most one step outside [0, len): no loop (reflect101's `while` becomes a real loop
+// with its own exec masking around every load that uses it)
+__device__ __forceinline__ int reflect101_near(int p, int len) { return len < 2 ? 0 : reflect101_once(p, len); }
 
 // ---------------------------------------------------------------------------------
 // A1: level image = resize(GaussianBlur(float(frame)), level size), one kernel per level.
@@ -1019,7 +1022,7 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
                 for (int u = 0; u < U; u++) {
                     int ry = j0 + 4 * u;
                     if (ry < ny + 2)
-                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101(yr0 - 1 + ry, H) * W + xs + 4 * c);
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101_near(yr0 - 1 + ry, H) * W + xs + 4 * c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -1031,14 +1034,14 @@ k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
         }
     } else {
         for (int c = lane; c < ncols; c += 64) {
-            const int x = reflect101(xs + c, W);
+            const int x = reflect101_near(xs + c, W);
             for (int j0 = wave; j0 < ny + 2; j0 += 4 * U) {
                 uint8_t v[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     int ry = j0 + 4 * u;
                     if (ry < ny + 2)
-                        v[u] = src[(size_t)reflect101(yr0 - 1 + ry, H) * W + x];
+                        v[u] = src[(size_t)reflect101_near(yr0 - 1 + ry, H) * W + x];
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -1125,7 +1128,7 @@ k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
                 for (int u = 0; u < U; u++) {
                     int ry = j0 + 4 * u;
                     if (ry < nrows)
-                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101(rfirst + ry, H) * W + xs + 4 * c);
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101_near(rfirst + ry, H) * W + xs + 4 * c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -1137,14 +1140,14 @@ k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ 
         }
     } else {
         for (int c = lane; c < ncols; c += 64) {
-            const int x = reflect101(xs + c, W);
+            const int x = reflect101_near(xs + c, W);
             for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
                 uint8_t v[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     int ry = j0 + 4 * u;
                     if (ry < nrows)
-                        v[u] = src[(size_t)reflect101(rfirst + ry, H) * W + x];
+                        v[u] = src[(size_t)reflect101_near(rfirst + ry, H) * W + x];
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
