@@ -679,23 +679,51 @@ k_level_colpass(const float *__restrict__ rowf, float *__restrict__ img, int W, 
     if (dx >= Wk || dy >= Hk)
         return;
     const float *plane = rowf + (size_t)pi * H * NC + 2 * dx;
-    auto row = [&](int y) { return *reinterpret_cast<const float2u *>(plane + (size_t)reflect101(y, H) * NC); };
+    // rows at most r + 1 outside the frame: one reflection does where the frame is taller than that (no loop around
+    // the loads then: the whole column is written twice, under one uniform branch); the taps go four at a time, their
+    // eight rows loaded before the first is used
     const int sy = yofs[dy];
     const int row0 = clampi(sy, 0, H - 1), row1 = clampi(sy + 1, 0, H - 1);
-    const float kc = s_taps[r];
-    const float2u c0 = row(row0);
-    float2u up = row(row0 + 1);   // U[1]
-    float2u down_prev = c0;       // D[0]
-    float2u v0 = kc * c0, v1 = kc * up; // row1 == row0 + 1 wherever v1 is used: its centre is U[1]
-    for (int i = 1; i <= r; i++) {
-        const float k = s_taps[r + i];
-        const float2u down = row(row0 - i);     // D[i]
-        const float2u up_next = row(row0 + i + 1); // U[i + 1]
-        v0 += k * (up + down);
-        v1 += k * (up_next + down_prev);
-        up = up_next;
-        down_prev = down;
-    }
+    float2u v0, v1;
+    auto column = [&](auto reflect) {
+        auto row = [&](int y) { return *reinterpret_cast<const float2u *>(plane + (size_t)reflect(y) * NC); };
+        const float kc = s_taps[r];
+        const float2u c0 = row(row0);
+        float2u up = row(row0 + 1);   // U[1]
+        float2u down_prev = c0;       // D[0]
+        v0 = kc * c0;
+        v1 = kc * up; // row1 == row0 + 1 wherever v1 is used: its centre is U[1]
+        int i = 1;
+        for (; i + 3 <= r; i += 4) {
+            float2u dn[4], un[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dn[q] = row(row0 - (i + q));     // D[i + q]
+                un[q] = row(row0 + (i + q) + 1); // U[i + q + 1]
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float k = s_taps[r + i + q];
+                v0 += k * (up + dn[q]);
+                v1 += k * (un[q] + down_prev);
+                up = un[q];
+                down_prev = dn[q];
+            }
+        }
+        for (; i <= r; i++) {
+            const float k = s_taps[r + i];
+            const float2u down = row(row0 - i);     // D[i]
+            const float2u up_next = row(row0 + i + 1); // U[i + 1]
+            v0 += k * (up + down);
+            v1 += k * (up_next + down_prev);
+            up = up_next;
+            down_prev = down;
+        }
+    };
+    if (H > r + 2)
+        column([&](int y) { return reflect101_once(y, H); });
+    else
+        column([&](int y) { return reflect101(y, H); });
     if (row1 == row0) // both source rows clamp to the same frame row (above the first / below the last)
         v1 = v0;
     const float fx = xfrac[dx], fy = yfrac[dy];
