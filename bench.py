@@ -103,14 +103,17 @@ class ClipSynth:
             return list(ex.map(self.frame, range(lo, hi)))
 
 
-def make_plan(total_frames, batch, rank, world):
-    """Which pairs, frames and passes rank `rank` of `world` owns."""
-    from transflow_amd.batch import batch_starts, frames_needed, shard_range
+def make_plan(total_frames, batch, rank, world, equal=False):
+    """Which pairs, frames and passes rank `rank` of `world` owns.  Shards differ by at
+    most one pair, so the ranks' passes may differ in length (T = 256 over 8 ranks: 32 pairs on seven
+    ranks, 31 on the last); `equal` (--equal-batches) trims every rank's pass to the shortest."""
+    from transflow_amd.batch import batch_starts, frames_needed, pass_pairs, shard_range
     pairs = shard_range(max(0, total_frames - 1), rank, world)
     frames = frames_needed(pairs)
     n = pairs[1] - pairs[0]
+    per_pass = pass_pairs(max(0, total_frames - 1), batch, world, equal)[rank]
     return {"rank": rank, "pairs": list(pairs), "frames": list(frames), "n_pairs": n,
-            "pairs_per_pass": min(batch, n), "pass_starts": batch_starts(n, batch)}
+            "pairs_per_pass": per_pass, "pass_starts": batch_starts(n, per_pass) if per_pass else []}
 
 
 class Job:
@@ -138,9 +141,13 @@ class Job:
             self.reset_mask = (np.random.default_rng(1238).random((h, w), dtype=np.float32)
                                if reset_mask is None else reset_mask)
         self.layer = self.make_layer()
-        # pair i of a pass paints its own image: the pass's frames stay in HBM until the next pass (what a
-        # gather to rank 0 would send)
-        self.comps = [CompImage(h, w, (255, 255, 255)) for _ in range(self.batch)]
+        # pair i of a pass paints its own image: the pass's frames stay in HBM, side by side in one buffer,
+        # until the next pass (what ONE gather to rank 0 sends)
+        from transflow_amd.device import DevBuffer
+        self.frame_bytes = h * w * 3
+        self.out_frames = DevBuffer(self.batch * self.frame_bytes)
+        self.comps = [CompImage(h, w, (255, 255, 255), image_dev=self.out_frames.ptr + i * self.frame_bytes)
+                      for i in range(self.batch)]
         if pixmap_dev is None:
             p = C.c_void_p()
             self.check(self.lib.tf_dev_alloc(C.byref(p), self.pixmap.nbytes))
@@ -288,34 +295,61 @@ def host_description():
     return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cores": usable}
 
 
+def mem_available_bytes():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(job, gate_times):
     """The CPU side of the same workload on this host: the oracle (scalar C port of OpenCV's CPU path +
     the numpy remap) on one thread -- the sample is the parity gate's own oracle work -- and the C port on
-    all usable cores (one frame pair per thread: pairs are independent).  cv2 is timed too where it
-    exists.  Checker code, used here only as the reported baseline."""
+    every usable core (one frame pair per OpenMP thread: pairs are independent; fewer threads only where the
+    host's free memory does not hold one pair's working set per core, and the line says so).  cv2 is timed
+    too where it exists.  Checker code, used here only as the reported baseline."""
     from oracle import farneback as OF
     wl = job.wl
     host = host_description()
     n1 = gate_times["pairs"]
     one = n1 / (gate_times["farneback_s"] + gate_times["remap_s"])
-    cores = max(1, min(host["usable_cores"], 32))
+    # working set of one pair in the C port: level image, blur scratch, two flows, M, two expansions + the result
+    per_pair = wl["w"] * wl["h"] * 4 * (1 + 1 + 4 + 5 + 10 + 2) + (64 << 20)
+    cores = host["usable_cores"]
+    avail = mem_available_bytes()
+    if avail is not None:
+        cores = min(cores, max(1, int(0.6 * avail / per_pair)))
+    cores = max(1, min(cores, int(os.environ.get("TF_BENCH_CPU_THREADS", cores))))
     f0 = job.plan["frames"][0]
     prev, nxt = job.passes[0]
-    n = min(cores, job.batch)
-    fa = [job.synth.frame(f0 + prev[i]) for i in range(n)]
-    fb_ = [job.synth.frame(f0 + nxt[i]) for i in range(n)]
+    have = {}
+
+    def frame(slot):
+        if slot not in have:
+            have[slot] = job.synth.frame(f0 + slot)
+        return have[slot]
+
+    n = cores                                     # one pair per thread; the batch's pairs repeat beyond its length
+    fa = [frame(prev[i % job.batch]) for i in range(n)]
+    fb_ = [frame(nxt[i % job.batch]) for i in range(n)]
     t0 = time.perf_counter()
     OF.calc_batch(fa, fb_, cores, levels=wl["levels"])
     t_all = time.perf_counter() - t0
     remap_per_frame = gate_times["remap_s"] / n1
+    key = "all_cores" if cores == host["usable_cores"] else "multi_core"
     out = {"value": one, "unit": "frames/s", "cores": 1, "kind": "port", "host": host,
            "sample": f"{n1} frame pair(s) of the same workload ({wl['w']}x{wl['h']}, levels={wl['levels']}): C port of "
                      f"OpenCV Farneback {gate_times['farneback_s'] / n1:.2f} s/frame + numpy remap "
                      f"{remap_per_frame:.2f} s/frame, one thread",
-           "all_cores": {"value": n / (t_all + n * remap_per_frame), "farneback_only_value": n / t_all, "unit": "frames/s",
-                         "cores": min(cores, n), "kind": "port",
-                         "sample": f"{n} frame pairs, one per OpenMP thread, {t_all:.2f} s for the C port of Farneback; "
-                                   f"the numpy remap ({remap_per_frame:.2f} s/frame, serial: it is a recurrence) added per frame"}}
+           key: {"value": n / (t_all + n * remap_per_frame), "farneback_only_value": n / t_all, "unit": "frames/s",
+                 "cores": cores, "usable_cores": host["usable_cores"], "kind": "port",
+                 "sample": f"{n} frame pairs, one per OpenMP thread on {cores} of the host's {host['usable_cores']} usable "
+                           f"cores, {t_all:.2f} s for the C port of Farneback; the numpy remap ({remap_per_frame:.2f} "
+                           "s/frame, serial: it is a recurrence) added per frame"}}
     try:
         import cv2
     except ImportError:
@@ -356,53 +390,64 @@ def copy_ceiling(lib, check, nbytes=1 << 30, reps=8):
     return 2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9
 
 
-def gather_leg(job, host, rccl, reps=3):
-    """The gather of BASELINE configs[4], outside the timed region: every rank's frames of its last pass
-    (one image per pair) go to rank 0 through tf_batch_gather.  Checked: rank 0 compares the CRC of what
-    arrived from each rank for pair 0 with the CRC that rank computed of its own frame."""
+def gather_leg(job, host, rccl, plans, reps=3):
+    """The gather of BASELINE configs[4], outside the timed region: every rank's frames of its last pass go
+    to rank 0 in ONE tf_batch_gather per pass -- rank r sends its pairs_per_pass[r] frames (they sit side
+    by side in one buffer), the root posts one receive per rank with that rank's byte count
+    (transflow_amd.batch.gather_counts: the ranks' passes may differ in length, every rank derives the same
+    counts from the all-gathered plans).  Checked: rank 0 compares the CRC of what arrived from each rank
+    (first and last frame of its pass) with the CRCs that rank computed of its own frames."""
+    from transflow_amd.batch import gather_counts
     from transflow_amd.device import DevBuffer
-    w, h = job.wl["w"], job.wl["h"]
-    nbytes = h * w * 3
+    nbytes = job.frame_bytes
     world, rank = host.world, host.rank
-    recv = DevBuffer(world * job.batch * nbytes) if rank == 0 else None
-    own = zlib.crc32(job.comps[0].download().tobytes())
+    per_pass = [p["pairs_per_pass"] for p in plans]
+    assert per_pass[rank] == job.batch
+    counts, offsets = gather_counts(per_pass, nbytes)
+    total = sum(counts)
+    recv = DevBuffer(total) if rank == 0 else None
+    own = [zlib.crc32(job.comps[i].download().tobytes()) for i in (0, job.batch - 1)]
     crcs = host.gather(own)
 
     def once():
-        for i, comp in enumerate(job.comps):
-            rccl.gather_dev(comp.image_ptr(), nbytes, None if recv is None else recv.ptr + i * world * nbytes)
-        job.sync()
+        rccl.gather_dev(job.out_frames.ptr, counts[rank], None if recv is None else recv.ptr,
+                        counts if rank == 0 else None)
 
     once()
+    job.sync()
     ok = None
     if rank == 0:
-        got = recv.download((world, nbytes), np.uint8)
-        ok = all(zlib.crc32(got[r].tobytes()) == crcs[r] for r in range(world))
+        got = recv.download((total,), np.uint8)
+        ok = True
+        for r in range(world):
+            first = got[offsets[r]:offsets[r] + nbytes]
+            last = got[offsets[r] + counts[r] - nbytes:offsets[r] + counts[r]]
+            ok = ok and [zlib.crc32(first.tobytes()), zlib.crc32(last.tobytes())] == list(crcs[r])
     host.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         once()
+    job.sync()
     host.barrier()
     dt = host.max_over_ranks(time.perf_counter() - t0) / reps
     # the rate a step would have with the gather inside it
-    job.sync()
     host.barrier()
     t0 = time.perf_counter()
     n = 5
     for _ in range(n):
         job.step()
-        for i, comp in enumerate(job.comps):
-            rccl.gather_dev(comp.image_ptr(), nbytes, None if recv is None else recv.ptr + i * world * nbytes)
+        once()
     job.sync()
     host.barrier()
     dt_in = host.max_over_ranks(time.perf_counter() - t0) / n
     if recv is not None:
         recv.close()
-    into_root = (world - 1) * job.batch * nbytes
-    return {"what": "untimed region: each rank's frames of one pass (uint8 RGB, one per pair) to rank 0, tf_batch_gather "
-                    "(RCCL send/recv into the root)", "frames_per_gather": world * job.batch, "bytes_into_root": into_root,
-            "ms": dt * 1e3, "GBs_into_root": into_root / dt / 1e9 if dt > 0 else None, "verified_crc": ok,
-            "frames_per_s_with_gather_every_step": world * job.batch / dt_in}
+    into_root = total - counts[0]
+    return {"what": "untimed region: each rank's frames of one pass (uint8 RGB, one per pair, side by side) to rank 0 in "
+                    "one tf_batch_gather (RCCL send/recv into the root, per-rank byte counts)",
+            "frames_per_gather": sum(per_pass), "frames_per_rank": per_pass, "bytes_into_root": into_root,
+            "ms": dt * 1e3, "GBs_into_root": into_root / dt / 1e9 if dt > 0 else None, "verified_crc": bool(ok),
+            "frames_per_s_with_gather_every_step": sum(per_pass) / dt_in}
 
 
 def run_with_timeout(fn, seconds):
@@ -429,10 +474,11 @@ def run_with_timeout(fn, seconds):
 
 
 STUCK_THREADS = False
+EXIT_CODE = 0
 
 
 def main():
-    global STUCK_THREADS
+    global STUCK_THREADS, EXIT_CODE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -444,6 +490,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (the JSON line says so)")
+    ap.add_argument("--equal-batches", action="store_true",
+                    help="trim every rank's pass to the shortest one (T=256 over 8 ranks: 31 pairs everywhere instead of 32 x 7 + 31)")
     ap.add_argument("--rccl", action="store_true", help="use the RCCL legs (broadcast, gather) even with one rank")
     ap.add_argument("--dry-run", action="store_true", help="ranks meet, shard the clip and report the plan; no GPU call")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -465,7 +513,7 @@ def main():
     w, h = wl["w"], wl["h"]
     if args.clip_frames < 2:
         raise SystemExit("--clip-frames must be at least 2")
-    plan = make_plan(args.clip_frames, args.batch, rank, world)
+    plan = make_plan(args.clip_frames, args.batch, rank, world, args.equal_batches)
     plans = host.allgather(plan)
     if args.dry_run:
         if rank == 0:
@@ -572,13 +620,29 @@ def main():
     rank_fps = host.gather(args.steps * job.batch / t_rank)
     oob = host.gather(bool(job.layer.out_of_frame()))
 
+    # Everything the result line needs from the other ranks has been collected by now.  What follows are
+    # untimed side legs: each runs under a time limit and reports its failure in the line instead of losing it.
+    leg_errors = {}
     gather, rccl_version = None, None
     if rccl is not None:
-        gather = gather_leg(job, host, rccl)
         rccl_version = rccl.rccl_version
-        rccl.close()
+
+        def leg():
+            g = gather_leg(job, host, rccl, plans)
+            rccl.close()
+            return g
+
+        try:
+            gather = run_with_timeout(leg, float(os.environ.get("TF_BENCH_LEG_TIMEOUT", 240)))
+        except TimeoutError as err:
+            STUCK_THREADS = True        # a helper thread sits in a call that never returned; the sockets are its
+            rccl.abandon()
+            leg_errors["gather"] = f"TimeoutError: {err}"
+        except BaseException as err:    # noqa: BLE001 -- reported in the line
+            leg_errors["gather"] = f"{type(err).__name__}: {err}"
     if rank != 0:
-        host.close()
+        if not STUCK_THREADS:
+            host.close()
         return
 
     from transflow_amd import roofline as rf
@@ -608,8 +672,9 @@ def main():
                                f"(reset {'random p=0.5 through a float mask, u drawn on the GPU' if wl['reset'] else 'off'}), "
                                "1 RGB pixmap source, render",
                    "clip_frames": args.clip_frames,
-                   "frame_pairs_per_step_per_gpu": P,
-                   "frames_per_step_per_gpu": P + 1,
+                   "frame_pairs_per_step_per_gpu": [p["pairs_per_pass"] for p in plans],
+                   "frame_pairs_per_step": pairs_per_step,
+                   "equal_batches": bool(args.equal_batches),
                    "pairs_per_rank": [p["n_pairs"] for p in plans],
                    "frame_expansions": "pairs t and t+1 of a step share frame t+1: its pyramid levels and polynomial "
                                        "expansion (A1+A2, functions of the frame alone) are computed once per step and "
@@ -649,41 +714,70 @@ def main():
         out["library_options"] = options   # not the defaults: an A/B run
     if gather is not None:
         out["gather"] = gather
+    leg_limit = float(os.environ.get("TF_BENCH_LEG_TIMEOUT", 240))
     if world == 1 and not args.no_cpu_baseline and gate_times is not None:
-        out["cpu_baseline"] = cpu_baseline(job, gate_times)
-    if world == 1 and not args.no_extra:
-        ceiling = copy_ceiling(job.lib, job.check)
-        out["roofline"]["measured_copy_ceiling_GBs"] = ceiling
-        assert achieved <= ceiling * 1.02, f"roofline.achieved {achieved:.0f} GB/s exceeds the measured copy ceiling {ceiling:.0f}"
-        extra = {}
-        for name in ("1080p", "1080p-1level"):
-            if name == args.workload:
-                continue
-            w2 = WORKLOADS[name]
-            # the same bytes per call as the main workload: more pairs of the smaller frames
-            b2 = max(1, min(64, args.batch * (w * h) // (w2["w"] * w2["h"])))
-            j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=local_rank)
-            for _ in range(3):
-                j.step()
-            j.sync()
-            t0 = time.perf_counter()
-            n = 20
-            for _ in range(n):
-                j.step()
-            j.sync()
-            dt = time.perf_counter() - t0
-            sb = rf.built_step_bytes(w2["w"], w2["h"], w2["levels"], b2, reset_mask=w2["reset"], forward=w2["direction"] == 0)
-            extra[name] = {"frames_per_s": n * b2 / dt, "frame_pairs_per_step": b2,
-                           "whole_step_frac_of_8TBs": sb * n / dt / 1e9 / rf.HBM_PEAK_GBS}
-            del j
-        out["other_workloads_untimed_region"] = extra
-    print(json.dumps(out))
-    host.close()
+        try:
+            out["cpu_baseline"] = run_with_timeout(lambda: cpu_baseline(job, gate_times), leg_limit)
+        except BaseException as err:    # noqa: BLE001 -- reported in the line
+            STUCK_THREADS = STUCK_THREADS or isinstance(err, TimeoutError)
+            leg_errors["cpu_baseline"] = f"{type(err).__name__}: {err}"
+    if world == 1 and not args.no_extra and not STUCK_THREADS:
+
+        def extras():
+            ceiling = copy_ceiling(job.lib, job.check)
+            out["roofline"]["measured_copy_ceiling_GBs"] = ceiling
+            # above the copy kernel's rate the byte model would be wrong: flagged in the line, never a lost line
+            out["roofline"]["exceeds_copy_ceiling"] = bool(achieved > ceiling * 1.02)
+            extra = {}
+            for name in ("1080p", "1080p-1level"):
+                if name == args.workload:
+                    continue
+                w2 = WORKLOADS[name]
+                # the same bytes per call as the main workload: more pairs of the smaller frames
+                b2 = max(1, min(64, args.batch * (w * h) // (w2["w"] * w2["h"])))
+                j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=local_rank)
+                g2 = None
+                if not args.no_gate:            # the same gate as the main workload, before its rate is reported
+                    g2, _ = parity_gate(j, n_check=1)
+                    if not g2["ok"]:
+                        extra[name] = {"parity_gate": g2, "frames_per_s": None,
+                                       "error": "parity gate failed: no rate is reported for this workload"}
+                        continue
+                for _ in range(3):
+                    j.step()
+                j.sync()
+                t0 = time.perf_counter()
+                n = 20
+                for _ in range(n):
+                    j.step()
+                j.sync()
+                dt = time.perf_counter() - t0
+                sb = rf.built_step_bytes(w2["w"], w2["h"], w2["levels"], b2, reset_mask=w2["reset"], forward=w2["direction"] == 0)
+                extra[name] = {"frames_per_s": n * b2 / dt, "frame_pairs_per_step": b2,
+                               "whole_step_frac_of_8TBs": sb * n / dt / 1e9 / rf.HBM_PEAK_GBS,
+                               "parity_gate": g2 if g2 is not None else "skipped (--no-gate)"}
+                del j
+            out["other_workloads_untimed_region"] = extra
+
+        try:
+            run_with_timeout(extras, leg_limit)
+        except BaseException as err:    # noqa: BLE001 -- reported in the line
+            STUCK_THREADS = STUCK_THREADS or isinstance(err, TimeoutError)
+            leg_errors["extras"] = f"{type(err).__name__}: {err}"
+    if leg_errors:
+        out["side_leg_errors"] = leg_errors
+    print(json.dumps(out), flush=True)
+    if not STUCK_THREADS:
+        host.close()
+    if out["roofline"].get("exceeds_copy_ceiling"):
+        print("[bench] roofline.achieved exceeds the copy ceiling measured in this run: check the byte model", file=sys.stderr)
+        EXIT_CODE = 5
 
 
 if __name__ == "__main__":
     main()
     sys.stdout.flush()
     sys.stderr.flush()
-    if STUCK_THREADS:      # a helper thread is still inside a call that never returned
-        os._exit(0)
+    if STUCK_THREADS:      # a helper thread is still inside a call that never returned: leave without joining it,
+        os._exit(4)        # and say so (the result line, if this is rank 0, has been printed)
+    sys.exit(EXIT_CODE)

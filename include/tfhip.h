@@ -359,6 +359,10 @@ int tf_remap_set_state(tf_remap *layer, const int32_t *data, const uint8_t *rgba
 
 /* Compositor image (compositor.py:17-40): background colour + output frame. */
 int tf_comp_create(tf_comp **out, int height, int width, const uint8_t background_rgb[3]);
+/* The same with the image in the caller's device memory (H*W*3 bytes at image_dev, which must outlive
+   the handle): the frames of a batch side by side in one buffer are what one tf_batch_gather sends
+   (pipeline.py:518 hands every finished frame to one output). */
+int tf_comp_create_on(tf_comp **out, int height, int width, const uint8_t background_rgb[3], void *image_dev);
 void tf_comp_destroy(tf_comp *comp);
 int tf_comp_begin(tf_comp *comp);                      /* image = background.copy() (:35) */
 int tf_comp_download(tf_comp *comp, uint8_t *rgb_out); /* uint8 [H][W][3] (:40) */

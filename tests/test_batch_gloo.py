@@ -12,7 +12,7 @@ import textwrap
 import numpy as np
 import pytest
 
-from transflow_amd.batch import batch_starts, frames_needed, shard_range
+from transflow_amd.batch import batch_starts, frames_needed, gather_calls, gather_counts, pass_pairs, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -41,6 +41,75 @@ def test_batch_starts_cover_the_shard(n, batch):
         covered.update(range(s, s + size))
     assert covered == set(range(n))
     assert len(starts) == (0 if n == 0 else max(1, -(-n // batch)))
+
+
+def replay_gather(calls):
+    """csrc/batch.hip's posting rules for ONE tf_batch_gather, replayed on the argument lists the ranks pass:
+    a non-root rank posts one Send of send_bytes (none when it is 0); the root posts, for every rank r != root with
+    recv_bytes[r] > 0, one Recv of recv_bytes[r] at recv_dev + sum(recv_bytes[:r]), and copies its own send_bytes
+    locally (which must equal recv_bytes[root]).  Returns the byte ranges written on the root; raises if a Recv
+    has no Send, a Send has no Recv, their sizes differ, or a range leaves the receive buffer."""
+    root = calls[0]["root"]
+    rc = calls[root]
+    assert rc["rank"] == root and rc["recv_bytes"] is not None
+    counts = rc["recv_bytes"]
+    assert len(counts) == len(calls)
+    assert counts[root] == rc["send_bytes"], "root's own count must equal what it sends (TF_ERR_ARG otherwise)"
+    sends = {c["rank"]: c["send_bytes"] for c in calls if c["rank"] != root and c["send_bytes"] > 0}
+    ranges, off = [], 0
+    for r, n in enumerate(counts):
+        lo, off = off, off + n
+        if n == 0:
+            continue
+        assert off <= rc["recv_capacity"], f"rank {r}'s bytes leave the receive buffer"
+        if r != root:
+            assert r in sends, f"the root waits for rank {r}, which sends nothing: deadlock"
+            assert sends.pop(r) == n, f"rank {r} sends a different size than the root expects"
+        ranges.append((r, lo, off))
+    assert not sends, f"ranks {sorted(sends)} send but the root posts no receive: deadlock"
+    return ranges
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("clip_frames", [256, 257, 40])
+@pytest.mark.parametrize("batch,equal", [(32, False), (7, False), (32, True)])
+def test_gather_call_sequence_has_a_send_for_every_receive(world, clip_frames, batch, equal):
+    """The sequence of (rank, send_bytes, recv_bytes[]) bench.py's gather leg passes to tf_batch_gather: with
+    T = 256 over 8 ranks seven ranks hold 32 pairs per pass and the last one 31, and a gather per image (round 2)
+    left the root waiting for a 32nd send rank 7 never made."""
+    sys.path.insert(0, ROOT)
+    import bench
+    frame_bytes = 3840 * 2160 * 3
+    plans = [bench.make_plan(clip_frames, batch, r, world, equal) for r in range(world)]
+    per_pass = [p["pairs_per_pass"] for p in plans]
+    assert per_pass == pass_pairs(clip_frames - 1, batch, world, equal)
+    if equal:
+        assert len(set(per_pass)) == 1 and per_pass[0] == min(min(batch, p["n_pairs"]) for p in plans)
+    else:
+        assert per_pass == [min(batch, p["n_pairs"]) for p in plans]
+    for p in plans:                                        # every pass lies inside the rank's shard
+        for s0 in p["pass_starts"]:
+            assert 0 <= s0 and s0 + p["pairs_per_pass"] <= p["n_pairs"]
+    calls = gather_calls(per_pass, frame_bytes)
+    assert [c["rank"] for c in calls] == list(range(world))  # one call per rank and pass: the same number everywhere
+    ranges = replay_gather(calls)
+    counts, offsets = gather_counts(per_pass, frame_bytes)
+    assert [(r, lo, hi) for r, lo, hi in ranges] == [(r, offsets[r], offsets[r] + counts[r]) for r in range(world) if counts[r]]
+    assert sum(hi - lo for _, lo, hi in ranges) == sum(per_pass) * frame_bytes == calls[0]["recv_capacity"]
+    for (_, _, hi), (_, lo, _) in zip(ranges, ranges[1:]):
+        assert hi == lo                                     # frames of all ranks side by side, no gap, no overlap
+
+
+def test_replay_catches_the_round2_deadlock():
+    """The per-image form of round 2 (equal counts assumed): on the 32nd image rank 7 has nothing to send."""
+    per_pass = pass_pairs(255, 32, 8)
+    assert per_pass == [32] * 7 + [31]
+    nb = 100
+    with pytest.raises(AssertionError, match="deadlock"):
+        for i in range(max(per_pass)):
+            calls = [{"rank": r, "root": 0, "send_bytes": nb if i < per_pass[r] else 0,
+                      "recv_bytes": [nb] * 8 if r == 0 else None, "recv_capacity": 8 * nb} for r in range(8)]
+            replay_gather(calls)
 
 
 WORKER = textwrap.dedent("""
@@ -122,6 +191,13 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
         assert tuple(p["frames"]) == (p["pairs"][0], p["pairs"][1] + 1)        # the halo frame
         assert p["pairs_per_pass"] == min(32, p["n_pairs"])                        # bench.py's default --batch
         assert p["pass_starts"] == batch_starts(p["n_pairs"], 32)
+    if world == 8:                                                               # the case that must not hang
+        assert [p["pairs_per_pass"] for p in d["plans"]] == [32] * 7 + [31]
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--equal-batches"],
+                             env=env, capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        assert [p["pairs_per_pass"] for p in d["plans"]] == [31] * 8
 
 
 def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
@@ -155,3 +231,48 @@ def test_launcher_stops_the_other_ranks_when_one_fails(tmp_path):
     rc = launch_ranks([sys.executable, str(script)], 3)
     assert rc == 15 or rc == 7        # 7 from the failing rank (or 15: SIGTERM's code of a terminated peer, abs())
     assert time.monotonic() - t0 < 30
+
+
+def test_host_group_ignores_a_stranger_and_parses_nothing_it_sends(tmp_path):
+    """The rendezvous file is private (0600, created exclusively) and carries two tokens: a connection that does not
+    present the first is dropped before a byte of it is parsed; messages are JSON, never pickles."""
+    import stat
+    import threading
+    import time
+    from transflow_amd.batch import HostGroup
+    path = str(tmp_path / "rdzv")
+    box = {}
+
+    def rank0():
+        box["g"] = HostGroup(0, 2, path=path, timeout=60)
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    deadline = time.monotonic() + 30
+    while not os.path.exists(path) and time.monotonic() < deadline:
+        time.sleep(0.01)
+    st = os.stat(path)
+    assert stat.S_IMODE(st.st_mode) == 0o600
+    where, hello, answer = open(path).read().split()
+    host, port = where.rsplit(":", 1)
+    import pickle
+    with socket.create_connection((host, int(port))) as bad:       # a stranger: wrong token, then a pickle
+        bad.sendall(b"x" * len(hello) + b"\x01\x00\x00\x00" + pickle.dumps({"boom": 1}))
+        bad.settimeout(10)
+        try:
+            assert bad.recv(64) == b""                               # dropped without an answer
+        except ConnectionResetError:
+            pass                                                     # ... or reset: its bytes were never read
+    g1 = HostGroup(1, 2, path=path, timeout=60)
+    t.join(60)
+    g0 = box["g"]
+    res = {}
+    th = threading.Thread(target=lambda: res.setdefault("r0", g0.allgather({"id": bytes(range(4)), "x": 1.5})))
+    th.start()
+    r1 = g1.allgather({"id": b"\xff", "x": None})
+    th.join(30)
+    assert r1 == res["r0"] == [{"id": bytes(range(4)), "x": 1.5}, {"id": b"\xff", "x": None}]
+    with pytest.raises(TypeError):
+        g1.gather(object())                                          # nothing but plain data travels
+    g0.close()
+    g1.close()

@@ -50,12 +50,45 @@ def test_bench_runs_its_rccl_legs_with_one_rank():
     """bench.py --rccl at a small frame size: shared inputs through tf_batch_broadcast, the gather leg
     verified by CRC, the parity gate on, one JSON line out."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl", "--size", "640x360", "--clip-frames",
-                          "9", "--batch", "4", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                          "40", "--batch", "7", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "rccl_error" not in d
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and "rccl_error" not in d and "side_leg_errors" not in d
     assert d["parity_gate"]["ok"] and d["parity_gate"]["remap_bit_exact"]
-    assert d["gather"]["verified_crc"] is True
-    assert d["config"]["pairs_per_rank"] == [8]
+    assert d["gather"]["verified_crc"] is True and d["gather"]["frames_per_gather"] == 7
+    assert d["gather"]["frames_per_rank"] == [7]
+    assert d["config"]["pairs_per_rank"] == [39] and d["config"]["frame_pairs_per_step_per_gpu"] == [7]
     assert d["value"] > 0
+
+
+def test_compositor_image_in_the_callers_buffer():
+    """tf_comp_create_on: the frames of a batch side by side in one device buffer (what one gather sends)."""
+    from transflow_amd.device import DevBuffer
+    from transflow_amd.remap import CompImage, RemapLayer
+    h, w = 37, 53
+    rng = np.random.default_rng(3)
+    buf = DevBuffer(3 * h * w * 3)
+    comps = [CompImage(h, w, (1, 2, 3), image_dev=buf.ptr + i * h * w * 3) for i in range(3)]
+    own = CompImage(h, w, (1, 2, 3))
+    pix = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(3)]
+    for c, p in zip(comps, pix):
+        layer = RemapLayer(h, w)
+        layer.set_sources([np.ones((h, w), np.uint8)])
+        flow = rng.integers(-2, 3, (h, w, 2)).astype(np.float32)
+        from oracle import remap_ref as OR
+        flow = OR.post_process(flow, OR.BACKWARD)
+        for target in (c, own):
+            lay = RemapLayer(h, w)
+            lay.set_sources([np.ones((h, w), np.uint8)])
+            lay.update(flow)
+            lay.gather(0, p)
+            target.begin()
+            lay.render(target)
+        np.testing.assert_array_equal(c.download(), own.download())
+    whole = buf.download((3, h, w, 3), np.uint8)
+    for i, c in enumerate(comps):
+        np.testing.assert_array_equal(whole[i], c.download())
+    for c in comps:
+        c.close()
+    np.testing.assert_array_equal(buf.download((3, h, w, 3), np.uint8), whole)   # the buffer outlives its handles

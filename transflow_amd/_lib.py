@@ -127,6 +127,7 @@ PROTOTYPES = {
     "tf_remap_get_state": (_I, [_P, _P, _P]),
     "tf_remap_set_state": (_I, [_P, _P, _P]),
     "tf_comp_create": (_I, [_PP, _I, _I, C.POINTER(C.c_uint8)]),
+    "tf_comp_create_on": (_I, [_PP, _I, _I, C.POINTER(C.c_uint8), _P]),
     "tf_comp_destroy": (None, [_P]),
     "tf_comp_begin": (_I, [_P]),
     "tf_comp_download": (_I, [_P, _P]),

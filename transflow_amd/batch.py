@@ -20,8 +20,9 @@ Two transports, neither of them torch:
 from __future__ import annotations
 
 import ctypes as C
+import json
 import os
-import pickle
+import secrets
 import socket
 import struct
 import tempfile
@@ -63,21 +64,101 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def pass_pairs(total_pairs: int, batch: int, world: int, equal: bool = False) -> list[int]:
+    """Pairs per pass of every rank: min(batch, the rank's shard).  Shards differ by at most one pair, so at
+    world = 8 over the 255 pairs of a T = 256 clip seven ranks run 32 pairs per pass and the last one 31.
+    `equal` trims every rank to the smallest of them (each pass then moves the same bytes on every rank)."""
+    sizes = []
+    for r in range(world):
+        a, b = shard_range(total_pairs, r, world)
+        sizes.append(min(int(batch), b - a))
+    if equal and sizes:
+        sizes = [min(sizes)] * world
+    return sizes
+
+
+def gather_counts(pairs_per_pass: list[int], frame_bytes: int) -> tuple[list[int], list[int]]:
+    """(recv_bytes, offsets) of the ONE tf_batch_gather a pass ends with: rank r sends the
+    pairs_per_pass[r] frames of its pass (side by side in one buffer) and they land on the root at
+    offsets[r].  Every rank derives the same lists from the plans, so every Recv the root posts has its
+    Send even when the ranks' passes differ in length."""
+    counts = [int(n) * int(frame_bytes) for n in pairs_per_pass]
+    offsets, off = [], 0
+    for c in counts:
+        offsets.append(off)
+        off += c
+    return counts, offsets
+
+
+def gather_calls(pairs_per_pass: list[int], frame_bytes: int, root: int = 0) -> list[dict]:
+    """The argument list each rank hands to tf_batch_gather for one pass (what bench.py's gather leg does,
+    and what tests/test_batch_gloo.py replays against csrc/batch.hip's posting rules)."""
+    counts, _ = gather_counts(pairs_per_pass, frame_bytes)
+    total = sum(counts)
+    return [{"rank": r, "send_bytes": counts[r], "recv_bytes": counts if r == root else None,
+             "recv_capacity": total if r == root else 0, "root": root} for r in range(len(counts))]
+
+
+# ---- rendezvous ------------------------------------------------------------------------------------
+def _private_dir() -> str:
+    """A directory only this user can enter (0700, owned by us, not a symlink): the rendezvous file of a launch
+    that no launcher named lives here, so no other local user can plant or replace it."""
+    d = os.path.join(tempfile.gettempdir(), f"tfhip-{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"rendezvous directory {d} is not a private directory of this user")
+    return d
+
+
 def rendezvous_path() -> str:
-    """One file per launch.  bench.py's launcher names it (TF_BATCH_RDZV); under
-    torch.distributed.run all ranks are children of one agent process, whose pid with the
-    master port and restart count identifies the launch."""
+    """One file per launch.  bench.py's launcher names it (TF_BATCH_RDZV, inside a fresh 0700 mkdtemp
+    directory); under torch.distributed.run all ranks are children of one agent process, whose pid with
+    the master port and restart count identifies the launch, inside this user's private directory."""
     p = os.environ.get("TF_BATCH_RDZV")
     if p:
         return p
     key = "-".join([os.environ.get("MASTER_PORT", "0"), str(os.getppid()),
                     os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
-                    os.environ.get("TORCHELASTIC_RUN_ID", "none")])
-    return os.path.join(tempfile.gettempdir(), f"tfhip-rdzv-{key}")
+                    "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "none") if c.isalnum())[:32]])
+    return os.path.join(_private_dir(), f"rdzv-{key}")
+
+
+def _encode(obj):
+    """Host messages are JSON (ints, floats, strings, None, lists, dicts); bytes travel as hex under a tag.
+    Nothing that arrives on the socket is ever unpickled."""
+    if isinstance(obj, (bytes, bytearray)):
+        return {"__bytes__": bytes(obj).hex()}
+    if isinstance(obj, dict):
+        return {str(k): _encode(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_encode(v) for v in obj]
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if hasattr(obj, "item"):                  # numpy scalars
+        return _encode(obj.item())
+    raise TypeError(f"HostGroup cannot carry a {type(obj).__name__}")
+
+
+def _decode(obj):
+    if isinstance(obj, dict):
+        if set(obj) == {"__bytes__"}:
+            return bytes.fromhex(obj["__bytes__"])
+        return {k: _decode(v) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_decode(v) for v in obj]
+    return obj
+
+
+MAX_MESSAGE = 1 << 26
 
 
 def _send_msg(sock: socket.socket, obj) -> None:
-    data = pickle.dumps(obj, protocol=4)
+    data = json.dumps(_encode(obj), allow_nan=True).encode()
     sock.sendall(struct.pack("<Q", len(data)) + data)
 
 
@@ -93,43 +174,63 @@ def _recv_exact(sock: socket.socket, n: int) -> bytes:
 
 def _recv_msg(sock: socket.socket):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > MAX_MESSAGE:
+        raise ConnectionError(f"rendezvous message of {n} bytes refused")
+    return _decode(json.loads(_recv_exact(sock, n)))
 
 
 class HostGroup:
     """Host-side star of the ranks of one node: rank 0 listens on an ephemeral port of 127.0.0.1
-    and publishes it through the rendezvous file; every collective is gather-to-0 + answer."""
+    and publishes it, with two random tokens, through the rendezvous file (created exclusively, mode
+    0600, never through a symlink); every collective is gather-to-0 + answer.  A peer must present the
+    first token before anything it sends is parsed, and rank 0 answers with the second, so neither side
+    talks to a process that could not read the file."""
 
     def __init__(self, rank: int | None = None, world: int | None = None, path: str | None = None,
                  timeout: float = 300.0):
         r, _, w = env_world()
         self.rank = r if rank is None else int(rank)
         self.world = w if world is None else int(world)
-        self.path = path or rendezvous_path()
         self.timeout = timeout
         self.peers: list[socket.socket | None] = []
         self.sock: socket.socket | None = None
         if self.world == 1:
+            self.path = path
             return
+        self.path = path or rendezvous_path()
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind(("127.0.0.1", 0))
             srv.listen(self.world)
             srv.settimeout(timeout)
+            hello, answer = secrets.token_hex(16), secrets.token_hex(16)
             tmp = f"{self.path}.{os.getpid()}.tmp"
-            with open(tmp, "w") as f:
-                f.write(f"127.0.0.1:{srv.getsockname()[1]}\n")
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, "w") as f:
+                f.write(f"127.0.0.1:{srv.getsockname()[1]} {hello} {answer}\n")
             os.replace(tmp, self.path)          # atomic: a reader sees nothing or the whole line
             self.peers = [None] * self.world
-            for _ in range(self.world - 1):
+            deadline = time.monotonic() + timeout
+            joined = 0
+            while joined < self.world - 1:
+                if time.monotonic() > deadline:
+                    raise TimeoutError("rendezvous: not every rank arrived")
                 conn, _ = srv.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(10.0)
+                try:
+                    head = _recv_exact(conn, len(hello) + 4)
+                    token, peer = head[:len(hello)].decode("ascii", "replace"), struct.unpack("<i", head[len(hello):])[0]
+                    if not secrets.compare_digest(token, hello) or not (0 < peer < self.world) or self.peers[peer] is not None:
+                        raise ConnectionError("bad token or rank")
+                    conn.sendall(answer.encode())
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()                # a stranger on the port: dropped, nothing of it was parsed
+                    continue
                 conn.settimeout(timeout)
-                peer = _recv_msg(conn)
-                if not (0 < peer < self.world) or self.peers[peer] is not None:
-                    raise RuntimeError(f"rendezvous: unexpected rank {peer}")
                 self.peers[peer] = conn
+                joined += 1
             srv.close()
             try:
                 os.unlink(self.path)            # everyone is in: the file has done its job
@@ -140,9 +241,16 @@ class HostGroup:
             addr = None
             while addr is None:
                 try:
-                    with open(self.path) as f:
+                    fd = os.open(self.path, os.O_RDONLY | os.O_NOFOLLOW)
+                    with os.fdopen(fd) as f:
+                        st = os.fstat(f.fileno())
+                        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                            raise RuntimeError(f"rendezvous file {self.path} is not a private file of this user")
                         line = f.read().strip()
-                    host, port = line.rsplit(":", 1)
+                    where, hello, answer = line.split(" ")
+                    host, port = where.rsplit(":", 1)
+                    if host != "127.0.0.1":
+                        raise RuntimeError(f"rendezvous file {self.path} names {host}, not this node")
                     addr = (host, int(port))
                 except (OSError, ValueError):
                     if time.monotonic() > deadline:
@@ -150,7 +258,9 @@ class HostGroup:
                     time.sleep(0.02)
             self.sock = socket.create_connection(addr, timeout=timeout)
             self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send_msg(self.sock, self.rank)
+            self.sock.sendall(hello.encode() + struct.pack("<i", self.rank))
+            if not secrets.compare_digest(_recv_exact(self.sock, len(answer)).decode("ascii", "replace"), answer):
+                raise ConnectionError("rendezvous: the listener did not know the launch's token")
 
     # -- collectives on host objects ---------------------------------------------------
     def gather(self, obj):

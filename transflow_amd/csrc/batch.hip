@@ -3,11 +3,27 @@
 // frames to rank 0.  Both go through RCCL (xGMI) on the library stream.  librccl is loaded on first
 // use (dlopen), so the drop-in flow source / compositor never map it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 
 #include "common.h"
+
+// The few RCCL types and constants the dlsym'ed entry points need, declared here so that the library
+// builds on a ROCm install without RCCL's development headers (values are NCCL's public ABI: nccl.h's
+// ncclResult_t / ncclDataType_t / ncclRedOp_t, a 128-byte unique id passed by value).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[TF_BATCH_ID_BYTES];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint8 = 1, ncclFloat64 = 8;
+static constexpr ncclRedOp_t ncclSum = 0, ncclMax = 2;
+static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in every NCCL / RCCL release");
 
 namespace tf {
 
@@ -86,8 +102,6 @@ struct tf_batch {
     DevBuf scratch; // the reduction's few doubles
 };
 
-static_assert(TF_BATCH_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "tfhip.h and rccl.h disagree on the id size");
-
 TF_API int tf_batch_unique_id(uint8_t *id)
 {
     TF_REQUIRE(id, "tf_batch_unique_id: null pointer");
@@ -95,7 +109,7 @@ TF_API int tf_batch_unique_id(uint8_t *id)
     TF_TRY(rccl_load());
     ncclUniqueId u;
     TF_RCCL(g_rccl.GetUniqueId(&u));
-    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    memcpy(id, u.internal, TF_BATCH_ID_BYTES);
     return TF_OK;
 }
 
@@ -109,7 +123,7 @@ TF_API int tf_batch_init(tf_batch **out, int rank, int world, const uint8_t *id)
     b->rank = rank;
     b->world = world;
     ncclUniqueId u;
-    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    memcpy(u.internal, id, TF_BATCH_ID_BYTES);
     ncclResult_t r = g_rccl.CommInitRank(&b->comm, world, u, rank);
     if (r != ncclSuccess) {
         delete b;

@@ -96,11 +96,13 @@ inline int launch(const char *name, K kernel, dim3 grid, dim3 block, size_t smem
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false; // p belongs to the caller (tf_comp_create_on): never freed here
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     int alloc(size_t n);
+    void borrow(void *ptr, size_t n);
     void release();
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };

@@ -886,9 +886,8 @@ static int upload(DevBuf &buf, const void *host, size_t bytes)
     return TF_OK;
 }
 
-TF_API int tf_comp_create(tf_comp **out, int height, int width, const uint8_t background_rgb[3])
+static int comp_create(tf_comp **out, int height, int width, const uint8_t background_rgb[3], void *image_dev)
 {
-    TF_REQUIRE(out && background_rgb, "tf_comp_create: null pointer");
     TF_REQUIRE(height >= 0 && width >= 0 && (long long)height * width < (1ll << 31), "tf_comp_create: bad size %dx%d",
                width, height);
     TF_TRY(ensure_init());
@@ -897,13 +896,30 @@ TF_API int tf_comp_create(tf_comp **out, int height, int width, const uint8_t ba
     c->W = width;
     c->N = height * width;
     c->bg = make_uchar4(background_rgb[0], background_rgb[1], background_rgb[2], 0);
-    int rc = c->image.alloc((size_t)c->N * 3);
+    int rc = TF_OK;
+    if (image_dev)
+        c->image.borrow(image_dev, (size_t)c->N * 3);
+    else
+        rc = c->image.alloc((size_t)c->N * 3);
     if (rc != TF_OK) {
         delete c;
         return rc;
     }
     *out = c;
     return tf_comp_begin(c);
+}
+
+TF_API int tf_comp_create(tf_comp **out, int height, int width, const uint8_t background_rgb[3])
+{
+    TF_REQUIRE(out && background_rgb, "tf_comp_create: null pointer");
+    return comp_create(out, height, width, background_rgb, nullptr);
+}
+
+TF_API int tf_comp_create_on(tf_comp **out, int height, int width, const uint8_t background_rgb[3], void *image_dev)
+{
+    TF_REQUIRE(out && background_rgb, "tf_comp_create_on: null pointer");
+    TF_REQUIRE(image_dev || (long long)height * width == 0, "tf_comp_create_on: null image");
+    return comp_create(out, height, width, background_rgb, image_dev);
 }
 
 TF_API void tf_comp_destroy(tf_comp *comp) { delete comp; }

@@ -117,12 +117,21 @@ int DevBuf::alloc(size_t n)
     return TF_OK;
 }
 
+void DevBuf::borrow(void *ptr, size_t n)
+{
+    release();
+    p = ptr;
+    bytes = n;
+    borrowed = true;
+}
+
 void DevBuf::release()
 {
-    if (p)
+    if (p && !borrowed)
         (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    borrowed = false;
 }
 
 // ---- profiler ---------------------------------------------------------------------

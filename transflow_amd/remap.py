@@ -19,12 +19,17 @@ def _ptr(a):
 class CompImage:
     """Background + output frame of Compositor (compositor/compositor.py:17-40)."""
 
-    def __init__(self, height: int, width: int, background_rgb=(255, 255, 255)):
+    def __init__(self, height: int, width: int, background_rgb=(255, 255, 255), image_dev: int | None = None):
+        """image_dev: device address of H*W*3 bytes the caller owns (and keeps alive) for the image --
+        the frames of a batch side by side in one buffer leave in one gather."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.height, self.width = int(height), int(width)
         bg = (C.c_uint8 * 3)(*[int(v) & 255 for v in background_rgb])
-        check(self._lib.tf_comp_create(C.byref(self._h), self.height, self.width, bg))
+        if image_dev is None:
+            check(self._lib.tf_comp_create(C.byref(self._h), self.height, self.width, bg))
+        else:
+            check(self._lib.tf_comp_create_on(C.byref(self._h), self.height, self.width, bg, C.c_void_p(image_dev)))
 
     def begin(self):
         check(self._lib.tf_comp_begin(self._h))
