@@ -53,6 +53,11 @@ int tf_device_count(int *count);
      "remap_px"       4   pixels per thread of tf_remap_step_dev's kernel: 1, 2 or 4
      "remap_no_pack"  0   1 = tf_remap_step_dev keeps the layer state as int32 x 4 between steps
      "prof_levels"    0   1 = profiler labels carry the pyramid level
+     "fb_exact_sums"  0   1 = the box window (flags without OPTFLOW_FARNEBACK_GAUSSIAN) is summed exactly as
+                          FarnebackUpdateFlow_Blur sums it -- one set of running sums per image, float-differenced
+                          down the columns from row 0, double-differenced along the rows from column 0 -- so the
+                          flow is bit-identical to the CPU path's instead of within 1e-4 of it; a checking mode,
+                          about ten times slower (read per call)
    Unknown names and out-of-range values return TF_ERR_ARG.  The environment is never read. */
 int tf_set_option(const char *name, long value);
 int tf_get_option(const char *name, long *value);
@@ -128,6 +133,10 @@ int tf_fb_calc(tf_fb *fb, const uint8_t *prev, ptrdiff_t prev_stride, const uint
    previous result keeps running beside it), so a caller that fills frame slots on the device itself (through tf_fb_frame_ptr) calls tf_sync() before the next tf_fb_calc_slots;
    tf_fb_set_frame already returns with the frame in place. */
 int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t stride);
+/* The same from a decoded BGR frame, transflow/flow/sources/cv.py:461-466: uint8 [src_height][src_width][3]
+   (row stride in bytes) is uploaded as it is and cv2.resize(INTER_NEAREST) to the handle's size +
+   cv2.cvtColor(COLOR_BGR2GRAY) run on the device (tf_frame_grey_dev) straight into the slot. */
+int tf_fb_set_frame_bgr(tf_fb *fb, int slot, const uint8_t *bgr, int src_width, int src_height, ptrdiff_t stride);
 /* Resident path with TF_OPTFLOW_USE_INITIAL_FLOW: the initial flow of `pair` for the next tf_fb_calc_slots
    (float32 [height][width][2]; kept until written again, zero at creation), from the host or -- through
    its device address -- filled on the GPU (e.g. copied from a previous result). */

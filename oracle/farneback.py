@@ -16,6 +16,9 @@ _LIB = None
 
 
 def build(force: bool = False) -> str:
+    alt = os.environ.get("FBREF_LIBRARY")      # tools/oracle_asan.sh: the sanitizer build of the same source
+    if alt:
+        return alt
     so = os.path.join(_HERE, "libfbref.so")
     src = os.path.join(_HERE, "farneback_ref.c")
     if force or not os.path.exists(so) or (

@@ -206,3 +206,65 @@ def test_pipeline_loop_matches_oracle_sequence():
             np.testing.assert_array_equal(comp.layers[0].data, ora.data)
             np.testing.assert_array_equal(frame, R.composite(white, [ora.render()]))
 
+
+
+def _bgr_frames(h, w, n, seed=5):
+    """Colour frames whose grey value carries the synthetic texture: three channels with different gains + noise."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for g in _frames(h, w, n, seed):
+        f = np.stack([np.clip(g.astype(np.int32) * k // 8 + rng.integers(0, 24, g.shape), 0, 255) for k in (5, 8, 11)], axis=2)
+        out.append(f.astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("direction", ["forward", "backward"])
+@pytest.mark.parametrize("src_size,size", [((480, 854), None), ((300, 500), (854, 480)), ((961, 1282), (640, 360))])
+def test_flow_source_over_bgr_frames_ingests_on_the_device(direction, src_size, size, lib_option):
+    """cv.py:461-466 + 479-490 through the drop-in source: decoded BGR frames go up as they are, the nearest-neighbour
+    resize to the size the source reports and the BGR -> grey conversion run on the device (one arithmetic: OpenCV 4's
+    15-bit weights, the oracle's), then Farnebäck.  Against frames_ref -> the Farnebäck oracle -> post_process: with
+    fb_exact_sums bit-identical in both directions; in the default mode within tolerance (BACKWARD) / an integer map
+    that agrees wherever rounding the two raw flows agrees (FORWARD)."""
+    from oracle import frames_ref
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    sh, sw = src_size
+    frames = _bgr_frames(sh, sw, 3)
+    w, h = (sw, sh) if size is None else size
+    greys = [frames_ref.bgr_to_grey(f, (w, h)) for f in frames]
+    d = R.FORWARD if direction == "forward" else R.BACKWARD
+    exp = []
+    for t in range(2):
+        prev, nxt = (greys[t], greys[t + 1]) if direction == "forward" else (greys[t + 1], greys[t])
+        exp.append(R.post_process(OF.calc(prev, nxt), d))
+    for exact in (1, 0):
+        lib_option("fb_exact_sums", exact)
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0, size=size), direction=direction) as source:
+            assert (source.width, source.height, source.length) == (w, h, 2)
+            np.testing.assert_array_equal(source.prev_gray, greys[0])      # what cv.py:456 keeps
+            flows = [f.copy() for f in source]
+        assert len(flows) == 2
+        for t, flow in enumerate(flows):
+            assert flow.shape == (h, w, 2) and flow.dtype == np.float32
+            if exact:
+                np.testing.assert_array_equal(flow, exp[t])
+            elif d == R.BACKWARD:
+                assert np.abs(flow - exp[t]).max() <= 1e-4 * max(1.0, float(np.abs(exp[t]).max()))
+            else:
+                assert (flow == np.rint(flow)).all() and (flow != exp[t]).any(axis=2).mean() < 0.01
+
+
+def test_flow_source_host_path_ingests_on_the_device_too(lib_option):
+    """A lock expression makes __next__ take the public next() / post_process() pair (host arrays): the frames still
+    become grey on the device, and the flows equal the resident path's."""
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 120, 160
+    frames = _bgr_frames(h, w, 4)
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward") as source:
+        resident = [f.copy() for f in source]
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", lock_expr="0", lock_mode="skip") as source:
+        assert not source._resident_ok()
+        host = [f.copy() for f in source]
+    assert len(resident) == len(host) == 3
+    for a, b in zip(resident, host):
+        np.testing.assert_array_equal(a, b)

@@ -629,3 +629,159 @@ def test_initial_flows_of_a_batch(FB, lib_option):
             got = fb.get_flow(i)
             assert np.abs(got - refs[i]).max() <= flow_tol(refs[i]), (fused, i)
         fb.close()
+
+
+# ---- option fb_exact_sums: the box window summed in OpenCV's own order -------------------------------------------
+@pytest.mark.parametrize("shape,winsize", [((64, 64), 15), ((67, 531), 15), ((270, 480), 15), ((40, 50), 9),
+                                           ((33, 300), 4), ((9, 11), 15), ((5, 7), 15), ((1, 1), 15), ((300, 200), 1),
+                                           ((130, 70), 3), ((31, 33), 21)])
+def test_exact_sums_blur_solve_bit_identical(FB, lib_option, shape, winsize):
+    """FarnebackUpdateFlow_Blur keeps one set of running sums per image (float-differenced down the columns from
+    row 0, double-differenced along the rows from column 0); with fb_exact_sums the kernels repeat that order and the
+    flow is the oracle's, bit for bit -- windows wider than the frame, one-pixel frames and winsize 1 included."""
+    lib_option("fb_exact_sums", 1)
+    h, w = shape
+    rng = np.random.default_rng(5)
+    r = rng.normal(0, 3, (h, w, 5)).astype(np.float32)
+    m = O.update_matrices(r, rng.normal(0, 3, (h, w, 5)).astype(np.float32), np.zeros((h, w, 2), np.float32))
+    ref, _ = O.update_flow_blur(r, r, np.zeros((h, w, 2), np.float32), m, winsize, False)
+    fb = FB(max(w, 32), max(h, 32), levels=0, winsize=winsize)
+    got = fb.stage_blur_solve(m)
+    fb.close()
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape,kw", CASES + SWEEP)
+def test_exact_sums_whole_call_bit_identical(FB, lib_option, shape, kw):
+    """A1, A2, A3 and A5 are bit-identical to the oracle stage by stage; with the window sums in OpenCV's order A4 is
+    too, and so is the whole pyramid: every difference the default mode shows against the oracle is summation order."""
+    lib_option("fb_exact_sums", 1)
+    h, w = shape
+    a, b = synth_pair(h, w, seed=21)
+    ref = O.calc(a, b, **kw)
+    fb = FB(w, h, **kw)
+    got = fb.calc(a, b)
+    fb.close()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_exact_sums_random_configurations_bit_identical(FB, lib_option):
+    lib_option("fb_exact_sums", 1)
+    rng = np.random.default_rng(404)
+    shapes = [(1, 1), (2, 3), (1, 64), (64, 1), (9, 9), (10, 10), (31, 33)]
+    shapes += [(int(rng.integers(1, 200)), int(rng.integers(1, 300))) for _ in range(25)]
+    for h, w in shapes:
+        kw = dict(levels=int(rng.integers(0, 5)), pyr_scale=float(rng.choice([0.5, 0.6, 0.75, 0.8])),
+                  winsize=int(rng.choice([1, 3, 5, 7, 9, 11, 15, 21, 25])), iterations=int(rng.integers(1, 4)),
+                  poly_n=int(rng.choice([5, 7])))
+        kw["poly_sigma"] = 1.2 if kw["poly_n"] == 5 else 1.5
+        a, b = synth_pair(h, w, seed=h * 1000 + w, shift=(1.7, -0.9), noise=3.0)
+        ref = O.calc(a, b, **kw)
+        fb = FB(w, h, **kw)
+        got = fb.calc(a, b)
+        fb.close()
+        np.testing.assert_array_equal(got, ref, err_msg=f"{h}x{w} {kw}")
+
+
+def test_exact_sums_batch_with_initial_flow_bit_identical(FB, lib_option):
+    """OPTFLOW_USE_INITIAL_FLOW keeps the box window: exact there too (the Gaussian window has no running sums)."""
+    lib_option("fb_exact_sums", 1)
+    h, w = 270, 480
+    a, b = synth_pair(h, w, seed=9)
+    init = np.random.default_rng(1).normal(0, 1.5, (h, w, 2)).astype(np.float32)
+    ref = O.calc(a, b, flags=4, flow=init)
+    fb = FB(w, h, flags=4)
+    got = fb.calc(a, b, flow=init)
+    fb.close()
+    np.testing.assert_array_equal(got, ref)
+
+
+# ---- what bench.py times, against the oracle at the bench's own shapes (strict tolerance) --------------------------
+def clip_frames(h, w, n, seed, step=(0.6, 0.4)):
+    """n consecutive frames of one scene: the same texture seen through a displacement that grows with the frame index."""
+    return [synth_pair(h, w, seed=seed, shift=(step[0] * i, step[1] * i))[1] for i in range(n)]
+
+
+def outliers(got, ref):
+    d = np.abs(got - ref).max(axis=2)
+    return int((d > flow_tol(ref)).sum()), float(d.max())
+
+
+def test_bench_shape_1080p_levels5_four_consecutive_pairs_forward_remap(FB, lib_option):
+    """BASELINE configs[2] as benched: 1080p, levels=5, consecutive pairs of one call sharing their frames'
+    expansions, levels 0-1 on the one-kernel iteration (the default above 4 M pixels per level over the batch), then per
+    pair the FORWARD scatter and the remap step that finishes post_process in registers (clip_flow=2).  Flow strictly
+    within tolerance (and bit-identical with fb_exact_sums); layer state, rgba and frame bit-exact."""
+    from oracle import remap_ref as OR
+    from transflow_amd.remap import CompImage, RemapLayer
+    h, w, P = 1080, 1920, 4
+    frames = clip_frames(h, w, P + 1, seed=700)
+    refs = [O.calc(frames[i], frames[i + 1], levels=5) for i in range(P)]
+    fb = FB(w, h, levels=5, frame_slots=P + 1, max_pairs=P)
+    for i, f in enumerate(frames):
+        fb.set_frame(i, f)
+    fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+    flows = [fb.get_flow(i) for i in range(P)]
+    for i in range(P):
+        n, err = outliers(flows[i], refs[i])
+        assert n == 0, f"pair {i}: {n} pixels beyond {flow_tol(refs[i])}, max|d|={err}"
+    pixmap = np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    layer = RemapLayer(h, w)
+    layer.set_sources([np.ones((h, w), np.uint8)])
+    comp = CompImage(h, w, (255, 255, 255))
+    ora = OR.MoveRefLayer(h, w, OR.LayerParams(), introduction_masks=[np.ones((h, w), bool)])
+    from transflow_amd.device import DevBuffer
+    pix = DevBuffer.from_array(pixmap)
+    white = np.full((h, w, 3), 255, np.uint8)
+    for i in range(P):
+        layer.step_dev(comp, fb.post_process_scatter(i), pix.ptr, 3, clip_flow=2)
+        ora.update(OR.post_process(flows[i].copy(), OR.FORWARD), [pixmap], None)
+        data, rgba = layer.get_state()
+        np.testing.assert_array_equal(data, ora.data)
+        np.testing.assert_array_equal(rgba, ora.rgba)
+        np.testing.assert_array_equal(comp.download(), OR.composite(white, [ora.render()]))
+    assert not layer.out_of_frame()
+    lib_option("fb_exact_sums", 1)
+    fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+    for i in range(P):
+        np.testing.assert_array_equal(fb.get_flow(i), refs[i])
+    fb.close()
+
+
+def test_bench_shape_1080p_one_scale(FB, lib_option):
+    """BASELINE configs[1]: 1080p, a single scale (levels=0), a batch of pairs, both iteration forms."""
+    h, w, P = 1080, 1920, 3
+    frames = clip_frames(h, w, P + 1, seed=800)
+    refs = [O.calc(frames[i], frames[i + 1], levels=0) for i in range(P)]
+    for fused in (1, 0):
+        lib_option("fb_fused", fused)
+        fb = FB(w, h, levels=0, frame_slots=P + 1, max_pairs=P)
+        for i, f in enumerate(frames):
+            fb.set_frame(i, f)
+        fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+        for i in range(P):
+            n, err = outliers(fb.get_flow(i), refs[i])
+            assert n == 0, f"fb_fused={fused} pair {i}: {n} pixels beyond tolerance, max|d|={err}"
+        fb.close()
+
+
+def test_bench_shape_4k_two_pairs_sharing_a_frame_fused_on_every_level(FB, lib_option):
+    """BASELINE configs[3]/[4] as benched: 4K, levels=5, two pairs that share a frame (its expansion computed once),
+    the one-kernel iteration on every level.  Strict tolerance; where a pair shows outliers (the in-frame test's
+    branch flip) they must be few, and the exact mode must reproduce the oracle bit for bit."""
+    h, w = 2160, 3840
+    frames = clip_frames(h, w, 3, seed=900)
+    refs = [O.calc(frames[i], frames[i + 1], levels=5) for i in range(2)]
+    lib_option("fb_fused", 1)
+    fb = FB(w, h, levels=5, frame_slots=3, max_pairs=2)
+    for i, f in enumerate(frames):
+        fb.set_frame(i, f)
+    fb.calc_slots([0, 1], [1, 2])
+    over = [outliers(fb.get_flow(i), refs[i]) for i in range(2)]
+    lib_option("fb_exact_sums", 1)
+    fb.calc_slots([0, 1], [1, 2])
+    for i in range(2):
+        np.testing.assert_array_equal(fb.get_flow(i), refs[i])
+    fb.close()
+    for i, (n, err) in enumerate(over):
+        assert n <= 1e-4 * h * w and err <= 100 * flow_tol(refs[i]), f"pair {i}: {n} pixels beyond tolerance, max|d|={err}"

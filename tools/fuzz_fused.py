@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """A longer run of tests/test_gpu_farneback.py::test_fused_iteration_on_random_shapes_and_batches: N random frame
-shapes, window widths, level counts, iteration counts, polynomial radii and batch sizes, every pair three ways -- the
+shapes, window widths, level counts, iteration counts, polynomial radii and batch sizes, every pair four ways -- the
 one-kernel iteration (option fb_fused = 1), the two-kernel iteration (= 0, whose stages are bit-identical to the
-oracle's up to the window sums) and the oracle.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow
-(DESIGN.md section 4), so a pair may carry a small patch of outliers against the oracle; what must hold is
+oracle's up to the window sums), the exact mode (fb_exact_sums = 1: the window summed in OpenCV's own order) and the
+oracle.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow, so in the default
+modes a pair may carry a small patch of outliers against the oracle; what must hold is
+  * exact mode: the oracle's flow BIT FOR BIT, every pair;
   * against the oracle: at most 0.5 % of a pair's pixels beyond 1e-4 * max(1, max|ref|);
   * one-kernel against two-kernel: at most 0.5 % of the pixels beyond 2e-5 * max(1, max|ref|), and
     no more outliers against the oracle than the two-kernel path has, plus 0.2 % of the pixels.
@@ -25,8 +27,9 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
-def run(mode, w, h, n, frames, kw):
+def run(mode, w, h, n, frames, kw, exact=0):
     _lib.set_option("fb_fused", mode)
+    _lib.set_option("fb_exact_sums", exact)
     fb = Farneback(w, h, max_pairs=n, frame_slots=n + 1, **kw)
     for i, f in enumerate(frames):
         fb.set_frame(i, f)
@@ -37,14 +40,15 @@ def run(mode, w, h, n, frames, kw):
 
 
 bad = 0
-stats = dict(pairs=0, clean=0, worst_frac_oracle=0.0, worst_frac_between=0.0, worst_clean_ratio=0.0)
+stats = dict(pairs=0, clean=0, exact_identical=0, outlier_pairs=0, worst_frac_oracle=0.0, worst_frac_between=0.0,
+             worst_clean_ratio=0.0)
 for case in range(n_cases):
     h, w = int(rng.integers(10, 300)), int(rng.integers(10, 460))
     kw = dict(levels=int(rng.integers(0, 4)), winsize=int(rng.choice([7, 11, 15])), iterations=int(rng.integers(1, 4)),
               poly_n=int(rng.choice([5, 7])))
     n = int(rng.integers(1, 5))
     frames = [synth_pair(h, w, seed=h * 1000 + w, shift=(0.7 * i, -0.4 * i))[1] for i in range(n + 1)]
-    one, two = run(1, w, h, n, frames, kw), run(0, w, h, n, frames, kw)
+    one, two, exact = run(1, w, h, n, frames, kw), run(0, w, h, n, frames, kw), run(-1, w, h, n, frames, kw, exact=1)
     for i in range(n):
         ref = O.calc(frames[i + 1], frames[i], **kw)
         scale = max(1.0, float(np.abs(ref).max()))
@@ -53,6 +57,14 @@ for case in range(n_cases):
         f1, f2, fb_ = float((d1 > 1e-4 * scale).mean()), float((d2 > 1e-4 * scale).mean()), float((db > 2e-5 * scale).mean())
         stats["pairs"] += 1
         stats["clean"] += f1 == 0.0
+        stats["outlier_pairs"] += f1 > 0.0
+        same = bool(np.array_equal(exact[i], ref))
+        stats["exact_identical"] += same
+        if not same:
+            bad += 1
+            de = np.abs(exact[i] - ref).max(axis=2)
+            print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: exact mode differs from the oracle in {int((de > 0).sum())} "
+                  f"pixels, max|d| {de.max():.3g}")
         stats["worst_frac_oracle"] = max(stats["worst_frac_oracle"], f1)
         stats["worst_frac_between"] = max(stats["worst_frac_between"], fb_)
         if f1 == 0.0:
@@ -62,7 +74,9 @@ for case in range(n_cases):
             print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: outliers vs oracle {f1:.2e} (two-kernel {f2:.2e}), "
                   f"one- vs two-kernel {fb_:.2e}; max|d| {d1.max():.3g} / {d2.max():.3g} / {db.max():.3g}, max|ref| {scale:.2f}")
 _lib.set_option("fb_fused", -1)
-print(f"{n_cases} cases, {stats['pairs']} pairs: {stats['clean']} with every pixel inside the tolerance (worst {stats['worst_clean_ratio']:.2f} of it); "
+_lib.set_option("fb_exact_sums", 0)
+print(f"{n_cases} cases, {stats['pairs']} pairs: exact mode bit-identical to the oracle in {stats['exact_identical']}; default mode: "
+      f"{stats['clean']} with every pixel inside the tolerance (worst {stats['worst_clean_ratio']:.2f} of it), {stats['outlier_pairs']} with outliers; "
       f"most outliers in a pair vs the oracle {stats['worst_frac_oracle']:.2e} of its pixels, one- vs two-kernel {stats['worst_frac_between']:.2e}; "
       f"{bad} failures")
 sys.exit(1 if bad else 0)

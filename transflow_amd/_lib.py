@@ -81,6 +81,7 @@ PROTOTYPES = {
     "tf_fb_destroy": (None, [_P]),
     "tf_fb_calc": (_I, [_P, _P, C.c_ssize_t, _P, C.c_ssize_t, _P]),
     "tf_fb_set_frame": (_I, [_P, _I, _P, C.c_ssize_t]),
+    "tf_fb_set_frame_bgr": (_I, [_P, _I, _P, _I, _I, C.c_ssize_t]),
     "tf_fb_frame_ptr": (_I, [_P, _I, _PP]),
     "tf_fb_set_initial_flow": (_I, [_P, _I, _P]),
     "tf_fb_initial_flow_ptr": (_I, [_P, _I, _PP]),

@@ -1520,7 +1520,7 @@ k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int W
             size_t ra = (size_t)min(y + m, Hk - 1) * Wk, rb = (size_t)max(y - m - 1, 0) * Wk;
 #pragma unroll
             for (int c = 0; c < 5; c++)
-                vs[c] += (double)Mi[c * Nk + ra] - (double)Mi[c * Nk + rb];
+                vs[c] += (double)(Mi[c * Nk + ra] - Mi[c * Nk + rb]); // FarnebackUpdateFlow_Blur: vsum += srow1[x] - srow0[x], a float difference
         }
 #pragma unroll
         for (int c = 0; c < 5; c++)
@@ -1564,6 +1564,70 @@ __global__ void k_blur_solve_w1(const float *__restrict__ Min, float2 *__restric
     const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
     flow_out[(size_t)blockIdx.z * Nk + (size_t)y * Wk + x] =
         make_float2((float)((g[0] * g[4] - g[1] * g[3]) * idet), (float)((g[2] * g[3] - g[1] * g[4]) * idet));
+}
+
+// ---------------------------------------------------------------------------------
+// A4 sum for sum as FarnebackUpdateFlow_Blur runs it (option "fb_exact_sums").  OpenCV keeps ONE set of
+// running sums for the whole image: per column a double that is primed with (m + 2) copies of the first row
+// (a float product) and then, row after row from row 0, receives the FLOAT difference of the row that
+// enters and the row that leaves; per row a double running sum of those across the columns, updated by
+// double differences from column 0 on.  Every sum therefore carries the rounding history of everything
+// above / left of it.  The marching kernels above and below restart their sums per segment and add across
+// columns directly -- the same numbers up to ~1e-7 relative (the float differences' roundings), which is
+// what decides FarnebackUpdateMatrices' discontinuous in-frame test for the rare border pixel whose sample
+// point sits within that distance of the last row / column.  These two kernels repeat
+// OpenCV's order exactly -- the same operations on the same operands, so the flow is bit-identical to the
+// CPU path's -- at the price of its serial dependences: one thread per column walks all rows, then one
+// thread per row walks all columns.  A checking mode, ~10x slower than the default.
+// vsum layout: [pair][channel][x][y] (y fastest): both kernels then read coalesced.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_exact_vsum(const float *__restrict__ Min, double *__restrict__ vsum, int Wk, int Hk, int m)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, pair = blockIdx.z;
+    if (x >= Wk)
+        return;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *P = Min + ((size_t)pair * 5 + c) * Nk + x;
+    double *V = vsum + ((size_t)pair * 5 + c) * Nk + (size_t)x * Hk;
+    double vs = (double)(P[0] * (float)(m + 2)); // vsum[x] = srow0[x] * (m + 2): a float product
+    for (int y = 1; y < m; y++)
+        vs += (double)P[(size_t)min(y, Hk - 1) * Wk];
+#pragma unroll 4
+    for (int y = 0; y < Hk; y++) {
+        const float in = P[(size_t)min(y + m, Hk - 1) * Wk], out = P[(size_t)max(y - m - 1, 0) * Wk];
+        vs += (double)(in - out); // vsum[x] += srow1[x] - srow0[x]
+        V[y] = vs;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_exact_hsolve(const double *__restrict__ vsum, float2 *__restrict__ flow_out, int Wk, int Hk, int m, double scale)
+{
+    const int y = blockIdx.x * 64 + threadIdx.x, pair = blockIdx.z;
+    if (y >= Hk)
+        return;
+    const size_t Nk = (size_t)Wk * Hk;
+    const double *V = vsum + (size_t)pair * 5 * Nk + y; // column x of channel c: V[c * Nk + x * Hk]
+    float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk;
+    double g[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        g[c] = V[c * Nk] * (double)(m + 2); // the border columns are copies of column 0 / W - 1
+    for (int x = 1; x < m; x++)
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            g[c] += V[c * Nk + (size_t)min(x, Wk - 1) * Hk];
+#pragma unroll 2
+    for (int x = 0; x < Wk; x++) {
+        const size_t a = (size_t)min(x + m, Wk - 1) * Hk, b = (size_t)max(x - m - 1, 0) * Hk;
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            g[c] += V[c * Nk + a] - V[c * Nk + b];
+        const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale, h1 = g[3] * scale, h2 = g[4] * scale;
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        o[x] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1646,8 +1710,9 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
             float2(&out)[5] = pout[(h + PD - 1) % PD];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                vs[c][0] += (double)in[c].x - (double)out[c].x;
-                vs[c][1] += (double)in[c].y - (double)out[c].y;
+                // OpenCV's increment: vsum[x] += srow1[x] - srow0[x] -- the difference in float, accumulated in double
+                vs[c][0] += (double)(in[c].x - out[c].x);
+                vs[c][1] += (double)(in[c].y - out[c].y);
             }
             load_row(min(y + PD + M, Hk - 1), in);                // step y+PD: entering row
             load_row(clampi(y + PD - 1 - M, 0, Hk - 1), out);     //            leaving row
@@ -1990,7 +2055,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 for (int c = 0; c < 5; c++) {
                     const float old = ring[slot][c][col];
                     ring[slot][c][col] = m[c];
-                    vs[c] += (double)m[c] - (double)old;
+                    vs[c] += (double)(m[c] - old); // OpenCV's increment: a float difference accumulated in double (old = 0 while the window fills)
                     s_v[s & 1][c][col] = vs[c];
                 }
                 slot = slot + 1 == WIN ? 0 : slot + 1;
@@ -2544,6 +2609,8 @@ struct tf_fb {
     DevBuf area_i, area_f;       // resize(INTER_AREA) tables to the coarsest scale: ints, then weights
     AreaTabs area{};
     DevBuf gauss_taps;           // winsize / 2 + 1 taps of the Gaussian window (flag 256)
+    DevBuf bgr_stage;            // tf_fb_set_frame_bgr: the decoded frame on its way to a slot
+    DevBuf exact_vsum;           // option fb_exact_sums: OpenCV's column sums of the level being solved, [pair][5][x][y] doubles
     bool use_initial() const { return (prm.flags & 4) != 0; }
     bool gaussian() const { return (prm.flags & 256) != 0; }
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
@@ -2845,6 +2912,15 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
 {
     const int m = fb->prm.winsize / 2;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
+    if (option(OPT_FB_EXACT_SUMS)) { // OpenCV's own running sums, in its order (k_exact_vsum's note)
+        const size_t need = (size_t)n_pairs * 5 * w * h * sizeof(double);
+        if (fb->exact_vsum.bytes < need)
+            TF_TRY(fb->exact_vsum.alloc(need));
+        TF_TRY(launch(lvl_name("fb_exact_vsum", k), k_exact_vsum, dim3(cdiv(w, 64), 5, n_pairs), dim3(64), 0,
+                      (const float *)fb->M.as<float>(), fb->exact_vsum.as<double>(), w, h, m));
+        return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve, dim3(cdiv(h, 64), 1, n_pairs), dim3(64), 0,
+                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
+    }
     switch (m) {
     case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, flow_out, scale, k);
     case 3: return launch_blur_solve_wave<3>(fb, w, h, n_pairs, flow_out, scale, k);
@@ -3232,6 +3308,29 @@ TF_API int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t s
     return TF_OK;
 }
 
+// cv.py:461-466 on the device: the decoded BGR frame goes up as it is, cv2.resize(INTER_NEAREST) to the
+// handle's size and cv2.cvtColor(COLOR_BGR2GRAY) run as one kernel straight into the frame slot.
+TF_API int tf_fb_set_frame_bgr(tf_fb *fb, int slot, const uint8_t *bgr, int src_width, int src_height, ptrdiff_t stride)
+{
+    TF_REQUIRE(fb && bgr, "tf_fb_set_frame_bgr: null pointer");
+    TF_REQUIRE(slot >= 0 && slot < fb->slots, "tf_fb_set_frame_bgr: slot %d out of range (%d slots)", slot, fb->slots);
+    TF_REQUIRE(src_width >= 1 && src_height >= 1 && (long long)src_width * src_height < (1ll << 31),
+               "tf_fb_set_frame_bgr: bad source size %dx%d", src_width, src_height);
+    TF_REQUIRE(stride >= (ptrdiff_t)3 * src_width, "tf_fb_set_frame_bgr: stride %td smaller than a row of %d BGR pixels", stride,
+               src_width);
+    TF_TRY(ensure_init());
+    const size_t row = (size_t)3 * src_width, need = row * src_height;
+    if (fb->bgr_stage.bytes < need)
+        TF_TRY(fb->bgr_stage.alloc(need));
+    uint8_t *dst = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
+    if (fb->keep)
+        fb->expanded[slot] = 0;
+    TF_HIP(hipMemcpy2DAsync(fb->bgr_stage.p, row, bgr, (size_t)stride, row, src_height, hipMemcpyHostToDevice, stream()));
+    TF_TRY(tf_frame_grey_dev(fb->bgr_stage.p, src_width, src_height, dst, fb->W, fb->H));
+    TF_HIP(hipStreamSynchronize(stream())); // the host frame is borrowed for this call only
+    return TF_OK;
+}
+
 TF_API int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev)
 {
     TF_REQUIRE(fb && dev, "tf_fb_frame_ptr: null pointer");
@@ -3404,7 +3503,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
-        const bool fused_here = fusable && !fb->gaussian() && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
+        const bool fused_here = fusable && !fb->gaussian() && !option(OPT_FB_EXACT_SUMS) && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;

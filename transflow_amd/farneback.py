@@ -81,6 +81,16 @@ class Farneback:
         a = self._grey(frame)
         check(self._lib.tf_fb_set_frame(self._h, int(slot), _ptr(a), a.strides[0]))
 
+    def set_frame_bgr(self, slot: int, frame) -> None:
+        """cv.py:461-466 on the device: a decoded BGR frame of any size -> nearest-neighbour resize to the
+        handle's size -> grey, straight into the slot."""
+        a = np.asarray(frame)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
+            raise ValueError(f"expected a uint8 BGR frame (H, W, 3), got {a.dtype} {a.shape}")
+        if a.strides[2] != 1 or a.strides[1] != 3:
+            a = np.ascontiguousarray(a)
+        check(self._lib.tf_fb_set_frame_bgr(self._h, int(slot), _ptr(a), a.shape[1], a.shape[0], a.strides[0]))
+
     def set_initial_flow(self, pair: int, flow) -> None:
         """Resident path, OPTFLOW_USE_INITIAL_FLOW: the initial flow of `pair` for the next calc_slots."""
         f = np.ascontiguousarray(flow, dtype=np.float32)

@@ -401,13 +401,17 @@ class FlowSource:
 
 
 class ArrayFrameProvider:
-    """Frames held in memory: a sequence of uint8 arrays, grey (H, W) or BGR (H, W, 3)."""
+    """Frames held in memory: a sequence of uint8 arrays, grey (H, W) or BGR (Hs, Ws, 3).  `size` = (width,
+    height) the source reports (cv2.CAP_PROP_FRAME_WIDTH / HEIGHT, cv.py:420-427); BGR frames of another size
+    are brought to it by the nearest-neighbour resize of cv.py:461, on the device."""
 
-    def __init__(self, frames, framerate: float = 30.0):
+    def __init__(self, frames, framerate: float = 30.0, size=None):
         self.frames = frames
         self.framerate = float(framerate)
         first = np.asarray(frames[0])
         self.height, self.width = first.shape[:2]
+        if size is not None:
+            self.width, self.height = int(size[0]), int(size[1])
         self.frame_count = len(frames)
         self.pos = 0
 
@@ -450,21 +454,10 @@ class Cv2FrameProvider:
         ok, frame = self.capture.read()
         if not ok or frame is None:
             return None
-        return self.cv2.resize(frame, dsize=(self.width, self.height), interpolation=self.cv2.INTER_NEAREST)
+        return frame     # as decoded: the resize of cv.py:461 and the grey conversion run on the device
 
     def release(self):
         self.capture.release()
-
-
-def to_grey(frame: np.ndarray) -> np.ndarray:
-    """Grey uint8 (H, W).  BGR input is converted with cv2's COLOR_BGR2GRAY fixed-point
-    weights ((B*1868 + G*9617 + R*4899 + 8192) >> 14) -- SURVEY §8(f) N4 keeps this step on
-    the host for now (cv.py:463)."""
-    a = np.asarray(frame)
-    if a.ndim == 2:
-        return a if a.dtype == np.uint8 else a.astype(np.uint8)
-    b, g, r = (a[:, :, i].astype(np.uint32) for i in range(3))
-    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
 
 
 class HipFlowSource(FlowSource):
@@ -502,9 +495,9 @@ class HipFlowSource(FlowSource):
         self.config = config
         self.provider = provider
         self.device = device
-        self.prev_gray = None
+        self._prev_frame = None  # the decoded frame behind prev_gray
         self._fb = None
-        self._prev_slot = None   # frame slot holding prev_gray on the device (resident path)
+        self._prev_slot = None   # frame slot holding prev_gray on the device
         self._pending = None     # array handed out by read_next_flow whose flow is still on the device
         self._mask_dev = None
         self._flow_pool = None
@@ -523,6 +516,30 @@ class HipFlowSource(FlowSource):
             self._pp = self._fb  # one handle serves both calls
         return self._fb
 
+    # The frame the reference keeps as `prev_gray` (cv.py:456, 519) lives in a frame slot of the handle; on the
+    # host only the decoded frame it came from is kept (to fill the slot again after a rewind).  Frames are
+    # made grey ON THE DEVICE (tf_fb_set_frame_bgr: cv2.resize INTER_NEAREST + COLOR_BGR2GRAY of cv.py:461-466
+    # as one kernel into the slot, OpenCV 4's 15-bit weights); a provider of grey frames is taken as it is.
+    @property
+    def prev_gray(self):
+        f = self._prev_frame
+        if f is None or np.asarray(f).ndim == 2:
+            return f
+        from .flowops import bgr_to_grey
+        return bgr_to_grey(f, (self.width, self.height))
+
+    @prev_gray.setter
+    def prev_gray(self, value):
+        self._prev_frame = value
+        self._prev_slot = None
+
+    def _ingest(self, slot: int, frame) -> None:
+        a = np.asarray(frame)
+        if a.ndim == 2:
+            self._handle().set_frame(slot, a)
+        else:
+            self._handle().set_frame_bgr(slot, a)
+
     def rewind(self):
         """cv.py:447-458: decode from the start up to the start frame, keep it as `prev`."""
         FlowSource.rewind(self)
@@ -532,9 +549,34 @@ class HipFlowSource(FlowSource):
             frame = self.provider.read()
             if frame is None:
                 raise RuntimeError(f"An error occurred while reading frame at index {i}")
-        self.prev_gray = to_grey(frame)
+        self._prev_frame = frame
         self.prev_flow = None
         self._prev_slot = None
+
+    def _advance(self) -> None:
+        """cv.py:460-490 up to the call: read a frame, make it grey in the slot the older of the two frames
+        held, order (prev, next) by direction, run Farnebäck on the two slots.  The flow stays on the device."""
+        frame = self.provider.read()
+        if frame is None:
+            raise StopIteration
+        if self._prev_frame is None:
+            raise ValueError("Missing reference frames")
+        fb = self._handle()
+        if self._prev_slot is None:                  # first frame, or after a rewind
+            self._ingest(0, self._prev_frame)
+            self._prev_slot = 0
+        new_slot = self._prev_slot ^ 1
+        self._ingest(new_slot, frame)
+        if self._uses_initial_flow():                # cv.py:478: a copy of the previous flow, zeros before the first
+            init = self.prev_flow if self.prev_flow is not None else np.zeros((self.height, self.width, 2), np.float32)
+            fb.set_initial_flow(0, init)
+        if self.direction == FlowSource.Direction.FORWARD:      # cv.py:467-472
+            fb.calc_slots([self._prev_slot], [new_slot])
+        elif self.direction == FlowSource.Direction.BACKWARD:
+            fb.calc_slots([new_slot], [self._prev_slot])
+        else:
+            raise ValueError(f"Invalid flow direction '{self.direction}'")
+        self._prev_slot, self._prev_frame = new_slot, frame
 
     # ---- resident form of one iteration -------------------------------------------------------
     # __next__ (source.py:293-321) calls read_next_flow() and hands its result straight to
@@ -557,23 +599,7 @@ class HipFlowSource(FlowSource):
             return FlowSource.read_next_flow(self)
         if self.input_frame_index == self.end_frame:
             self.rewind()
-        frame = self.provider.read()
-        if frame is None:
-            raise StopIteration
-        gray = to_grey(frame)
-        if self.prev_gray is None:
-            raise ValueError("Missing reference frames")
-        fb = self._handle()
-        if self._prev_slot is None:                  # first frame, or after a rewind
-            fb.set_frame(0, self.prev_gray)
-            self._prev_slot = 0
-        new_slot = self._prev_slot ^ 1
-        fb.set_frame(new_slot, gray)
-        if self.direction == FlowSource.Direction.FORWARD:      # cv.py:467-472
-            fb.calc_slots([self._prev_slot], [new_slot])
-        else:
-            fb.calc_slots([new_slot], [self._prev_slot])
-        self._prev_slot, self.prev_gray = new_slot, gray
+        self._advance()
         self.input_frame_index += 1
         if self._flow_pool is None:
             from .device import ArrayPool
@@ -599,24 +625,9 @@ class HipFlowSource(FlowSource):
         return raw
 
     def next(self):
-        """cv.py:460-490: (prev, next) ordered by direction, one Farnebäck call."""
-        frame = self.provider.read()
-        if frame is None:
-            raise StopIteration
-        gray = to_grey(frame)
-        if self.direction == FlowSource.Direction.FORWARD:
-            left, right = self.prev_gray, gray
-        else:
-            left, right = gray, self.prev_gray
-        if left is None or right is None:
-            raise ValueError("Missing reference frames")
-        if self._uses_initial_flow():     # cv.py:478: a copy of the previous flow, zeros before the first
-            flow = self._handle().calc(left, right, flow=self.prev_flow)
-        else:
-            flow = self._handle().calc(left, right)
-        self.prev_gray = gray
-        self._prev_slot = None       # calc() used both frame slots
-        return flow
+        """cv.py:460-490: (prev, next) ordered by direction, one Farnebäck call; the flow as a host array."""
+        self._advance()
+        return self._handle().get_flow(0)
 
     def close(self):
         if self._mask_dev is not None:
