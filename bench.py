@@ -466,11 +466,10 @@ def gather_leg(job, host, rccl, plans, reps=3):
     job.sync()
     ok = None
     if rank == 0:
-        got = recv.download((total,), np.uint8)
         ok = True
-        for r in range(world):
-            first = got[offsets[r]:offsets[r] + nbytes]
-            last = got[offsets[r] + counts[r] - nbytes:offsets[r] + counts[r]]
+        for r in range(world):      # the first and the last frame of what each rank sent
+            first = recv.download((nbytes,), np.uint8, offset=offsets[r])
+            last = recv.download((nbytes,), np.uint8, offset=offsets[r] + counts[r] - nbytes)
             ok = ok and [zlib.crc32(first.tobytes()), zlib.crc32(last.tobytes())] == list(crcs[r])
     host.barrier()
     t0 = time.perf_counter()
@@ -572,7 +571,14 @@ def main():
 
     from transflow_amd import _lib
     lib, check = _lib.load(), _lib.check
-    check(lib.tf_init(local_rank))
+    device = local_rank
+    if os.environ.get("TF_BENCH_SHARE_GPU"):
+        # rehearsal on a box with fewer GPUs than ranks: the ranks share the devices there are (RCCL then refuses
+        # the communicator -- two ranks on one device -- and the run goes on without its legs, which the line says)
+        n_dev = C.c_int()
+        check(lib.tf_device_count(C.byref(n_dev)))
+        device = local_rank % max(1, n_dev.value)
+    check(lib.tf_init(device))
     options = {}
     for item in args.option:
         name, _, value = item.partition("=")
@@ -623,7 +629,7 @@ def main():
                 rccl.close()
             rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
         rccl_error = next((e for e in errs if e), None)
-    job = Job(wl, args.batch, plan, args.clip_frames, seed=2000, device=local_rank, pixmap=pixmap, reset_mask=reset_mask,
+    job = Job(wl, args.batch, plan, args.clip_frames, seed=2000, device=device, pixmap=pixmap, reset_mask=reset_mask,
               pixmap_dev=pixmap_dev)
     if pixmap_dev is not None:
         job.pixmap_buffer = pix_buf     # the job gathers from this buffer: it lives as long as the job
@@ -784,7 +790,7 @@ def main():
                 w2 = WORKLOADS[name]
                 # the same bytes per call as the main workload: more pairs of the smaller frames
                 b2 = max(1, min(64, args.batch * (w * h) // (w2["w"] * w2["h"])))
-                j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=local_rank)
+                j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=device)
                 g2 = None
                 if not args.no_gate:            # the same gate as the main workload, before its rate is reported
                     g2, _ = parity_gate(j, n_check=1)

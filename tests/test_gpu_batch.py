@@ -92,3 +92,27 @@ def test_compositor_image_in_the_callers_buffer():
     for c in comps:
         c.close()
     np.testing.assert_array_equal(buf.download((3, h, w, 3), np.uint8), whole)   # the buffer outlives its handles
+
+
+def test_bench_with_three_ranks_sharing_the_one_gpu():
+    """A rehearsal of the multi-rank run on the one GPU of the test box: `bench.py --gpus 3` starts three rank
+    processes that share device 0 (TF_BENCH_SHARE_GPU), meet through the host group, shard a 40-frame clip into
+    13 + 13 + 13 pairs, time the same steps and report one line.  RCCL refuses a communicator with two ranks on one
+    device, so the line says rccl_ranks 0 and why -- every rank then makes the shared inputs itself; the multi-GPU
+    data legs are the 8-GPU node's to exercise (tests/test_batch_gloo.py replays their call sequence)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TF_BATCH_RDZV")}
+    env["TF_BENCH_SHARE_GPU"] = "1"
+    env["TF_BENCH_RCCL_TIMEOUT"] = "60"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--size", "640x360", "--clip-frames",
+                          "40", "--batch", "7", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, out.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 3 and d["config"]["pairs_per_rank"] == [13, 13, 13]
+    assert d["config"]["frame_pairs_per_step_per_gpu"] == [7, 7, 7] and d["config"]["frame_pairs_per_step"] == 21
+    assert len(d["per_rank_frames_per_s"]) == 3 and all(v > 0 for v in d["per_rank_frames_per_s"])
+    assert d["parity_gate"]["ok"] and d["value"] > 0
+    assert d["rccl_ranks"] in (0, 3)
+    if d["rccl_ranks"] == 0:
+        assert d.get("rccl_error")

@@ -7,8 +7,9 @@ oracle.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow (DE
 modes a pair may carry a small patch of outliers against the oracle; what must hold is
   * exact mode: the oracle's flow BIT FOR BIT, every pair;
   * against the oracle: at most 0.5 % of a pair's pixels beyond 1e-4 * max(1, max|ref|);
-  * one-kernel against two-kernel: at most 0.5 % of the pixels beyond 2e-5 * max(1, max|ref|), and
-    no more outliers against the oracle than the two-kernel path has, plus 0.2 % of the pixels.
+  * one-kernel against two-kernel, on pairs where neither carries such a patch: at most 0.5 % of the pixels beyond
+    2e-5 * max(1, max|ref|); everywhere: no more outliers against the oracle than the two-kernel path has, plus
+    0.2 % of the pixels.
 usage (GPU box, repo root): python3 tools/fuzz_fused.py [N] [seed]"""
 import os
 import sys
@@ -69,7 +70,7 @@ for case in range(n_cases):
         stats["worst_frac_between"] = max(stats["worst_frac_between"], fb_)
         if f1 == 0.0:
             stats["worst_clean_ratio"] = max(stats["worst_clean_ratio"], float(d1.max()) / (1e-4 * scale))
-        if f1 > 5e-3 or fb_ > 5e-3 or f1 > f2 + 2e-3:
+        if f1 > 5e-3 or (fb_ > 5e-3 and f1 == 0.0 and f2 == 0.0) or f1 > f2 + 2e-3:
             bad += 1
             print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: outliers vs oracle {f1:.2e} (two-kernel {f2:.2e}), "
                   f"one- vs two-kernel {fb_:.2e}; max|d| {d1.max():.3g} / {d2.max():.3g} / {db.max():.3g}, max|ref| {scale:.2f}")

@@ -31,12 +31,13 @@ class DevBuffer:
         if a.nbytes:
             check(self._lib.tf_dev_upload(C.c_void_p(self.ptr), C.c_void_p(a.ctypes.data), a.nbytes))
 
-    def download(self, shape, dtype) -> np.ndarray:
+    def download(self, shape, dtype, offset: int = 0) -> np.ndarray:
+        """The bytes at `offset` as an array of `shape` / `dtype`."""
         out = np.empty(shape, dtype)
-        if out.nbytes > self.nbytes:
-            raise ValueError("requested more bytes than the device buffer holds")
+        if offset < 0 or offset + out.nbytes > self.nbytes:
+            raise ValueError("requested bytes outside the device buffer")
         if out.nbytes:
-            check(self._lib.tf_dev_download(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), out.nbytes))
+            check(self._lib.tf_dev_download(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr + int(offset)), out.nbytes))
         return out
 
     def close(self):
