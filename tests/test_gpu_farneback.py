@@ -537,15 +537,26 @@ def test_strided_input_and_errors(FB):
         FB(0, 0)
 
 
-def test_against_cv2_when_available(FB):
+def test_against_cv2_when_available(FB, lib_option):
+    """Wherever `import cv2` works (neither this build container nor the GPU box): OpenCV itself as the reference --
+    the box window in the default mode (tolerance) and in the exact mode (bit for bit, if the build of OpenCV does not
+    contract multiply-adds), and the Gaussian window (flags = 256: tolerance; this is where the float-or-double question
+    of FarnebackUpdateFlow_GaussianBlur's solve would be decided)."""
     cv2 = pytest.importorskip("cv2")
     h, w = 480, 854
     a, b = synth_pair(h, w, seed=70)
+    for flags in (0, 256):
+        ref = cv2.calcOpticalFlowFarneback(a, b, None, 0.5, 3, 15, 3, 5, 1.2, flags)
+        fb = FB(w, h, flags=flags)
+        got = fb.calc(a, b)
+        fb.close()
+        assert np.abs(got - ref).max() <= flow_tol(ref), f"flags={flags}"
     ref = cv2.calcOpticalFlowFarneback(a, b, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+    lib_option("fb_exact_sums", 1)
     fb = FB(w, h)
     got = fb.calc(a, b)
     fb.close()
-    assert np.abs(got - ref).max() <= flow_tol(ref)
+    assert np.abs(got - ref).max() <= 1e-6 * max(1.0, float(np.abs(ref).max())), "exact mode vs cv2"
 
 
 # ---- fb_flags: OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256), cv.py:281, 489 ----------------

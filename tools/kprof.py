@@ -11,16 +11,19 @@ from transflow_amd import _lib  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "4k"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 _lib.set_option("prof_levels", 1)
+reps = 5
 for arg in sys.argv[3:]:
     k, v = arg.split("=")
-    _lib.set_option(k, int(v))
+    if k == "reps":
+        reps = int(v)          # a longer run (tools/clock_watch.sh samples clocks and power beside it)
+    else:
+        _lib.set_option(k, int(v))
 job = bench.Job(bench.WORKLOADS[name], batch, bench.make_plan(batch + 1, batch, 0, 1), batch + 1, seed=2000, device=0)
 for _ in range(2):
     job.step()
 job.sync()
 job.prof(True)
 job.prof_reset()
-reps = 5
 for _ in range(reps):
     job.step()
 job.sync()

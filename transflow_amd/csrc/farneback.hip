@@ -1310,6 +1310,10 @@ struct FlowInit {
     // which two expansions (images of R, [image][5][Nk]) pair p compares: frames shared by the pairs of a
     // batch are expanded once.  Null: images 2p and 2p+1 (stage entry points).
     const int2 *rmap;
+    // k_flow_iter_pc on a 1-D grid (grid_pairs > 0): the workgroups of one XCD walk (strip, segment) groups in raster
+    // order and, within a group, the pairs of the batch -- consecutive pairs of a clip share a frame, so the workgroups
+    // that read the same rows of its expansion (one as R1, the other as R0) are resident in the same L2 together
+    int grid_strips, grid_segs, grid_pairs;
 };
 
 __device__ __forceinline__ int2 pair_images(const FlowInit &fi, int pair)
@@ -1957,8 +1961,21 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     __shared__ double s_p[TF_PC_CONS][5][64]; // each consumer's pair sums
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
-    xcd_tile(bx, by);
-    const int pair = blockIdx.z;
+    int pair;
+    if (fi.grid_pairs > 0) {
+        // workgroup L runs on XCD L % 8 (dispatch is round-robin); q = L / 8 is its place in that XCD's queue
+        const unsigned xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const unsigned groups = fi.grid_strips * fi.grid_segs, per_xcd = (groups + 7) >> 3;
+        const unsigned g = xcd * per_xcd + q / fi.grid_pairs;
+        if (q / fi.grid_pairs >= per_xcd || g >= groups)
+            return; // padding of the last XCD's share (the whole workgroup leaves before any barrier)
+        pair = q % fi.grid_pairs;
+        bx = g % fi.grid_strips;
+        by = g / fi.grid_strips;
+    } else {
+        xcd_tile(bx, by);
+        pair = blockIdx.z;
+    }
     const size_t Nk = (size_t)Wk * Hk;
     const int r0 = by * seg, r1 = min(r0 + seg, Hk);
     // step s: producers make entering row e = r0 - M + s (s < n_rows) and its window sums; the consumer
@@ -3130,9 +3147,20 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     FlowInit none;
     memset(&none, 0, sizeof(none));
     none.rmap = fb->rmap_dev;
+    static const long pairmap = tune("TF_PC_PAIRMAP", 0);
+    if (pairmap && n_pairs > 1) {
+        none.grid_strips = (int)grid.x;
+        none.grid_segs = (int)grid.y;
+        none.grid_pairs = n_pairs;
+        const unsigned groups = grid.x * grid.y, per_xcd = (groups + 7) / 8;
+        grid = dim3(per_xcd * 8 * n_pairs);
+    }
     if (up) {
         FlowInit f = *up;
         f.rmap = fb->rmap_dev;
+        f.grid_strips = none.grid_strips;
+        f.grid_segs = none.grid_segs;
+        f.grid_pairs = none.grid_pairs;
         return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
                       seg, f);
     }
