@@ -35,6 +35,10 @@ if [ "$part" = b ]; then
     for p in a b c; do python3 tools/pmc_top.py gpurun_out/pmc_r03_$p $k; done
   done > $out/r03_sq_counters.txt
   tail -40 $out/r03_sq_counters.txt
+  # what the exact mode costs: the same step with the box window summed in OpenCV's own order
+  python3 tools/kprof.py 4k 8 > $out/r03_kprof_4k_batch8_default.txt 2>&1
+  python3 tools/kprof.py 4k 8 fb_exact_sums=1 > $out/r03_kprof_4k_batch8_exact.txt 2>&1
+  head -4 $out/r03_kprof_4k_batch8_default.txt $out/r03_kprof_4k_batch8_exact.txt
 fi
 if [ "$part" = c ]; then
   python3 tools/fuzz_fused.py 400 7 > $out/r03_fuzz_exact.txt 2>&1 || true
