@@ -276,3 +276,31 @@ def test_host_group_ignores_a_stranger_and_parses_nothing_it_sends(tmp_path):
         g1.gather(object())                                          # nothing but plain data travels
     g0.close()
     g1.close()
+
+
+def test_host_group_survives_a_stale_rendezvous_file(tmp_path):
+    """A launch that died leaves its file behind; the next one with the same key must not trip over the dead port in it."""
+    import threading
+    import time
+    from transflow_amd.batch import HostGroup
+    path = str(tmp_path / "rdzv")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        dead = s.getsockname()[1]
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "w") as f:
+        f.write(f"127.0.0.1:{dead} {'0' * 32} {'1' * 32}\n")
+    box = {}
+    t1 = threading.Thread(target=lambda: box.setdefault("g1", HostGroup(1, 2, path=path, timeout=60)))
+    t1.start()                       # rank 1 first: it finds the stale file and keeps trying
+    time.sleep(0.5)
+    g0 = HostGroup(0, 2, path=path, timeout=60)
+    t1.join(60)
+    g1 = box["g1"]
+    th = threading.Thread(target=lambda: box.setdefault("r0", g0.max_over_ranks(1.0)))
+    th.start()
+    assert g1.max_over_ranks(3.0) == 3.0
+    th.join(30)
+    assert box["r0"] == 3.0
+    g0.close()
+    g1.close()

@@ -206,6 +206,10 @@ class HostGroup:
             srv.settimeout(timeout)
             hello, answer = secrets.token_hex(16), secrets.token_hex(16)
             tmp = f"{self.path}.{os.getpid()}.tmp"
+            try:
+                os.unlink(tmp)                  # a leftover of a process that died with this pid
+            except OSError:
+                pass
             fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
             with os.fdopen(fd, "w") as f:
                 f.write(f"127.0.0.1:{srv.getsockname()[1]} {hello} {answer}\n")
@@ -237,9 +241,13 @@ class HostGroup:
             except OSError:
                 pass
         else:
+            # A file left behind by a launch that died (same port, same parent) may still name a dead listener, and a
+            # listener that is not this launch's does not know its token: keep reading and trying until the deadline.
             deadline = time.monotonic() + timeout
-            addr = None
-            while addr is None:
+            last = "no rendezvous file"
+            while self.sock is None:
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rank {self.rank}: rendezvous through {self.path} failed ({last})")
                 try:
                     fd = os.open(self.path, os.O_RDONLY | os.O_NOFOLLOW)
                     with os.fdopen(fd) as f:
@@ -251,16 +259,20 @@ class HostGroup:
                     host, port = where.rsplit(":", 1)
                     if host != "127.0.0.1":
                         raise RuntimeError(f"rendezvous file {self.path} names {host}, not this node")
-                    addr = (host, int(port))
-                except (OSError, ValueError):
-                    if time.monotonic() > deadline:
-                        raise TimeoutError(f"rank {self.rank}: no rendezvous file {self.path}")
-                    time.sleep(0.02)
-            self.sock = socket.create_connection(addr, timeout=timeout)
-            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            self.sock.sendall(hello.encode() + struct.pack("<i", self.rank))
-            if not secrets.compare_digest(_recv_exact(self.sock, len(answer)).decode("ascii", "replace"), answer):
-                raise ConnectionError("rendezvous: the listener did not know the launch's token")
+                    sock = socket.create_connection((host, int(port)), timeout=min(timeout, 30.0))
+                    try:
+                        sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        sock.sendall(hello.encode() + struct.pack("<i", self.rank))
+                        if not secrets.compare_digest(_recv_exact(sock, len(answer)).decode("ascii", "replace"), answer):
+                            raise ConnectionError("the listener did not know the launch's token")
+                    except BaseException:
+                        sock.close()
+                        raise
+                    sock.settimeout(timeout)
+                    self.sock = sock
+                except (OSError, ValueError, ConnectionError) as err:
+                    last = f"{type(err).__name__}: {err}"
+                    time.sleep(0.05)
 
     # -- collectives on host objects ---------------------------------------------------
     def gather(self, obj):
