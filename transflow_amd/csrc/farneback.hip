@@ -1883,6 +1883,9 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
 // from 1 (and a factor of exactly 1 changes nothing), so the product is border(min(x, W-1-x)) * border(min(y,
 // H-1-y)), the column's factor first as in the original: bit-identical, with the column's half a constant of the
 // march and the row's half wave-uniform.
+// UNWEIGHTED: the pixel is at least 5 pixels from every edge of the level (weight exactly 1: the five multiplications by
+// it change no bit and are not issued).
+template <bool UNWEIGHTED = false>
 __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float wy, float m[5])
 {
     // The one place where this library lets the compiler contract a * b + c into fused multiply-adds (the file is
@@ -1894,7 +1897,14 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     float2u r23 = a00 * g.t01.xy + a01 * g.t01.zw + a10 * g.b01.xy + a11 * g.b01.zw;
     float2u r45 = a00 * g.t23.xy + a01 * g.t23.zw + a10 * g.b23.xy + a11 * g.b23.zw;
+#ifdef TF_PC_C4_PAIRED
+    // c4 as its two columns side by side: (a00 t(x1) + a10 b(x1), a01 t(x1+1) + a11 b(x1+1)), one packed multiply, one
+    // packed multiply-add and an addition instead of a multiply and three multiply-adds in a chain
+    const float2u c4 = float2u{a00, a01} * g.t4 + float2u{a10, a11} * g.b4;
+    float r6 = c4.x + c4.y;
+#else
     float r6 = a00 * g.t4.x + a01 * g.t4.y + a10 * g.b4.x + a11 * g.b4.y;
+#endif
     r45 = (g.r0b + r45) * 0.5f;
     r6 = (g.r0c + r6) * 0.25f;
     const float o6 = g.r0c * 0.5f;
@@ -1905,7 +1915,7 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float
     float r2 = r23.x, r3 = r23.y, r4 = r45.x, r5 = r45.y;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
-    {
+    if (!UNWEIGHTED) {
         const float scale = wx * wy;
         r2 *= scale;
         r3 *= scale;
@@ -2072,9 +2082,10 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 #define TF_TICK() __builtin_readcyclecounter()
 #endif
         // One step of a producer.  INTERIOR (compile time): the step's three rows (finished, issued, flow loaded) and the
-        // row whose table entries are fetched lie inside the level and the finished row is at least 5 rows from its top
-        // and bottom, so nothing is clamped and the row's edge weight is 1 (x * 1.f == x: the same bits) -- the scalar
-        // clamps and selects of the general step are not even issued.  A march runs three loops: the rows at the top
+        // row whose table entries are fetched lie inside the level, the finished row is at least 5 rows from its top
+        // and bottom and the strip's columns at least 5 from its sides, so nothing is clamped and the pixel's edge weight
+        // is 1 (x * 1.f == x: the same bits) -- the scalar clamps and selects of the general step and the five
+        // multiplications by the weight are not even issued.  A march runs three loops: the rows at the top
         // of the level, the interior, the rows at the bottom (and the steps that only drain the window).
         auto step = [&](int s, auto interior) {
             constexpr bool INTERIOR = decltype(interior)::value;
@@ -2092,7 +2103,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 const int y_flow = INTERIOR ? r0 - M + s + 2 : clampi(r0 - M + s + 2, 0, Hk - 1);
                 const FlowRaw Fn = load_flow(y_flow);
                 fetch_row_entries(INTERIOR ? r0 - M + s + 3 : clampi(r0 - M + s + 3, 0, Hk - 1));
-                gather1_finish(G, wx, __uint_as_float(wyb), m);
+                gather1_finish<INTERIOR>(G, wx, __uint_as_float(wyb), m);
                 gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
                 F = Fn;
                 y_fin = y_iss;
@@ -2139,7 +2150,12 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         };
         // steps whose finished row e = r0 - M + s lies in [5, Hk - 6] (then e + 3 <= Hk - 1 too)
         int s_in0 = min(max(5 - (r0 - M), 0), n_rows), s_in1 = min(max(Hk - 5 - (r0 - M), s_in0), n_rows);
-#ifndef TF_PC_SPLIT // measured: 135 instead of 156 instructions per producer row, 0 - 1 % less time (the scalar ones are not what a step waits for)
+        // ... and only in strips whose 128 columns all lie at least 5 pixels inside the level (wave-uniform): there the
+        // interior step also drops the edge weight's five multiplications
+        const int strip0 = (int)bx * OUTC - HALO;
+        if (strip0 < 5 || strip0 + 127 > Wk - 6)
+            s_in0 = s_in1 = 0;
+#ifdef TF_PC_NO_SPLIT
         s_in0 = s_in1 = 0;
 #endif
         int s = 0;
