@@ -57,7 +57,7 @@ int tf_device_count(int *count);
                           FarnebackUpdateFlow_Blur sums it -- one set of running sums per image, float-differenced
                           down the columns from row 0, double-differenced along the rows from column 0 -- so the
                           flow is bit-identical to the CPU path's instead of within 1e-4 of it; a checking mode,
-                          about ten times slower (read per call)
+                          about five times slower (read per call)
    Unknown names and out-of-range values return TF_ERR_ARG.  The environment is never read. */
 int tf_set_option(const char *name, long value);
 int tf_get_option(const char *name, long *value);

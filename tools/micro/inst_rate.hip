@@ -11,6 +11,7 @@ __global__ void __launch_bounds__(64) k_rate(float *out, int n, float seed)
     float f[8];
     double d[8];
     int sc[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    unsigned long long mask = 0x5555555555555555ull + (unsigned long long)n;
     for (int i = 0; i < 8; i++) {
         f[i] = seed + i + threadIdx.x;
         d[i] = seed * 3 + i;
@@ -33,6 +34,17 @@ __global__ void __launch_bounds__(64) k_rate(float *out, int n, float seed)
             if (MODE == 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
             if (MODE == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(f[(i + 1) & 7]) : "vcc");
             if (MODE == 14) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc[i]));
+            // selects: the mask in an SGPR pair set once (no VCC traffic), and the compare + select pair a ternary compiles to
+            if (MODE == 15) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(f[i]) : "v"(f[(i + 1) & 7]), "s"(mask));
+            if (MODE == 16) asm volatile("v_cmp_gt_f32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(f[(i + 1) & 7]) : "vcc");
+            if (MODE == 17) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 18) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 19) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 20) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+            if (MODE == 21) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 22) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 7]));
+            if (MODE == 23) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+            if (MODE == 24) asm volatile("v_cmp_gt_f32_e64 %1, %0, %0" : "+v"(f[i]), "=s"(mask));
         }
     }
     float s = 0;
@@ -81,6 +93,16 @@ int main()
         run<12>("v_add_f32 (2 regs)", out, w);
         run<13>("v_cndmask_b32", out, w);
         run<14>("s_add_u32", out, w);
+        run<15>("v_cndmask (sgpr mask)", out, w);
+        run<16>("v_cmp + v_cndmask vcc (x2)", out, w);
+        run<17>("v_bfi_b32", out, w);
+        run<18>("v_max_f32", out, w);
+        run<19>("v_med3_i32", out, w);
+        run<20>("v_pk_mul_f32", out, w);
+        run<21>("v_mul_hi_u32", out, w);
+        run<22>("v_mul_lo_u32", out, w);
+        run<23>("v_lshl_add_u64", out, w);
+        run<24>("v_cmp_gt_f32 -> sgpr", out, w);
     }
     return 0;
 }

@@ -1583,7 +1583,7 @@ __global__ void k_blur_solve_w1(const float *__restrict__ Min, float2 *__restric
 // point sits within that distance of the last row / column.  These two kernels repeat
 // OpenCV's order exactly -- the same operations on the same operands, so the flow is bit-identical to the
 // CPU path's -- at the price of its serial dependences: one thread per column walks all rows, then one
-// thread per row walks all columns.  A checking mode, ~10x slower than the default.
+// thread per row walks all columns.  A checking mode, ~5x slower than the default.
 // vsum layout: [pair][channel][x][y] (y fastest): both kernels then read coalesced.
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)

@@ -40,7 +40,7 @@ static OptDef g_opts[OPT_COUNT] = {
     {"remap_px", 4, 1, 4},                     // pixels per thread of the one-kernel remap step: 1, 2 or 4 (4: 1.98 ms per 32 4K frames, 2: 2.04, 1: 2.45)
     {"remap_no_pack", 0, 0, 1},                // 1: the one-kernel remap step keeps its state as int32 x 4
     {"prof_levels", 0, 0, 1},                  // 1: profiler labels carry the pyramid level ("fb_polyexp.k2")
-    {"fb_exact_sums", 0, 0, 1},                // 1: the box window's sums in OpenCV's own order (bit-identical flow, ~10x slower; read per call)
+    {"fb_exact_sums", 0, 0, 1},                // 1: the box window's sums in OpenCV's own order (bit-identical flow, ~5x slower; read per call)
 };
 long option(Opt which) { return g_opts[which].value; }
 
