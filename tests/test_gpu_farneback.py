@@ -822,3 +822,32 @@ def test_bench_shape_4k_two_pairs_sharing_a_frame_fused_on_every_level(FB, lib_o
     fb.close()
     for i in range(2):
         assert_within_tolerance_up_to_border_flips(got[i], refs[i], f"pair {i}")
+
+
+def test_bgr_frame_into_a_slot_matches_the_host_conversion_and_validates(FB):
+    """tf_fb_set_frame_bgr (cv.py:461-466 on the device): a strided BGR view, a frame of another size (nearest resize),
+    and its argument checks; the flow computed from slots filled that way equals the flow from the oracle's grey frames."""
+    from oracle import frames_ref
+    h, w = 96, 128
+    rng = np.random.default_rng(12)
+    big = rng.integers(0, 256, (h + 7, w + 9, 3), dtype=np.uint8)
+    view = big[3:3 + h, 4:4 + w]                      # row stride larger than the row
+    other = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    fb = FB(w, h)
+    fb.set_frame_bgr(0, view)
+    fb.set_frame_bgr(1, other)                         # 83 x 61 -> 128 x 96 by nearest neighbour
+    fb.calc_slots([0], [1])
+    got = fb.get_flow(0)
+    ga, gb = frames_ref.bgr_to_grey(np.ascontiguousarray(view)), frames_ref.bgr_to_grey(other, (w, h))
+    ref = O.calc(ga, gb)
+    assert np.abs(got - ref).max() <= flow_tol(ref)
+    fb2 = FB(w, h)
+    np.testing.assert_array_equal(fb2.calc(ga, gb), got)   # the same flow as from host-side grey frames
+    fb2.close()
+    with pytest.raises(ValueError):
+        fb.set_frame_bgr(2, view)                      # slot out of range
+    with pytest.raises(ValueError):
+        fb.set_frame_bgr(0, view[:, :, :2])            # not three channels
+    with pytest.raises(ValueError):
+        fb.set_frame_bgr(0, view.astype(np.float32))   # not uint8
+    fb.close()
