@@ -268,3 +268,21 @@ def test_flow_source_host_path_ingests_on_the_device_too(lib_option):
     assert len(resident) == len(host) == 3
     for a, b in zip(resident, host):
         np.testing.assert_array_equal(a, b)
+
+
+def test_flow_config_can_ask_for_opencv_identical_flows(lib_option):
+    """`"hip_exact_sums": true` in the cv_config JSON: the drop-in source's flows equal the CPU path's bit for bit."""
+    from transflow_amd import _lib
+    from transflow_amd.config import FlowConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    lib_option("fb_exact_sums", 0)                     # restored afterwards whatever the source sets
+    h, w = 120, 160
+    frames = _frames(h, w, 3)
+    cfg = FlowConfig(hip_exact_sums=True, fb_levels=2)
+    assert cfg.to_dict()["hip_exact_sums"] is True and FlowConfig(**cfg.to_dict()).hip_exact_sums
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
+        flows = [f.copy() for f in source]
+    assert _lib.get_option("fb_exact_sums") == 1
+    for t, flow in enumerate(flows):
+        exp = R.post_process(OF.calc(frames[t + 1], frames[t], levels=2), R.BACKWARD)
+        np.testing.assert_array_equal(flow, exp)

@@ -91,6 +91,11 @@ class FlowConfig:
         self.method = method
         for k, v in self.FB_DEFAULTS.items():
             setattr(self, k, kwargs.pop(k, v))
+        # This backend's own key in a CvFlowConfig JSON: "hip_exact_sums": true asks for the box window summed in
+        # OpenCV's own order (library option fb_exact_sums: flows bit-identical to the CPU path's, about five times
+        # the Farnebäck time).  The reference ignores keys it does not know only if they are not there: leave it out
+        # of files the reference itself must read.
+        self.hip_exact_sums = parse_bool_arg(kwargs.pop("hip_exact_sums", None), False)
         self.extra = dict(kwargs)  # hs_*, lk_*, show_window ...: not used by this backend
 
     def fb_kwargs(self) -> dict:
@@ -102,6 +107,8 @@ class FlowConfig:
         d = {"method": self.method}
         d.update({k: getattr(self, k) for k in self.FB_DEFAULTS})
         d.update(self.extra)
+        if self.hip_exact_sums:
+            d["hip_exact_sums"] = True
         return d
 
     def to_file(self, path: str):

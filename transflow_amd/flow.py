@@ -511,6 +511,11 @@ class HipFlowSource(FlowSource):
     def _handle(self):
         if self._fb is None:
             from .farneback import Farneback
+            if getattr(self.config, "hip_exact_sums", False):
+                # the flow source is the only Farnebäck user of its process (the reference forks it into a child,
+                # pipeline.py:56-64), so the library-wide option is this source's
+                from . import _lib
+                _lib.set_option("fb_exact_sums", 1)
             self._fb = Farneback(self.width, self.height, device=self.device, **self.config.fb_kwargs())
             self._fb.keep_expansions(True)  # the frame that was "next" stays expanded for its turn as "prev"
             self._pp = self._fb  # one handle serves both calls
