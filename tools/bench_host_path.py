@@ -5,7 +5,7 @@ This is the PCIe-inclusive rate DESIGN.md section 5 quotes; it is never bench.py
 source reads are decoded BGR frames, as a video capture hands them over (cv.py:461-466): the upload of the colour
 frame and its conversion to grey on the device are inside the measured time (`grey` as a third argument feeds
 ready-made grey frames instead, the form the round-2 figures were taken with).
-Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey]"""
+Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact]"""
 import os
 import sys
 import time
@@ -24,6 +24,7 @@ w, h = {"1080p": (1920, 1080), "4k": (3840, 2160)}[name]
 clip = bench.ClipSynth(h, w, n + 1, 2000)
 frames = [clip.frame(t) for t in range(n + 1)]
 kind = sys.argv[3] if len(sys.argv) > 3 else "bgr"
+exact = len(sys.argv) > 4 and sys.argv[4] == "exact"     # flows bit-identical to the CPU path's (option fb_exact_sums)
 if kind == "bgr":   # three channels around the texture, so that the grey value still carries it
     frames = [np.stack([f // 2 + 20, f, 255 - (255 - f) // 2], axis=2).astype(np.uint8) for f in frames]
 pix = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -39,7 +40,11 @@ class Src:
 comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
 comp.set_sources({0: [Src()]})
 t_flow = t_comp = 0.0
-with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backward") as source:
+cfg = None
+if exact:
+    from transflow_amd.config import FlowConfig  # noqa: E402
+    cfg = FlowConfig(hip_exact_sums=True)
+with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backward", cv_config=cfg) as source:
     it = iter(source)
     flow = next(it)                      # warm-up: handle creation, first launches
     comp.update(flow)
@@ -58,5 +63,5 @@ with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backwa
         t_flow += t1 - t0
         t_comp += t2 - t1
         k += 1
-print(f"{name} ({kind} frames in): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
+print(f"{name} ({kind} frames in{', exact sums' if exact else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
       f"{k / (t_flow + t_comp):.1f} frames/s end to end through host arrays (one process)")
