@@ -683,6 +683,11 @@ def main():
         rccl_version = rccl.rccl_version
 
         def leg():
+            fault = os.environ.get("TF_BENCH_TEST_FAULT")      # tests only: what a failing / hanging leg does to the line
+            if fault == "gather-raises":
+                raise RuntimeError("injected failure of the gather leg")
+            if fault == "gather-hangs":
+                time.sleep(3600)
             g = gather_leg(job, host, rccl, plans)
             rccl.close()
             return g

@@ -116,3 +116,18 @@ def test_bench_with_three_ranks_sharing_the_one_gpu():
     assert d["rccl_ranks"] in (0, 3)
     if d["rccl_ranks"] == 0:
         assert d.get("rccl_error")
+
+
+@pytest.mark.parametrize("fault,rc,needle", [("gather-raises", 0, "injected failure"), ("gather-hangs", 4, "TimeoutError")])
+def test_a_lost_side_leg_never_loses_the_line(fault, rc, needle):
+    """The result line is complete before any untimed leg starts: a leg that raises is reported under side_leg_errors
+    (exit code 0), one that never returns is abandoned after its time limit, the line is printed all the same and the
+    process leaves with exit code 4."""
+    env = dict(os.environ, TF_BENCH_TEST_FAULT=fault, TF_BENCH_LEG_TIMEOUT="5")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl", "--size", "640x360", "--clip-frames",
+                          "9", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == rc, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["value"] > 0 and d["parity_gate"]["ok"] and "gather" not in d
+    assert needle in d["side_leg_errors"]["gather"]
