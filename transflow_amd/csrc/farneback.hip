@@ -1314,6 +1314,9 @@ struct FlowInit {
     // order and, within a group, the pairs of the batch -- consecutive pairs of a clip share a frame, so the workgroups
     // that read the same rows of its expansion (one as R1, the other as R0) are resident in the same L2 together
     int grid_strips, grid_segs, grid_pairs;
+    // Experiment TF_PC_GRING: the window's 15 rows of M in global memory (a region per workgroup, L2 / Infinity Cache
+    // resident) instead of LDS, so that LDS no longer limits a CU to three workgroups
+    float *gring;
 };
 
 __device__ __forceinline__ int2 pair_images(const FlowInit &fi, int pair)
@@ -1966,7 +1969,9 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     constexpr int HALO = (M + 1) & ~1;
 #endif
     constexpr int OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
+#ifndef TF_PC_GRING
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
+#endif
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
     __shared__ double s_p[TF_PC_CONS][5][64]; // each consumer's pair sums
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1991,9 +1996,11 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     // step s: producers make entering row e = r0 - M + s (s < n_rows) and its window sums; the consumer
     // turns the sums of step s - 1 into the flow of row r0 + (s - 1) - 2M
     const int n_rows = (r1 - r0) + 2 * M, nsteps = n_rows + 1;
+#ifndef TF_PC_GRING
     for (int i = threadIdx.x; i < WIN * 5 * 128; i += TF_PC_THREADS)
         (&ring[0][0][0])[i] = 0.f; // rows "above" the first window count as zero: the warm-up subtracts them
     __syncthreads();
+#endif
     if (wave < 2) {
         const int col = (wave & 1) * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
@@ -2071,6 +2078,13 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         fetch_row_entries(clampi(r0 - M + 2, 0, Hk - 1));
         double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
+#ifdef TF_PC_GRING
+        // this workgroup's region of the global ring, [slot][channel][column]; this lane only ever touches its column
+        const size_t wg_linear = fi.grid_pairs > 0 ? (size_t)blockIdx.x
+                                                   : ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        float *gr = fi.gring + wg_linear * (size_t)(WIN * 5 * 128) + col;
+        float old_row[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
 #ifdef TF_PC_RING_EARLY
         float old_row[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // the ring starts out zero
 #endif
@@ -2095,6 +2109,15 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 #endif
             if (INTERIOR || s < n_rows) {
                 float m[5];
+#ifdef TF_PC_GRING
+                // the row that leaves the window, written WIN steps ago by this very lane (zero while the window fills):
+                // read past the L1 (a device-scope load), a whole step before it is needed
+                if (s >= WIN) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++)
+                        old_row[c] = __hip_atomic_load(gr + (slot * 5 + c) * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#endif
                 // the row's edge weight is wave-uniform: border_weight() as scalar selects on the floats' bits (0.14f, 0.4472f, 1.f)
                 const int dyb = min(y_fin, Hk - 1 - y_fin);
                 const unsigned wyb = INTERIOR ? 0x3f800000u : (dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u));
@@ -2113,7 +2136,16 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 #endif
                 // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
                 // only this lane ever touches its column of the ring
-#ifdef TF_PC_RING_EARLY
+#ifdef TF_PC_GRING
+                // the leaving row was loaded at the top of the step (below); the entering row takes its place
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    gr[(slot * 5 + c) * 128] = m[c];
+                    vs[c] += (double)(m[c] - old_row[c]);
+                    s_v[s & 1][c][col] = vs[c];
+                }
+                slot = slot + 1 == WIN ? 0 : slot + 1;
+#elif defined(TF_PC_RING_EARLY)
                 // Experiment: the leaving row of the NEXT step is read at the end of this one (it sits in the next slot,
                 // which nothing writes in between), so its LDS round trips end in the barrier's shadow
 #pragma unroll
@@ -2789,6 +2821,7 @@ struct tf_fb {
     AreaTabs area{};
     DevBuf gauss_taps;           // winsize / 2 + 1 taps of the Gaussian window (flag 256)
     DevBuf bgr_stage;            // tf_fb_set_frame_bgr: the decoded frame on its way to a slot
+    DevBuf gring;                // experiment TF_PC_GRING: the iteration kernel's window rows, a region per workgroup
     DevBuf exact_vsum;           // option fb_exact_sums: OpenCV's column sums of the level being solved, [pair][5][x][y] doubles
     bool use_initial() const { return (prm.flags & 4) != 0; }
     bool gaussian() const { return (prm.flags & 256) != 0; }
@@ -3142,7 +3175,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     // rounds of 768, each as long as a segment plus its 2M+1 warm-up / drain steps.  Pick the segment
     // count that minimises rounds x steps (4K x 16: 4 segments = 2240 workgroups, 2.9 -> 3 rounds).
     static const long forced = tune("TF_PC_BLOCKS", 0);
-    const long per_seg = (long)strips * n_pairs, slots = 768;
+    const long per_seg = (long)strips * n_pairs, slots = tune("TF_PC_SLOTS", 768);
     long best_segs = 1;
     double best_cost = 1e300;
     for (long sg = 1; sg <= 64 && sg <= h; sg++) {
@@ -3163,6 +3196,15 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     FlowInit none;
     memset(&none, 0, sizeof(none));
     none.rmap = fb->rmap_dev;
+#ifdef TF_PC_GRING
+    {
+        const size_t wgs = (size_t)grid.x * grid.y * grid.z + 8 * (size_t)n_pairs; // (+ the 1-D grid's padding)
+        const size_t need = wgs * (size_t)(2 * M + 1) * 5 * 128 * sizeof(float);
+        if (fb->gring.bytes < need)
+            TF_TRY(fb->gring.alloc(need));
+        none.gring = fb->gring.as<float>();
+    }
+#endif
     static const long pairmap = tune("TF_PC_PAIRMAP", 0);
     if (pairmap && n_pairs > 1) {
         none.grid_strips = (int)grid.x;
@@ -3177,11 +3219,12 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
         f.grid_strips = none.grid_strips;
         f.grid_segs = none.grid_segs;
         f.grid_pairs = none.grid_pairs;
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
+        f.gring = none.gring;
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), (size_t)tune("TF_PC_DYNLDS", 0), R, flow_in, flow_out, w, h, scale,
                       seg, f);
     }
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), (size_t)tune("TF_PC_DYNLDS", 0), R, flow_in, flow_out, w, h, scale,
                       seg, none);
     return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
                   seg, none);
