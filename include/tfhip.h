@@ -58,6 +58,12 @@ int tf_device_count(int *count);
                           down the columns from row 0, double-differenced along the rows from column 0 -- so the
                           flow is bit-identical to the CPU path's instead of within 1e-4 of it; a checking mode,
                           about five times slower (read per call)
+     "fb_chain"       -1  the marching kernels keep FarnebackUpdateFlow_Blur's column sums (one running sum per column
+                          from row 0).  A column cut into row segments needs the sum's value at each cut: 1 = every
+                          segment waits for the one above it inside the launch (the sums are then the CPU path's bit
+                          for bit), 0 = a pre-pass computes the values (equal up to the association of double
+                          additions, ~1e-16), -1 = whichever is cheaper for the launch (read per call)
+     "fb_segs"        0   > 0: that many row segments per column (0: chosen per launch; read per call)
    Unknown names and out-of-range values return TF_ERR_ARG.  The environment is never read. */
 int tf_set_option(const char *name, long value);
 int tf_get_option(const char *name, long *value);

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """A longer run of tests/test_gpu_farneback.py::test_fused_iteration_on_random_shapes_and_batches: N random frame
-shapes, window widths, level counts, iteration counts, polynomial radii and batch sizes, every pair four ways -- the
-one-kernel iteration (option fb_fused = 1), the two-kernel iteration (= 0, whose stages are bit-identical to the
-oracle's up to the window sums), the exact mode (fb_exact_sums = 1: the window summed in OpenCV's own order) and the
-oracle.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow, so in the default
-modes a pair may carry a small patch of outliers against the oracle; what must hold is
+shapes, window widths, level counts, iteration counts, polynomial radii and batch sizes, every pair six ways --
+  * the one-kernel iteration (option fb_fused = 1) with its columns cut into 1 / 3 row segments, the segments' column sums
+    handed down inside the launch (fb_chain = 1) or computed by a pre-pass (fb_chain = 0),
+  * the two-kernel iteration (fb_fused = 0) whole and in 3 segments (pre-pass),
+  * the exact mode (fb_exact_sums = 1: the window summed in OpenCV's own order, along the rows too),
+and the oracle.  Since round 4 every form keeps FarnebackUpdateFlow_Blur's column sums (one running sum per column from row
+0, float-differenced), so what is left between a default form and the oracle is the association of double additions
+(~1e-16 in a sum).  What must hold:
   * exact mode: the oracle's flow BIT FOR BIT, every pair;
-  * against the oracle: at most 0.5 % of a pair's pixels beyond 1e-4 * max(1, max|ref|);
-  (how far the one- and the two-kernel form are from each other -- the first computes the 2x2 systems with fused
-  multiply-adds -- is reported, not judged: each is held to the oracle).
-usage (GPU box, repo root): python3 tools/fuzz_fused.py [N] [seed] [only-case]   (only-case: run that case alone and say
-where its outliers are)"""
+  * every other form: NO pixel beyond 1e-4 * max(1, max|ref|) of the oracle, in any pair (round 3 allowed 0.5 %);
+  * the forms among themselves: no pixel further apart than that either.
+Reported besides: in how many pairs each form is bit-identical to the oracle, and its largest deviation.
+usage (GPU box, repo root): python3 tools/fuzz_fused.py [N] [seed] [only-case]"""
 import os
 import sys
 
@@ -29,9 +31,18 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 
 
-def run(mode, w, h, n, frames, kw, exact=0):
-    _lib.set_option("fb_fused", mode)
-    _lib.set_option("fb_exact_sums", exact)
+FORMS = [("one-kernel whole", dict(fb_fused=1, fb_segs=1, fb_chain=-1)),
+         ("one-kernel 3 segments handed down", dict(fb_fused=1, fb_segs=3, fb_chain=1)),
+         ("one-kernel 3 segments pre-pass", dict(fb_fused=1, fb_segs=3, fb_chain=0)),
+         ("two-kernel whole", dict(fb_fused=0, fb_segs=1, fb_chain=-1)),
+         ("two-kernel 3 segments", dict(fb_fused=0, fb_segs=3, fb_chain=-1)),
+         ("default choice", dict(fb_fused=-1, fb_segs=0, fb_chain=-1))]
+DEFAULTS = dict(fb_fused=-1, fb_segs=0, fb_chain=-1, fb_exact_sums=0)
+
+
+def run(opts, w, h, n, frames, kw):
+    for k, v in {**DEFAULTS, **opts}.items():
+        _lib.set_option(k, v)
     fb = Farneback(w, h, max_pairs=n, frame_slots=n + 1, **kw)
     for i, f in enumerate(frames):
         fb.set_frame(i, f)
@@ -42,8 +53,9 @@ def run(mode, w, h, n, frames, kw, exact=0):
 
 
 bad = 0
-stats = dict(pairs=0, clean=0, exact_identical=0, outlier_pairs=0, worst_frac_oracle=0.0, worst_frac_between=0.0,
-             worst_clean_ratio=0.0)
+pairs = exact_identical = 0
+st = {name: dict(identical=0, worst=0.0, outlier_pairs=0, px_differ=0) for name, _ in FORMS}
+worst_between = 0.0
 for case in range(n_cases):
     h, w = int(rng.integers(10, 300)), int(rng.integers(10, 460))
     kw = dict(levels=int(rng.integers(0, 4)), winsize=int(rng.choice([7, 11, 15])), iterations=int(rng.integers(1, 4)),
@@ -52,40 +64,44 @@ for case in range(n_cases):
     if only is not None and case != only:
         continue
     frames = [synth_pair(h, w, seed=h * 1000 + w, shift=(0.7 * i, -0.4 * i))[1] for i in range(n + 1)]
-    one, two, exact = run(1, w, h, n, frames, kw), run(0, w, h, n, frames, kw), run(-1, w, h, n, frames, kw, exact=1)
+    got = {name: run(opts, w, h, n, frames, kw) for name, opts in FORMS}
+    exact = run(dict(fb_exact_sums=1), w, h, n, frames, kw)
     for i in range(n):
         ref = O.calc(frames[i + 1], frames[i], **kw)
         scale = max(1.0, float(np.abs(ref).max()))
-        d1, d2 = np.abs(one[i] - ref).max(axis=2), np.abs(two[i] - ref).max(axis=2)
-        db = np.abs(one[i] - two[i]).max(axis=2)
-        f1, f2, fb_ = float((d1 > 1e-4 * scale).mean()), float((d2 > 1e-4 * scale).mean()), float((db > 2e-5 * scale).mean())
-        if only is not None:
-            for name, d in (("one-kernel", d1), ("two-kernel", d2)):
-                ys, xs = np.nonzero(d > 1e-4 * scale)
-                where = f"rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}" if len(ys) else "none"
-                print(f"case {case} {h}x{w} {kw} pair {i}: {name}: {len(ys)} pixels beyond tolerance ({where}), max|d| {d.max():.3g}, max|ref| {scale:.3g}")
-        stats["pairs"] += 1
-        stats["clean"] += f1 == 0.0
-        stats["outlier_pairs"] += f1 > 0.0
+        pairs += 1
         same = bool(np.array_equal(exact[i], ref))
-        stats["exact_identical"] += same
+        exact_identical += same
         if not same:
             bad += 1
             de = np.abs(exact[i] - ref).max(axis=2)
             print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: exact mode differs from the oracle in {int((de > 0).sum())} "
                   f"pixels, max|d| {de.max():.3g}")
-        stats["worst_frac_oracle"] = max(stats["worst_frac_oracle"], f1)
-        stats["worst_frac_between"] = max(stats["worst_frac_between"], fb_)
-        if f1 == 0.0:
-            stats["worst_clean_ratio"] = max(stats["worst_clean_ratio"], float(d1.max()) / (1e-4 * scale))
-        if f1 > 5e-3 or f2 > 5e-3:
-            bad += 1
-            print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: outliers vs oracle {f1:.2e} (two-kernel {f2:.2e}), "
-                  f"one- vs two-kernel {fb_:.2e}; max|d| {d1.max():.3g} / {d2.max():.3g} / {db.max():.3g}, max|ref| {scale:.2f}")
-_lib.set_option("fb_fused", -1)
-_lib.set_option("fb_exact_sums", 0)
-print(f"{n_cases} cases, {stats['pairs']} pairs: exact mode bit-identical to the oracle in {stats['exact_identical']}; default mode: "
-      f"{stats['clean']} with every pixel inside the tolerance (worst {stats['worst_clean_ratio']:.2f} of it), {stats['outlier_pairs']} with outliers; "
-      f"most outliers in a pair vs the oracle {stats['worst_frac_oracle']:.2e} of its pixels, one- vs two-kernel {stats['worst_frac_between']:.2e}; "
-      f"{bad} failures")
+        for name, _ in FORMS:
+            d = np.abs(got[name][i] - ref).max(axis=2)
+            n_out = int((d > 1e-4 * scale).sum())
+            st[name]["identical"] += bool(np.array_equal(got[name][i], ref))
+            st[name]["px_differ"] += int((d > 0).sum())
+            st[name]["worst"] = max(st[name]["worst"], float(d.max()) / (1e-4 * scale))
+            st[name]["outlier_pairs"] += n_out > 0
+            if n_out or only is not None:
+                ys, xs = np.nonzero(d > 1e-4 * scale)
+                where = f"rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}" if len(ys) else "none"
+                print(f"{'FAIL ' if n_out else ''}case {case} {h}x{w} {kw} pair {i} of {n}: {name}: {n_out} pixels beyond tolerance ({where}), "
+                      f"{int((d > 0).sum())} differ at all, max|d| {d.max():.3g}, max|ref| {scale:.3g}")
+                bad += n_out > 0
+        for name, _ in FORMS[1:]:
+            db = float(np.abs(got[name][i] - got[FORMS[0][0]][i]).max()) / (1e-4 * scale)
+            worst_between = max(worst_between, db)
+            if db > 1.0:
+                bad += 1
+                print(f"FAIL case {case} {h}x{w} {kw} pair {i}: {name} is {db:.2f} tolerances from the one-kernel form")
+for k, v in DEFAULTS.items():
+    _lib.set_option(k, v)
+print(f"{n_cases} cases, {pairs} pairs: exact mode bit-identical to the oracle in {exact_identical}")
+for name, _ in FORMS:
+    t = st[name]
+    print(f"  {name:36s}: bit-identical to the oracle in {t['identical']} pairs ({t['px_differ']} pixels differ in all), "
+          f"largest deviation {t['worst']:.2e} of the tolerance, {t['outlier_pairs']} pairs with a pixel beyond it")
+print(f"  the forms among themselves: at most {worst_between:.2e} of the tolerance apart; {bad} failures")
 sys.exit(1 if bad else 0)

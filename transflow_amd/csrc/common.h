@@ -23,7 +23,7 @@ int ensure_init();
 
 // Documented run-time options (tf_set_option / tf_get_option, include/tfhip.h).
 enum Opt { OPT_FB_FUSED = 0, OPT_FB_FUSE_MIN_PX, OPT_FB_NO_SHARE, OPT_FB_NO_OVERLAP, OPT_REMAP_PX, OPT_REMAP_NO_PACK,
-           OPT_PROF_LEVELS, OPT_FB_EXACT_SUMS, OPT_COUNT };
+           OPT_PROF_LEVELS, OPT_FB_EXACT_SUMS, OPT_FB_CHAIN, OPT_FB_SEGS, OPT_COUNT };
 long option(Opt which);
 
 // Kernel-experiment knobs (tile sizes, segment counts ...) are compile-time constants in the shipped

@@ -1310,13 +1310,6 @@ struct FlowInit {
     // which two expansions (images of R, [image][5][Nk]) pair p compares: frames shared by the pairs of a
     // batch are expanded once.  Null: images 2p and 2p+1 (stage entry points).
     const int2 *rmap;
-    // k_flow_iter_pc on a 1-D grid (grid_pairs > 0): the workgroups of one XCD walk (strip, segment) groups in raster
-    // order and, within a group, the pairs of the batch -- consecutive pairs of a clip share a frame, so the workgroups
-    // that read the same rows of its expansion (one as R1, the other as R0) are resident in the same L2 together
-    int grid_strips, grid_segs, grid_pairs;
-    // Experiment TF_PC_GRING: the window's 15 rows of M in global memory (a region per workgroup, L2 / Infinity Cache
-    // resident) instead of LDS, so that LDS no longer limits a CU to three workgroups
-    float *gring;
 };
 
 __device__ __forceinline__ int2 pair_images(const FlowInit &fi, int pair)
@@ -1503,7 +1496,8 @@ k_update_matrices(const float *__restrict__ R, float *__restrict__ M, int Wk, in
 constexpr int BS_THREADS = 256;
 
 __global__ void __launch_bounds__(BS_THREADS)
-k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, int m, double scale, int seg)
+k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, int m, double scale, int seg,
+             const double *__restrict__ carry)
 {
     __shared__ double s_v[2][5][BS_THREADS];
     const int tid = threadIdx.x;
@@ -1514,17 +1508,27 @@ k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int W
     const size_t Nk = (size_t)Wk * Hk;
     const float *Mi = Min + (size_t)pair * 5 * Nk + colc;
     const int r0 = blockIdx.y * seg, r1 = min(r0 + seg, Hk);
-    double vs[5] = {0, 0, 0, 0, 0};
-    for (int j = -m; j <= m; j++) {
-        size_t ro = (size_t)clampi(r0 + j, 0, Hk - 1) * Wk;
+    // OpenCV's vertical chain (ColumnCarry's note): primed at row 0, or continued from the segment above
+    double vs[5];
+    if (r0 == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++)
-            vs[c] += (double)Mi[c * Nk + ro];
+            vs[c] = (double)(Mi[c * Nk] * (float)(m + 2)); // vsum[x] = srow0[x] * (m + 2): a float product
+        for (int j = 1; j < m; j++) {
+            size_t ro = (size_t)min(j, Hk - 1) * Wk;
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                vs[c] += (double)Mi[c * Nk + ro];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            vs[c] = carry[((((size_t)blockIdx.y * gridDim.z + pair) * 5 + c) * Wk) + colc];
     }
     const bool is_out = tid >= m && tid < BS_THREADS - m && col < Wk;
     int buf = 0;
     for (int y = r0; y < r1; y++) {
-        if (y > r0) {
+        {
             size_t ra = (size_t)min(y + m, Hk - 1) * Wk, rb = (size_t)max(y - m - 1, 0) * Wk;
 #pragma unroll
             for (int c = 0; c < 5; c++)
@@ -1652,8 +1656,8 @@ struct dpair {
 
 template <int M, bool VEC>
 __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ Min, float2 *__restrict__ flow_out,
-                                                     int Wk, int Hk, double scale, int seg, double (*s_e)[64], double (*s_o)[64],
-                                                     double (*s_p)[64])
+                                                     int Wk, int Hk, double scale, int seg, const double *__restrict__ carry,
+                                                     double (*s_e)[64], double (*s_o)[64], double (*s_p)[64])
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
@@ -1683,28 +1687,41 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
         }
     };
 
+    // OpenCV's vertical chain (ColumnCarry's note): the segment at the top primes it -- vsum = row 0 * (m + 2), a float
+    // product, plus rows 1 .. m - 1 --, the others continue from the chain's value after the row above them
     double vs[5][2];
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-        vs[c][0] = vs[c][1] = 0.0;
-#pragma unroll 3
-    for (int j = -M; j <= M; j++) {
+    if (r0 == 0) {
         float2 v[5];
-        load_row(clampi(r0 + j, 0, Hk - 1), v);
+        load_row(0, v);
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            vs[c][0] += (double)v[c].x;
-            vs[c][1] += (double)v[c].y;
+            vs[c][0] = (double)(v[c].x * (float)(M + 2));
+            vs[c][1] = (double)(v[c].y * (float)(M + 2));
+        }
+        for (int j = 1; j < M; j++) {
+            load_row(min(j, Hk - 1), v);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c][0] += (double)v[c].x;
+                vs[c][1] += (double)v[c].y;
+            }
+        }
+    } else {
+        const double *C = carry + (((size_t)by * gridDim.z + pair) * 5) * Wk;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            vs[c][0] = C[(size_t)c * Wk + ca];
+            vs[c][1] = C[(size_t)c * Wk + cb];
         }
     }
     // rows entering / leaving the window, prefetched PD steps ahead (slot t % PD serves step
-    // r0+1+t); always loaded from clamped row indices, so no branch surrounds a load
+    // r0+t); always loaded from clamped row indices, so no branch surrounds a load
     constexpr int PD = BLUR_PREFETCH;
     float2 pin[PD][5], pout[PD][5];
 #pragma unroll
     for (int t = 0; t < PD; t++) {
-        load_row(min(r0 + 1 + t + M, Hk - 1), pin[t]);
-        load_row(clampi(r0 + t - M, 0, Hk - 1), pout[t]);
+        load_row(min(r0 + t + M, Hk - 1), pin[t]);
+        load_row(clampi(r0 + t - M - 1, 0, Hk - 1), pout[t]);
     }
     const bool is_out = lane >= HALO / 2 && lane < 64 - HALO / 2 && c0 < Wk;
     for (int yb = r0; yb < r1; yb += PD) {
@@ -1713,9 +1730,9 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
         const int y = yb + h;
         if (y >= r1)
             break;
-        if (y > r0) {
-            float2(&in)[5] = pin[(h + PD - 1) % PD];
-            float2(&out)[5] = pout[(h + PD - 1) % PD];
+        {
+            float2(&in)[5] = pin[h];
+            float2(&out)[5] = pout[h];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 // OpenCV's increment: vsum[x] += srow1[x] - srow0[x] -- the difference in float, accumulated in double
@@ -1723,7 +1740,7 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
                 vs[c][1] += (double)(in[c].y - out[c].y);
             }
             load_row(min(y + PD + M, Hk - 1), in);                // step y+PD: entering row
-            load_row(clampi(y + PD - 1 - M, 0, Hk - 1), out);     //            leaving row
+            load_row(clampi(y + PD - M - 1, 0, Hk - 1), out);     //            leaving row
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1776,7 +1793,8 @@ __device__ __forceinline__ void blur_solve_wave_body(const float *__restrict__ M
 
 template <int M>
 __global__ void __launch_bounds__(64, 3)
-k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, double scale, int seg)
+k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk, double scale, int seg,
+                  const double *__restrict__ carry)
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
@@ -1785,15 +1803,15 @@ k_blur_solve_wave(const float *__restrict__ Min, float2 *__restrict__ flow_out, 
     xcd_tile(bx, by);
     const int first = (int)bx * OUTC - HALO;
     if (first >= 0 && first + 127 < Wk)
-        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o, s_p);
+        blur_solve_wave_body<M, true>(Min, flow_out, Wk, Hk, scale, seg, carry, s_e, s_o, s_p);
     else
-        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, s_e, s_o, s_p);
+        blur_solve_wave_body<M, false>(Min, flow_out, Wk, Hk, scale, seg, carry, s_e, s_o, s_p);
 }
 
 // ---------------------------------------------------------------------------------
 // One pixel of A3 split into "issue the loads" and "finish the arithmetic" (one column per lane),
 // so a marching wave can keep the gathers of later rows in flight: used by the producers of
-// k_flow_iter_pc below.  Same statements as update_matrix_px, with the multiply-adds fused (see gather1_finish).
+// k_flow_iter_pc below.  Same statements as update_matrix_px, rounding for rounding (see gather1_finish).
 // ---------------------------------------------------------------------------------
 struct Gather1 {
     float2u r0a, r0b;            // R0 at the pixel: (c0, c1), (c2, c3)
@@ -1880,7 +1898,10 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
 }
 
 // update_matrix_px's statements on the channel pairs as they were loaded: per channel the bilinear sum is
-// ((a00 * t(x1) + a01 * t(x1 + 1)) + a10 * b(x1)) + a11 * b(x1 + 1), two channels per packed instruction.
+// ((a00 * t(x1) + a01 * t(x1 + 1)) + a10 * b(x1)) + a11 * b(x1 + 1), two channels per packed instruction, every
+// operation rounded on its own (no contraction: the file is built with -ffp-contract=off), so this M is
+// k_update_matrices' and the CPU path's bit for bit.  (Round 2 let the compiler fuse these multiply-adds, +1.8 %
+// frames/s at 4K; M then differed in the last bit, which was half of why border pixels flipped: DESIGN.md section 4.)
 // wx, wy: the edge weights of the column and of the row.  FarnebackUpdateMatrices multiplies border[x] (x < 5),
 // border[W-1-x] (x >= W-5), border[y], border[H-1-y]; from 10 x 10 up at most one factor per direction differs
 // from 1 (and a factor of exactly 1 changes nothing), so the product is border(min(x, W-1-x)) * border(min(y,
@@ -1891,23 +1912,11 @@ __device__ __forceinline__ void gather1_issue(Gather1 &g, const PlaneBases &pb, 
 template <bool UNWEIGHTED = false>
 __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float wy, float m[5])
 {
-    // The one place where this library lets the compiler contract a * b + c into fused multiply-adds (the file is
-    // built with -ffp-contract=off): 10 vector instructions less per producer row, +1.8 % frames/s at 4K.  The
-    // values of M then differ from k_update_matrices' in the last bit (each fused operation rounds once instead of
-    // twice); the one-kernel iteration is held to the path's 1e-4 tolerance, not to bit-identity.
-#pragma clang fp contract(fast)
     const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     float2u r23 = a00 * g.t01.xy + a01 * g.t01.zw + a10 * g.b01.xy + a11 * g.b01.zw;
     float2u r45 = a00 * g.t23.xy + a01 * g.t23.zw + a10 * g.b23.xy + a11 * g.b23.zw;
-#ifdef TF_PC_C4_PAIRED
-    // c4 as its two columns side by side: (a00 t(x1) + a10 b(x1), a01 t(x1+1) + a11 b(x1+1)), one packed multiply, one
-    // packed multiply-add and an addition instead of a multiply and three multiply-adds in a chain
-    const float2u c4 = float2u{a00, a01} * g.t4 + float2u{a10, a11} * g.b4;
-    float r6 = c4.x + c4.y;
-#else
     float r6 = a00 * g.t4.x + a01 * g.t4.y + a10 * g.b4.x + a11 * g.b4.y;
-#endif
     r45 = (g.r0b + r45) * 0.5f;
     r6 = (g.r0c + r6) * 0.25f;
     const float o6 = g.r0c * 0.5f;
@@ -1934,274 +1943,352 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float
 }
 
 // ---------------------------------------------------------------------------------
-// A3+A4 fused, roles split inside the workgroup (the default on large levels).  Four waves march a strip
-// of 128 columns together: waves 0-1 are PRODUCERS (one column per lane: they compute row e of M
-// from R0, R1 and the flow -- gather1_issue / gather1_finish, the next row's loads in flight --, keep the window's
-// 2M+1 rows of their column in an LDS ring, slide the vertical window sum over it in double and
-// publish that sum), waves 2-3 are CONSUMERS taking turns by row (two columns per lane: a consumer adds
-// the sums across columns -- pair sums through LDS, as k_blur_solve_wave --, solves and writes the
-// flow; it copies what it needs of a row's sums out of s_v before the step's barrier and then has two
-// steps for the rest, so the producers set the pace).  One workgroup barrier per row, sums double-buffered
-// by step parity.  M is never stored: the window costs 38 KB of LDS per 112 output columns, 53.8 KB
-// per workgroup, 3 workgroups = 12 waves per CU.
+// The vertical window sums, kept as FarnebackUpdateFlow_Blur keeps them.  OpenCV holds ONE running sum per column and
+// channel for the whole image: a double primed with (m + 2) copies of row 0 -- a FLOAT product -- plus rows 1 .. m - 1,
+// which then receives, row after row from row 0, the FLOAT difference of the row that enters the window and the row that
+// leaves it (optflowgf.cpp, FarnebackUpdateFlow_Blur: `vsum[x] += srow1[x] - srow0[x]`).  Every sum so carries the roundings of all the float
+// differences above it, ~1e-7 relative: a march that starts its sums afresh at a segment's first row gets other
+// roundings, and that much decides FarnebackUpdateMatrices' in-frame test for the rare border pixel whose sample point
+// sits within float resolution of the last row or column.  The marching kernels therefore run
+// OpenCV's chain: the segment at the top of a column primes it as OpenCV does, every other segment starts from the
+// chain's value after the row above it (its "carry").  Two ways to have that value:
+//   mode 1 (hand-off inside the launch): the segments of a column run one after the other; a workgroup draws a ticket,
+//          tickets are dealt segment-major, and a segment waits for the carry its predecessor -- an earlier ticket, so
+//          resident or finished -- publishes when it is done.  The chain is then OpenCV's operation for operation: the
+//          vertical sums are bit-identical to the CPU path's.  Costs nothing where a launch has more columns of
+//          workgroups than the chip has slots (the predecessor is done before the successor is dispatched).
+//   mode 0 (carries from a pre-pass): where a launch is small, segments must run side by side.  A first launch marches
+//          every segment for its sum of differences alone (k_flow_carry_pc; k_blur_carry where M is in memory), a scan
+//          adds them up along each column (k_carry_scan), and the segments read their carry.  Adding a segment's
+//          differences up before adding them to the chain re-associates double additions: ~1e-16 relative.
+// The host picks per launch (choose_march).
 // ---------------------------------------------------------------------------------
-// FLOW: where the iteration's input flow comes from -- 0: zero (coarsest scale), 1: flow_in, 2: A5 on the
-// fly, resize(coarser flow, INTER_LINEAR) * 1/pyr_scale through `fi` (the statements of k_flow_upsample;
-// the column's table entries are loaded once per lane, the row's are the same address for all lanes).
-#define TF_PC_THREADS (128 + 64 * TF_PC_CONS)
+struct ColumnCarry {
+    int mode;             // 0: carry[((seg * pairs + pair) * 5 + c) * Wk + x], written by an earlier launch
+                          // 1: carry[(((seg * pairs + pair) * strips + strip) * 5 + c) * 128 + column of the strip], handed over in the launch
+    int segs, pairs, strips;
+    double *carry;
+    unsigned *flags;      // mode 1: [((seg * pairs + pair) * strips + strip) * 2 + producer wave] == epoch once that wave's carries are stored
+    unsigned epoch;       // never 0; a handle counts its chained launches
+    unsigned *ticket;     // mode 1: one counter per handle, never reset: this launch owns tickets ticket_base .. ticket_base + workgroups - 1
+    unsigned ticket_base;
+    unsigned *fault;      // host-visible word (pinned): set if a wait for a carry gave up
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define TF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// One wave waits for the word its predecessor stores (cdna_hip_programming.md, guideline 16: the word is written by an
+// agent-scope atomic store after the storing wave drained its payload stores; polled relaxed; the payload is then read
+// with agent-scope loads, which pass the L1).  Bounded: after ~5 s the wave sets the handle's fault word and goes on
+// (with a wrong carry -- the host turns the fault into an error), so every wave of the grid reaches its end.
+__device__ __forceinline__ void wait_for_epoch(unsigned *flag, unsigned epoch, unsigned *fault)
+{
+    gu32 *f = (gu32 *)flag;
+    if (__hip_atomic_load(f, TF_RLX_AGENT) != epoch) {
+        const unsigned long long t0 = wall_clock64(); // 100 MHz
+        while (__hip_atomic_load(f, TF_RLX_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t0 > 500000000ull) {
+                __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: the loads that follow stay behind the poll)
+}
+
+// ---------------------------------------------------------------------------------
+// One column per lane, row after row of the 2x2 systems M (A3, with A5 on the fly): what the producer waves of
+// k_flow_iter_pc and the lanes of k_flow_carry_pc do.  The gathers of row e + 1 are in flight while row e is finished
+// (two or more rows ahead were measured slower), the flow of row e + 2 is the first load of a step, and for A5 the two
+// lerps of a row's flow run one step after its four coarse loads.
+// FLOW: where the iteration's input flow comes from -- 0: zero (coarsest scale), 1: flow_in, 2: A5 on the fly,
+// resize(coarser flow, INTER_LINEAR) * 1/pyr_scale through `fi` (the statements of k_flow_upsample; the column's
+// table entries are loaded once per lane, the row's are the same address for all lanes).
+// ---------------------------------------------------------------------------------
+template <int FLOW>
+struct RowProducer {
+    struct FlowRaw {
+        float2 a, b, d, e; // FLOW == 2: the coarse flow at (sx, sy0), (sx + 1, sy0), (sx, sy1), (sx + 1, sy1); else a = the flow
+        float fy;
+    };
+    int Wk, Hk, x;
+    PlaneBases pb;
+    const float2 *fin, *coarse;
+    int Wc, Hc;
+    const int *yofs;
+    const float *yfrac;
+    float mul;
+    int up_sx, up_sx1;
+    float up_fx;
+    bool up_edge;
+    float wx;          // the column's edge weight
+    Gather1 G;         // the row being gathered
+    FlowRaw F;         // the flow of the row after it
+    int y_fin, y_iss;  // the (clamped) rows of G and F
+    int sy_q;          // FLOW == 2: the table entries of the row whose flow is loaded next (scalar loads, fetched a step early)
+    float fy_q;
+
+    // rows_ofs / rows_frac: fi.yofs / fi.yfrac as __restrict__ kernel arguments of their own -- a march reads a row's
+    // entries with SCALAR loads (the same address for all lanes), and the compiler only issues those for memory it can
+    // prove nothing in the kernel writes; behind the ticket's atomic a pointer out of the by-value struct no longer
+    // qualifies and the entries came as two vector loads per step (+6 % vector-memory instructions, +15 % time of an
+    // A5 launch)
+    __device__ __forceinline__ void init(const float *R, const float2 *flow_in, const FlowInit &fi, const int *rows_ofs,
+                                         const float *rows_frac, int pair, size_t Nk, int Wk_, int Hk_, int x_)
+    {
+        Wk = Wk_;
+        Hk = Hk_;
+        x = x_;
+        const int2 im = pair_images(fi, pair);
+        pb = plane_bases(R + (size_t)im.x * 5 * Nk, R + (size_t)im.y * 5 * Nk, Nk, Wk);
+        fin = FLOW == 1 ? flow_in + (size_t)pair * Nk : nullptr;
+        coarse = FLOW == 2 ? fi.src + (size_t)pair * fi.Wc * fi.Hc : nullptr;
+        Wc = fi.Wc;
+        Hc = fi.Hc;
+        yofs = rows_ofs;
+        yfrac = rows_frac;
+        mul = fi.mul;
+        up_sx = up_sx1 = 0;
+        up_fx = 0.f;
+        up_edge = false;
+        if (FLOW == 2) {
+            up_sx = fi.xofs[x];
+            up_fx = fi.xfrac[x];
+            up_edge = up_sx >= Wc - 1; // resize.cpp: dx >= xmax copies S[sx]
+            up_sx1 = min(up_sx + 1, Wc - 1);
+        }
+        wx = border_weight(min(x, Wk - 1 - x));
+        sy_q = 0;
+        fy_q = 0.f;
+    }
+    __device__ __forceinline__ void fetch_row_entries(int row)
+    {
+        if (FLOW == 2) {
+            sy_q = yofs[row];
+            fy_q = yfrac[row];
+        }
+    }
+    __device__ __forceinline__ FlowRaw load_flow(int row) const // row: clamped to the level; FLOW == 2: its table entries in sy_q, fy_q
+    {
+        FlowRaw r;
+        r.a = r.b = r.d = r.e = make_float2(0.f, 0.f);
+        r.fy = 0.f;
+        if (FLOW == 1) {
+            const unsigned off = ((unsigned)row * Wk + x) * 8u;
+            r.a = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
+        } else if (FLOW == 2) {
+            const int sy = sy_q;
+            r.fy = fy_q;
+            const int sy0 = clampi(sy, 0, Hc - 1), sy1 = clampi(sy + 1, 0, Hc - 1);
+            r.a = coarse[sy0 * Wc + up_sx];
+            r.b = coarse[sy0 * Wc + up_sx1];
+            r.d = coarse[sy1 * Wc + up_sx];
+            r.e = coarse[sy1 * Wc + up_sx1];
+        }
+        return r;
+    }
+    __device__ __forceinline__ float2 flow_of(const FlowRaw &r) const
+    {
+        if (FLOW != 2)
+            return r.a;
+        const float a0 = 1.f - up_fx;
+        float2 h0 = make_float2(r.a.x * a0 + r.b.x * up_fx, r.a.y * a0 + r.b.y * up_fx);
+        float2 h1 = make_float2(r.d.x * a0 + r.e.x * up_fx, r.d.y * a0 + r.e.y * up_fx);
+        if (up_edge) {
+            h0 = r.a;
+            h1 = r.d;
+        }
+        const float b0 = 1.f - r.fy;
+        return make_float2((h0.x * b0 + h1.x * r.fy) * mul, (h0.y * b0 + h1.y * r.fy) * mul);
+    }
+    // before the first next(): the march starts at row e0 (rows outside the level are their nearest row: replicated border)
+    __device__ __forceinline__ void start(int e0)
+    {
+        y_fin = clampi(e0, 0, Hk - 1);
+        y_iss = clampi(e0 + 1, 0, Hk - 1);
+        fetch_row_entries(y_fin);
+        gather1_issue(G, pb, Wk, Hk, x, y_fin, flow_of(load_flow(y_fin)));
+        fetch_row_entries(y_iss);
+        F = load_flow(y_iss);
+        fetch_row_entries(clampi(e0 + 2, 0, Hk - 1));
+    }
+    // Row e of M (the e-th call after start(e0) is for row e0 + e ...: the caller passes the unclamped row).  INTERIOR
+    // (compile time): rows e .. e + 3 lie inside the level, row e at least 5 rows from its top and bottom and the column
+    // at least 5 from its sides, so nothing is clamped and the pixel's edge weight is 1 (x * 1.f == x: the same bits) --
+    // the scalar clamps and selects of the general step and the five multiplications by the weight are not issued.
+    template <bool INTERIOR>
+    __device__ __forceinline__ void next(int e, float m[5])
+    {
+        // the row's edge weight is wave-uniform: border_weight() as scalar selects on the floats' bits (0.14f, 0.4472f, 1.f)
+        const int dyb = min(y_fin, Hk - 1 - y_fin);
+        const unsigned wyb = INTERIOR ? 0x3f800000u : (dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u));
+        // the flow of the row after next is the first load of the step: when the step ends by moving it into
+        // place the wave waits for a load a whole step old, not for one it has just issued
+        const int y_flow = INTERIOR ? e + 2 : clampi(e + 2, 0, Hk - 1);
+        const FlowRaw Fn = load_flow(y_flow);
+        fetch_row_entries(INTERIOR ? e + 3 : clampi(e + 3, 0, Hk - 1));
+        gather1_finish<INTERIOR>(G, wx, __uint_as_float(wyb), m);
+        gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
+        F = Fn;
+        y_fin = y_iss;
+        y_iss = y_flow;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// A3+A4 fused, roles split inside the workgroup (the default on large levels).  Four waves march a strip
+// of 128 columns together: waves 0-1 are PRODUCERS (one column per lane: RowProducer makes row e of M
+// from R0, R1 and the flow; the lane keeps the window's 2M+1 rows of its column in an LDS ring, runs OpenCV's
+// vertical running sum over it in double and publishes that sum), waves 2-3 are CONSUMERS taking turns by row
+// (two columns per lane: a consumer adds the sums across columns -- pair sums through LDS, as
+// k_blur_solve_wave --, solves and writes the flow; it copies what it needs of a row's sums out of s_v before
+// the step's barrier and then has two steps for the rest, so the producers set the pace).  One workgroup
+// barrier per row, sums double-buffered by step parity.  M is never stored: the window costs 38 KB of LDS per
+// 112 output columns, 53.8 KB per workgroup, 3 workgroups = 12 waves per CU.
+// A workgroup marches rows r0 .. r1 - 1 of its strip.  Its first WIN = 2M+1 steps only fill the ring (rows
+// r0 - M - 1 .. r0 + M - 1: what the window of row r0 - 1 held); then the chain continues from the carry (see
+// ColumnCarry) and every step slides it down one row: vs += (double)(entering row - leaving row), the difference in float.
+// ---------------------------------------------------------------------------------
 #ifndef TF_PC_CONS
 #define TF_PC_CONS 2 // consumer waves per workgroup: they take turns by row (1: 1701, 2: 1723 frames/s at 4K x 32)
 #endif
+#define TF_PC_THREADS (128 + 64 * TF_PC_CONS)
 template <int M, int FLOW>
 __global__ void __launch_bounds__(TF_PC_THREADS)
 k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
-               int Hk, double scale, int seg, FlowInit fi)
+               int Hk, double scale, int seg, FlowInit fi, const int *__restrict__ rows_ofs, const float *__restrict__ rows_frac,
+               ColumnCarry cc)
 {
     static_assert(M & 1, "the pair-sum window needs an odd half-width");
     // A strip's halo is M columns rounded up to whole lanes: 112 outputs per strip for M = 7, every strip starting on
-    // a multiple of 8 columns = 64 bytes of the 8-byte planes.  TF_PC_HALO_ODD (experiment): exactly M halo columns, 114
-    // outputs per strip, 34 instead of 35 strips across a 4K row -- and 3 % MORE time per launch (2.94 against 2.85 ms
-    // at 4K x 32): the strips then start on odd columns and every 512-byte row piece a wave loads straddles one more
-    // 128-byte line.
-#ifdef TF_PC_HALO_ODD
-    constexpr int HALO = M;
-#else
+    // a multiple of 8 columns = 64 bytes of the 8-byte planes (114 outputs on strips that start on odd columns were
+    // measured 3 % slower: every 512-byte row piece a wave loads then straddles one more 128-byte line).
     constexpr int HALO = (M + 1) & ~1;
-#endif
     constexpr int OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
-#ifndef TF_PC_GRING
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
-#endif
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
     __shared__ double s_p[TF_PC_CONS][5][64]; // each consumer's pair sums
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
     int pair;
-    if (fi.grid_pairs > 0) {
-        // workgroup L runs on XCD L % 8 (dispatch is round-robin); q = L / 8 is its place in that XCD's queue
-        const unsigned xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const unsigned groups = fi.grid_strips * fi.grid_segs, per_xcd = (groups + 7) >> 3;
-        const unsigned g = xcd * per_xcd + q / fi.grid_pairs;
-        if (q / fi.grid_pairs >= per_xcd || g >= groups)
-            return; // padding of the last XCD's share (the whole workgroup leaves before any barrier)
-        pair = q % fi.grid_pairs;
-        bx = g % fi.grid_strips;
-        by = g / fi.grid_strips;
+    if (cc.mode == 1) {
+        // Segment-major tickets: every segment of a column has a later ticket than the segment above it, and whoever
+        // holds a ticket is resident, so a wait for a predecessor always ends, whatever order the hardware dispatches in.
+        // (the ticket travels through a word of s_p, which the consumers first touch many barriers later: a word of its
+        // own would be the 43rd LDS granule of 1280 bytes and cost the CU its third workgroup)
+        unsigned *s_ticket = reinterpret_cast<unsigned *>(&s_p[0][0][0]);
+        if (threadIdx.x == 0)
+            *s_ticket = __hip_atomic_fetch_add(cc.ticket, 1u, TF_RLX_AGENT) - cc.ticket_base;
+        __syncthreads();
+        const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket), per_seg = (unsigned)(cc.pairs * cc.strips);
+        __syncthreads(); // every wave has read it
+        by = t / per_seg;
+        const unsigned rem = t - by * per_seg;
+        pair = (int)(rem / (unsigned)cc.strips);
+        bx = rem - (unsigned)pair * (unsigned)cc.strips;
     } else {
         xcd_tile(bx, by);
         pair = blockIdx.z;
     }
     const size_t Nk = (size_t)Wk * Hk;
     const int r0 = by * seg, r1 = min(r0 + seg, Hk);
-    // step s: producers make entering row e = r0 - M + s (s < n_rows) and its window sums; the consumer
-    // turns the sums of step s - 1 into the flow of row r0 + (s - 1) - 2M
-    const int n_rows = (r1 - r0) + 2 * M, nsteps = n_rows + 1;
-#ifndef TF_PC_GRING
-    for (int i = threadIdx.x; i < WIN * 5 * 128; i += TF_PC_THREADS)
-        (&ring[0][0][0])[i] = 0.f; // rows "above" the first window count as zero: the warm-up subtracts them
-    __syncthreads();
-#endif
+    // step s: the producers make row e = r0 - M - 1 + s of M (s < n_rows) and, from s = WIN on, the window sums of row
+    // e - M; a consumer turns the sums of step s - 1 into the flow of row r0 + (s - 1) - WIN
+    const int e0 = r0 - M - 1, n_rows = (r1 - r0) + WIN, nsteps = n_rows + 1;
     if (wave < 2) {
-        const int col = (wave & 1) * 64 + lane;
+        const int col = wave * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
-        const int2 im = pair_images(fi, pair);
-        const PlaneBases pb = plane_bases(R + (size_t)im.x * 5 * Nk, R + (size_t)im.y * 5 * Nk, Nk, Wk);
-        const float2 *fin = FLOW == 1 ? flow_in + (size_t)pair * Nk : nullptr;
-        const float2 *coarse = FLOW == 2 ? fi.src + (size_t)pair * fi.Wc * fi.Hc : nullptr;
-        int up_sx = 0, up_sx1 = 0;
-        float up_fx = 0.f;
-        bool up_edge = false;
-        if (FLOW == 2) {
-            up_sx = fi.xofs[x];
-            up_fx = fi.xfrac[x];
-            up_edge = up_sx >= fi.Wc - 1; // resize.cpp: dx >= xmax copies S[sx]
-            up_sx1 = min(up_sx + 1, fi.Wc - 1);
-        }
-        // The flow of a row arrives in two halves: the loads (issued a step ahead, behind that step's gathers) and,
-        // for A5 on the fly, the two lerps -- done at the top of the NEXT step, when the four coarse values have
-        // had a whole step to arrive (done at once they would be waited for in the step that issued them).
-        struct FlowRaw {
-            float2 a, b, d, e; // FLOW == 2: the coarse flow at (sx, sy0), (sx + 1, sy0), (sx, sy1), (sx + 1, sy1); else a = the flow
-            float fy;
-        };
-        // (FLOW == 2: the row's entries of the upsampling tables -- scalar loads -- are fetched a step before the
-        // flow loads that need them: sy_q, fy_q hold those of the row whose flow is loaded next)
-        int sy_q = 0;
-        float fy_q = 0.f;
-        auto fetch_row_entries = [&](int row) {
-            if (FLOW == 2) {
-                sy_q = fi.yofs[row];
-                fy_q = fi.yfrac[row];
-            }
-        };
-        auto load_flow = [&](int row) { // row: already clamped to the level; FLOW == 2: its table entries in sy_q, fy_q
-            FlowRaw r;
-            r.a = r.b = r.d = r.e = make_float2(0.f, 0.f);
-            r.fy = 0.f;
-            if (FLOW == 1) {
-                const unsigned off = ((unsigned)row * Wk + x) * 8u;
-                r.a = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(fin) + off);
-            } else if (FLOW == 2) {
-                const int sy = sy_q;
-                r.fy = fy_q;
-                const int sy0 = clampi(sy, 0, fi.Hc - 1), sy1 = clampi(sy + 1, 0, fi.Hc - 1);
-                r.a = coarse[sy0 * fi.Wc + up_sx];
-                r.b = coarse[sy0 * fi.Wc + up_sx1];
-                r.d = coarse[sy1 * fi.Wc + up_sx];
-                r.e = coarse[sy1 * fi.Wc + up_sx1];
-            }
-            return r;
-        };
-        auto flow_of = [&](const FlowRaw &r) {
-            if (FLOW != 2)
-                return r.a;
-            const float a0 = 1.f - up_fx;
-            float2 h0 = make_float2(r.a.x * a0 + r.b.x * up_fx, r.a.y * a0 + r.b.y * up_fx);
-            float2 h1 = make_float2(r.d.x * a0 + r.e.x * up_fx, r.d.y * a0 + r.e.y * up_fx);
-            if (up_edge) {
-                h0 = r.a;
-                h1 = r.d;
-            }
-            const float b0 = 1.f - r.fy;
-            return make_float2((h0.x * b0 + h1.x * r.fy) * fi.mul, (h0.y * b0 + h1.y * r.fy) * fi.mul);
-        };
-        const float wx = border_weight(min(x, Wk - 1 - x));
-        // One row of gathers in flight: those of row e + 1 are issued while row e is finished (two or more
-        // rows ahead were measured slower).  The three clamped rows a step works with (the one being finished,
-        // the one whose gathers are issued, the one whose flow is loaded) move along by one: one clamp per step.
-        Gather1 G;
-        int y_fin = clampi(r0 - M, 0, Hk - 1), y_iss = clampi(r0 - M + 1, 0, Hk - 1);
-        fetch_row_entries(y_fin);
-        gather1_issue(G, pb, Wk, Hk, x, y_fin, flow_of(load_flow(y_fin)));
-        fetch_row_entries(y_iss);
-        FlowRaw F = load_flow(y_iss);
-        fetch_row_entries(clampi(r0 - M + 2, 0, Hk - 1));
+        RowProducer<FLOW> P;
+        P.init(R, flow_in, fi, rows_ofs, rows_frac, pair, Nk, Wk, Hk, x);
+        P.start(e0);
         double vs[5] = {0, 0, 0, 0, 0};
         int slot = 0;
-#ifdef TF_PC_GRING
-        // this workgroup's region of the global ring, [slot][channel][column]; this lane only ever touches its column
-        const size_t wg_linear = fi.grid_pairs > 0 ? (size_t)blockIdx.x
-                                                   : ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        float *gr = fi.gring + wg_linear * (size_t)(WIN * 5 * 128) + col;
-        float old_row[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#endif
-#ifdef TF_PC_RING_EARLY
-        float old_row[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // the ring starts out zero
-#endif
-#ifdef TF_PC_TIMING
-        // Experiment: where a step's cycles go (s_memtime at the phase boundaries of one wave, summed over the march
-        // and printed by one workgroup of the level-0 launch).  Reading the clock waits for LDS and scalar memory
-        // (lgkmcnt), so the phases are slightly longer than in the shipped kernel.
-        long long tk_a = 0, tk_b = 0, tk_c = 0;
-#define TF_TICK() __builtin_readcyclecounter()
-#endif
-        // One step of a producer.  INTERIOR (compile time): the step's three rows (finished, issued, flow loaded) and the
-        // row whose table entries are fetched lie inside the level, the finished row is at least 5 rows from its top
-        // and bottom and the strip's columns at least 5 from its sides, so nothing is clamped and the pixel's edge weight
-        // is 1 (x * 1.f == x: the same bits) -- the scalar clamps and selects of the general step and the five
-        // multiplications by the weight are not even issued.  A march runs three loops: the rows at the top
-        // of the level, the interior, the rows at the bottom (and the steps that only drain the window).
-        auto step = [&](int s, auto interior) {
-            constexpr bool INTERIOR = decltype(interior)::value;
-#ifdef TF_PC_TIMING
-            const long long tk0 = TF_TICK();
-            long long tk1 = tk0, tk2 = tk0;
-#endif
-            if (INTERIOR || s < n_rows) {
-                float m[5];
-#ifdef TF_PC_GRING
-                // the row that leaves the window, written WIN steps ago by this very lane (zero while the window fills):
-                // read past the L1 (a device-scope load), a whole step before it is needed
-                if (s >= WIN) {
+        // The ring's first WIN rows.  The segment at the top of the level also primes the chain, statement for statement
+        // as FarnebackUpdateFlow_Blur does: vsum = row 0 * (m + 2), a float product; vsum += row y for y = 1 .. m - 1.
+        for (int s = 0; s < WIN; s++) {
+            float m[5];
+            P.template next<false>(e0 + s, m);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                ring[slot][c][col] = m[c];
+            if (r0 == 0) {
+                if (s == 0) {
 #pragma unroll
                     for (int c = 0; c < 5; c++)
-                        old_row[c] = __hip_atomic_load(gr + (slot * 5 + c) * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#endif
-                // the row's edge weight is wave-uniform: border_weight() as scalar selects on the floats' bits (0.14f, 0.4472f, 1.f)
-                const int dyb = min(y_fin, Hk - 1 - y_fin);
-                const unsigned wyb = INTERIOR ? 0x3f800000u : (dyb < 2 ? 0x3e0f5c29u : (dyb < 5 ? 0x3ee4f766u : 0x3f800000u));
-                // the flow of the row after next is the first load of the step: when the step ends by moving it into
-                // place the wave waits for a load a whole step old, not for one it has just issued
-                const int y_flow = INTERIOR ? r0 - M + s + 2 : clampi(r0 - M + s + 2, 0, Hk - 1);
-                const FlowRaw Fn = load_flow(y_flow);
-                fetch_row_entries(INTERIOR ? r0 - M + s + 3 : clampi(r0 - M + s + 3, 0, Hk - 1));
-                gather1_finish<INTERIOR>(G, wx, __uint_as_float(wyb), m);
-                gather1_issue(G, pb, Wk, Hk, x, y_iss, flow_of(F));
-                F = Fn;
-                y_fin = y_iss;
-                y_iss = y_flow;
-#ifdef TF_PC_TIMING
-                tk1 = TF_TICK();
-#endif
-                // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
-                // only this lane ever touches its column of the ring
-#ifdef TF_PC_GRING
-                // the leaving row was loaded at the top of the step (below); the entering row takes its place
+                        vs[c] = (double)(m[c] * (float)(M + 2));
+                } else if (s >= M + 2 && s <= 2 * M) { // rows 1 .. M - 1 (beyond the last row: the last row again)
 #pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    gr[(slot * 5 + c) * 128] = m[c];
-                    vs[c] += (double)(m[c] - old_row[c]);
-                    s_v[s & 1][c][col] = vs[c];
+                    for (int c = 0; c < 5; c++)
+                        vs[c] += (double)m[c];
                 }
-                slot = slot + 1 == WIN ? 0 : slot + 1;
-#elif defined(TF_PC_RING_EARLY)
-                // Experiment: the leaving row of the NEXT step is read at the end of this one (it sits in the next slot,
-                // which nothing writes in between), so its LDS round trips end in the barrier's shadow
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    ring[slot][c][col] = m[c];
-                    vs[c] += (double)(m[c] - old_row[c]);
-                    s_v[s & 1][c][col] = vs[c];
-                }
-                slot = slot + 1 == WIN ? 0 : slot + 1;
+            }
+            slot = slot + 1 == WIN ? 0 : slot + 1;
+            lds_barrier();
+        }
+        if (r0 != 0) { // the chain's value after row r0 - 1
+            if (cc.mode == 1) {
+                const size_t item = ((size_t)by * cc.pairs + pair) * cc.strips + bx;
+                wait_for_epoch(cc.flags + item * 2 + wave, cc.epoch, cc.fault);
+                gu64 *C = (gu64 *)(cc.carry + item * (5 * 128) + col);
 #pragma unroll
                 for (int c = 0; c < 5; c++)
-                    old_row[c] = ring[slot][c][col];
-#else
+                    vs[c] = __longlong_as_double((long long)__hip_atomic_load(C + c * 128, TF_RLX_AGENT));
+            } else {
+                const double *C = cc.carry + (((size_t)by * cc.pairs + pair) * 5) * Wk + x;
 #pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const float old = ring[slot][c][col];
-                    ring[slot][c][col] = m[c];
-                    vs[c] += (double)(m[c] - old); // OpenCV's increment: a float difference accumulated in double (old = 0 while the window fills)
-                    s_v[s & 1][c][col] = vs[c];
-                }
-                slot = slot + 1 == WIN ? 0 : slot + 1;
-#endif
-#ifdef TF_PC_TIMING
-                tk2 = TF_TICK();
-#endif
+                for (int c = 0; c < 5; c++)
+                    vs[c] = C[(size_t)c * Wk];
             }
+        }
+        // One step of the march proper.  A march runs three loops: the rows at the top of the level, the interior (see
+        // RowProducer::next), the rows at the bottom.
+        auto step = [&](int s, auto interior) {
+            constexpr bool INTERIOR = decltype(interior)::value;
+            float m[5];
+            P.template next<INTERIOR>(e0 + s, m);
+            // the row that leaves the window sits in the slot the new row takes (e - WIN == e mod WIN);
+            // only this lane ever touches its column of the ring
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float old = ring[slot][c][col];
+                ring[slot][c][col] = m[c];
+                vs[c] += (double)(m[c] - old); // vsum[x] += srow1[x] - srow0[x]: a float difference accumulated in double
+                s_v[s & 1][c][col] = vs[c];
+            }
+            slot = slot + 1 == WIN ? 0 : slot + 1;
             lds_barrier();
-#ifdef TF_PC_TIMING
-            const long long tk3 = TF_TICK();
-            tk_a += tk1 - tk0;
-            tk_b += tk2 - tk1;
-            tk_c += tk3 - tk2;
-#endif
         };
-        // steps whose finished row e = r0 - M + s lies in [5, Hk - 6] (then e + 3 <= Hk - 1 too)
-        int s_in0 = min(max(5 - (r0 - M), 0), n_rows), s_in1 = min(max(Hk - 5 - (r0 - M), s_in0), n_rows);
+        // steps whose row e = e0 + s lies in [5, Hk - 6] (then e + 3 <= Hk - 1 too)
+        int s_in0 = min(max(5 - e0, WIN), n_rows), s_in1 = min(max(Hk - 5 - e0, s_in0), n_rows);
         // ... and only in strips whose 128 columns all lie at least 5 pixels inside the level (wave-uniform): there the
         // interior step also drops the edge weight's five multiplications
         const int strip0 = (int)bx * OUTC - HALO;
         if (strip0 < 5 || strip0 + 127 > Wk - 6)
-            s_in0 = s_in1 = 0;
-#ifdef TF_PC_NO_SPLIT
-        s_in0 = s_in1 = 0;
-#endif
-        int s = 0;
+            s_in0 = s_in1 = WIN;
+        int s = WIN;
         for (; s < s_in0; s++)
             step(s, std::false_type{});
         for (; s < s_in1; s++)
             step(s, std::true_type{});
-        for (; s < nsteps; s++)
+        for (; s < n_rows; s++)
             step(s, std::false_type{});
-#ifdef TF_PC_TIMING
-        if (lane == 0 && bx == 10 && by == 0 && pair == 0 && Wk >= 3000)
-            printf("pc-timing producer wave %d: %d steps; per step: gathers+matrix %lld, ring+sums %lld, barrier %lld (s_memtime ticks)\n",
-                   wave, nsteps, tk_a / nsteps, tk_b / nsteps, tk_c / nsteps);
-#endif
+        if (cc.mode == 1 && (int)by + 1 < cc.segs) {
+            // vs is the chain after row r1 - 1: the carry of the segment below.  Write-through stores, drained, then this
+            // wave's flag (each producer wave hands over its own 64 columns: no barrier between the two).
+            const size_t item = ((size_t)(by + 1) * cc.pairs + pair) * cc.strips + bx;
+            gu64 *C = (gu64 *)(cc.carry + item * (5 * 128) + col);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                __hip_atomic_store(C + c * 128, (unsigned long long)__double_as_longlong(vs[c]), TF_RLX_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store((gu32 *)(cc.flags + item * 2 + wave), cc.epoch, TF_RLX_AGENT);
+        }
+        lds_barrier(); // step n_rows: the consumers' last row
     } else {
         // The consumers take turns: wave 2 + k serves the steps with s % TF_PC_CONS == k.  In its step a consumer first
         // takes what it needs of the row's sums out of s_v (the sum of its two columns and one single column at each end of
@@ -2209,85 +2296,36 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         // buffer -- and then has until its next turn for the exchange of pair sums, the solve and the store.
         const int who = wave - 2;
         double(*sp)[64] = s_p[who];
-        // A lane's two columns are strip columns SH + 2 * lane and the next one.  With the halo rounded up to whole
-        // lanes (SH = 0) the first output column is an even strip column; with HALO = M (odd) the lanes own the pairs
-        // that START at an odd strip column (SH = 1: strip column 0 is only ever the single column at the left end of
-        // lane (M - 1) / 2's window, column 127 the one at the right end of the last output lane's), so the outputs are
-        // whole lanes again and a lane's 16-byte flow store stays 16-byte aligned.
-        constexpr int SH = HALO & 1;
-        const int c0 = (int)bx * OUTC - HALO + SH + 2 * lane;
-        constexpr int first_out = (HALO - SH) / 2, last_out = (128 - HALO - SH) / 2 - 1; // lanes whose two columns are outputs
-        static_assert((128 - HALO - SH) % 2 == 0 && last_out - first_out + 1 == OUTC / 2, "outputs are whole lanes");
+        // A lane's two columns are strip columns 2 * lane and the next one; the halo is whole lanes
+        const int c0 = (int)bx * OUTC - HALO + 2 * lane;
+        constexpr int first_out = HALO / 2, last_out = (128 - HALO) / 2 - 1; // lanes whose two columns are outputs
+        static_assert(last_out - first_out + 1 == OUTC / 2, "outputs are whole lanes");
         const bool is_out = lane >= first_out && lane <= last_out && c0 < Wk;
         const double eps = 1e-3 / (scale * scale);
         constexpr int kk = (M + 1) / 2;
-        const int lo = max(lane - kk, -SH), hi = min(lane + kk, 63); // (lane - kk = -1 with SH = 1: strip column 0)
-#ifdef TF_PC_TIMING
-        long long tk_a = 0, tk_b = 0, tk_c = 0;
-#endif
+        const int lo = max(lane - kk, 0), hi = min(lane + kk, 63);
         for (int s = 0; s < nsteps; s++) {
-#ifdef TF_PC_TIMING
-            const long long tk0 = TF_TICK();
-#endif
-            const int y = r0 + (s - 1) - 2 * M; // the row whose window the producers completed in step s - 1
+            const int y = r0 + (s - 1) - WIN; // the row whose window the producers completed in step s - 1
             const bool mine = (s % TF_PC_CONS) == who && y >= r0; // wave-uniform
             double p[5], left[5], right[5];
             if (mine) {
                 const double(*sv)[128] = s_v[(s - 1) & 1];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    p[c] = sv[c][SH + 2 * lane] + sv[c][min(SH + 2 * lane + 1, 127)]; // (lane 63 with SH = 1: never used)
-                    left[c] = sv[c][SH + 2 * lo + 1];
-                    right[c] = sv[c][SH + 2 * hi];
+                    p[c] = sv[c][2 * lane] + sv[c][2 * lane + 1];
+                    left[c] = sv[c][2 * lo + 1];
+                    right[c] = sv[c][2 * hi];
                 }
             }
-#ifdef TF_PC_TIMING
-            const long long tk1 = TF_TICK();
-#endif
             lds_barrier();
-#ifdef TF_PC_TIMING
-            const long long tk2 = TF_TICK();
-            tk_a += tk1 - tk0;
-            tk_b += tk2 - tk1;
-#endif
             if (mine) {
                 // The M pair sums of a window through sums of three: T[l] = P[l-1] + P[l] + P[l+1] replaces P in
                 // LDS (a lane keeps its own P), and the window is T[l] (M = 3), T[l-1] + T[l+1] - P[l] (M = 5) or
                 // T[l-2] + P[l] + T[l+2] (M = 7): four LDS accesses and four additions per channel instead of
                 // eight and six.  T of lanes 0 and 63 is not a sum of three and no output lane reads it.
+                // (The same exchange as whole-wave DPP shifts was measured 4 % slower: tools/variants/.)
                 static_assert(M == 3 || M == 5 || M == 7, "window sums from sums of three");
                 double t[5];
-#ifdef TF_PC_DPP
-                // Experiment: the same exchange as cross-lane moves instead of LDS round trips -- a
-                // double travels as two dwords, one whole-wave DPP shift (wave_shr:1 / wave_shl:1) per lane of distance.
-                // 60 vector moves per row for M = 7 instead of 10 LDS writes and 20 LDS reads: measured slower.
-                auto from_lower = [](double v) { // lane l receives lane l - 1's value (lane 0 keeps its own)
-                    int lo = __double2loint(v), hi = __double2hiint(v);
-                    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-                    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-                    return __hiloint2double(hi, lo);
-                };
-                auto from_upper = [](double v) { // lane l receives lane l + 1's value (lane 63 keeps its own)
-                    int lo = __double2loint(v), hi = __double2hiint(v);
-                    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-                    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-                    return __hiloint2double(hi, lo);
-                };
-                double tm[5], tp[5]; // T of the lanes one (M = 5) or two (M = 7) below / above
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    t[c] = (from_lower(p[c]) + p[c]) + from_upper(p[c]);
-                    tm[c] = tp[c] = 0.0;
-                    if (M == 5) {
-                        tm[c] = from_lower(t[c]);
-                        tp[c] = from_upper(t[c]);
-                    } else if (M == 7) {
-                        tm[c] = from_lower(from_lower(t[c]));
-                        tp[c] = from_upper(from_upper(t[c]));
-                    }
-                }
-                (void)sp;
-#else
 #pragma unroll
                 for (int c = 0; c < 5; c++)
                     sp[c][lane] = p[c];
@@ -2303,27 +2341,17 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                         sp[c][lane] = t[c];
                     lds_wave_sync();
                 }
-#endif
                 if (is_out) {
                     double g0[5], g1[5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         double common;
-#ifdef TF_PC_DPP
-                        if (M == 3)
-                            common = t[c];
-                        else if (M == 5)
-                            common = (tm[c] + tp[c]) - p[c];
-                        else
-                            common = (tm[c] + p[c]) + tp[c];
-#else
                         if (M == 3)
                             common = t[c];
                         else if (M == 5)
                             common = (sp[c][lane - 1] + sp[c][lane + 1]) - p[c];
                         else
                             common = (sp[c][lane - 2] + p[c]) + sp[c][lane + 2];
-#endif
                         g0[c] = left[c] + common;
                         g1[c] = common + right[c];
                     }
@@ -2347,15 +2375,107 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 }
                 lds_wave_sync();
             }
-#ifdef TF_PC_TIMING
-            tk_c += TF_TICK() - tk2;
-#endif
         }
-#ifdef TF_PC_TIMING
-        if (lane == 0 && bx == 10 && by == 0 && pair == 0 && Wk >= 3000)
-            printf("pc-timing consumer wave %d: %d steps; per step: copy sums %lld, barrier %lld, exchange+solve+store %lld\n", wave,
-                   nsteps, tk_a / nsteps, tk_b / nsteps, tk_c / nsteps);
-#endif
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The pre-pass of mode 0 for the one-kernel iteration (M is never in memory there): every lane marches ONE column of one
+// segment through the same rows of M the iteration will make, with the same ring, for the chain's increments alone --
+// no halo columns, no window sums across columns, no barrier: the waves run free.  Segment 0 delivers the chain's value
+// after its last row (primed as OpenCV primes it), the others the sum of their rows' increments from zero; k_carry_scan
+// turns that into each segment's carry.  S: [segment][pair][channel][Wk].
+// ---------------------------------------------------------------------------------
+template <int M, int FLOW>
+__global__ void __launch_bounds__(128)
+k_flow_carry_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, int Wk, int Hk, int seg, FlowInit fi,
+                const int *__restrict__ rows_ofs, const float *__restrict__ rows_frac, double *__restrict__ S)
+{
+    constexpr int WIN = 2 * M + 1;
+    __shared__ float ring[WIN][5][128];
+    const int col = threadIdx.x, xr = blockIdx.x * 128 + col, x = min(xr, Wk - 1);
+    const int by = blockIdx.y, pair = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const int r0 = by * seg, r1 = min(r0 + seg, Hk);
+    const int e0 = r0 - M - 1, n_rows = (r1 - r0) + WIN;
+    RowProducer<FLOW> P;
+    P.init(R, flow_in, fi, rows_ofs, rows_frac, pair, Nk, Wk, Hk, x);
+    P.start(e0);
+    double vs[5] = {0, 0, 0, 0, 0};
+    int slot = 0;
+    for (int s = 0; s < WIN; s++) {
+        float m[5];
+        P.template next<false>(e0 + s, m);
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            ring[slot][c][col] = m[c];
+        if (r0 == 0) {
+            if (s == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    vs[c] = (double)(m[c] * (float)(M + 2));
+            } else if (s >= M + 2 && s <= 2 * M) {
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    vs[c] += (double)m[c];
+            }
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
+    }
+    for (int s = WIN; s < n_rows; s++) {
+        float m[5];
+        P.template next<false>(e0 + s, m);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float old = ring[slot][c][col];
+            ring[slot][c][col] = m[c];
+            vs[c] += (double)(m[c] - old);
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
+    }
+    if (xr < Wk) {
+        double *o = S + (((size_t)by * gridDim.z + pair) * 5) * Wk + xr;
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            o[(size_t)c * Wk] = vs[c];
+    }
+}
+
+// The same from M in memory (the two-kernel iteration): one thread per column and channel of a segment.
+__global__ void __launch_bounds__(64)
+k_blur_carry(const float *__restrict__ Min, double *__restrict__ S, int Wk, int Hk, int m, int seg)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y % 5, by = blockIdx.y / 5, pair = blockIdx.z;
+    if (x >= Wk)
+        return;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *P = Min + ((size_t)pair * 5 + c) * Nk + x;
+    const int r0 = by * seg, r1 = min(r0 + seg, Hk);
+    double vs = 0.0;
+    if (r0 == 0) {
+        vs = (double)(P[0] * (float)(m + 2)); // vsum[x] = srow0[x] * (m + 2): a float product
+        for (int y = 1; y < m; y++)
+            vs += (double)P[(size_t)min(y, Hk - 1) * Wk];
+    }
+#pragma unroll 8
+    for (int y = r0; y < r1; y++) {
+        const float in = P[(size_t)min(y + m, Hk - 1) * Wk], out = P[(size_t)max(y - m - 1, 0) * Wk];
+        vs += (double)(in - out); // vsum[x] += srow1[x] - srow0[x]
+    }
+    S[(((size_t)by * gridDim.z + pair) * 5 + c) * Wk + x] = vs;
+}
+
+// S[s][i] (what segment s adds to the chain; S[0]: the chain after segment 0) -> the chain's value in front of segment s
+__global__ void k_carry_scan(double *__restrict__ S, size_t n, int segs)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double acc = S[i];
+    for (int s = 1; s < segs; s++) {
+        const double t = S[(size_t)s * n + i];
+        S[(size_t)s * n + i] = acc;
+        acc += t;
     }
 }
 
@@ -2821,8 +2941,12 @@ struct tf_fb {
     AreaTabs area{};
     DevBuf gauss_taps;           // winsize / 2 + 1 taps of the Gaussian window (flag 256)
     DevBuf bgr_stage;            // tf_fb_set_frame_bgr: the decoded frame on its way to a slot
-    DevBuf gring;                // experiment TF_PC_GRING: the iteration kernel's window rows, a region per workgroup
     DevBuf exact_vsum;           // option fb_exact_sums: OpenCV's column sums of the level being solved, [pair][5][x][y] doubles
+    // OpenCV's column sums across row segments (ColumnCarry)
+    DevBuf col_carry;            // the chain's value in front of every segment of the launch being issued
+    DevBuf chain_words;          // word 0: the ticket counter (never reset); from word 16 on: the hand-off flags
+    unsigned chain_epoch = 0, ticket_base = 0;
+    unsigned *chain_fault = nullptr; // pinned, device-visible: a wait for a carry gave up (k_flow_iter_pc)
     bool use_initial() const { return (prm.flags & 4) != 0; }
     bool gaussian() const { return (prm.flags & 256) != 0; }
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
@@ -2849,6 +2973,8 @@ struct tf_fb {
             (void)hipEventDestroy(pairs_copied);
         if (pairs_host)
             (void)hipHostFree(pairs_host);
+        if (chain_fault)
+            (void)hipHostFree(chain_fault);
         for (auto e : entry)
             if (e)
                 (void)hipEventDestroy(e);
@@ -3100,24 +3226,135 @@ static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowIn
                   fb->M.as<float>(), w, h, f);
 }
 
+// ---------------------------------------------------------------------------------
+// How a marching launch is cut into row segments, and where its segments get the column sums' carries from
+// (ColumnCarry).  `columns` = strips x pairs workgroups stand side by side; a launch of `segs` segments has segs x columns
+// workgroups of (h / segs + warm-up) steps each, `slots` of them resident at a time.
+//   hand-off inside the launch (mode 1): the segments of a column run one after the other.  With at least as many
+//     columns as slots that costs nothing -- by the time a segment is dispatched the one above it is done -- and the
+//     segment count is the one that minimises rounds x steps.  With fewer columns the segments would only queue up
+//     behind each other, so the column is marched whole (one segment, no hand-off) on a part-empty chip.
+//   pre-pass (mode 0): segments side by side as before, for a second launch that makes the rows of M for their carries
+//     (prepass_cost x the march's time; k_blur_carry, which reads M, is cheap).
+// Times are in units of one workgroup step at full residency; a step is faster on a part-empty chip (step_time).
+// ---------------------------------------------------------------------------------
+struct March {
+    int mode, segs, seg; // seg: rows per segment
+};
+static double step_time(double wgs_per_cu, int slots_per_cu)
+{
+    // measured on MI355X for k_flow_iter_pc (3 slots per CU): one workgroup alone on its CU steps in ~0.6 of the time
+    // it takes beside two others
+    const double full = slots_per_cu, o = std::min(std::max(wgs_per_cu, 1.0), full);
+    static const double alone = tune("TF_STEP_ALONE_PCT", 60) / 100.0;
+    return full <= 1 ? 1.0 : alone + (1.0 - alone) * (o - 1.0) / (full - 1.0);
+}
+static March choose_march(long columns, int h, int warm, long slots, int slots_per_cu, double prepass_cost, int min_rows)
+{
+    const long forced_segs = option(OPT_FB_SEGS), forced_mode = option(OPT_FB_CHAIN);
+    const long cus = std::max(1l, slots / slots_per_cu);
+    auto rounds_cost = [&](long sg, double *cost) {
+        const long rows = (h + sg - 1) / sg;
+        const long wgs = columns * sg, rounds = (wgs + slots - 1) / slots;
+        *cost = (double)rounds * (double)(rows + warm + 1) * step_time((double)std::min(wgs, slots) / cus, slots_per_cu);
+        return rows;
+    };
+    // the best segment count for segments that run side by side
+    long best_segs = 1;
+    double best_cost = 1e300;
+    for (long sg = 1; sg <= 64 && sg <= h; sg++) {
+        double cost;
+        const long rows = rounds_cost(sg, &cost);
+        if (rows < min_rows && sg > 1)
+            break;
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best_segs = sg;
+        }
+    }
+    if (forced_segs > 0) {
+        best_segs = std::min<long>(forced_segs, h);
+        rounds_cost(best_segs, &best_cost);
+    }
+    March m;
+    double whole;
+    rounds_cost(1, &whole);
+    if (best_segs == 1) {
+        m.mode = 0;
+        m.segs = 1;
+    } else if (forced_mode == 1 || (forced_mode < 0 && columns >= slots)) {
+        m.mode = 1;
+        m.segs = (int)best_segs;
+    } else if (forced_mode == 0 || forced_segs > 0 || best_cost * (1.0 + prepass_cost) < whole) {
+        m.mode = 0;
+        m.segs = (int)best_segs;
+    } else {
+        m.mode = 0;
+        m.segs = 1;
+    }
+    m.seg = (h + m.segs - 1) / m.segs;
+    m.segs = (h + m.seg - 1) / m.seg;
+    return m;
+}
+
+// room for the carries of a launch (and, for hand-offs inside it, its flags); the fault word
+static int fb_carry_room(tf_fb *fb, size_t carry_doubles, size_t flags)
+{
+    if (fb->col_carry.bytes < carry_doubles * sizeof(double))
+        TF_TRY(fb->col_carry.alloc(carry_doubles * sizeof(double)));
+    const size_t words = ((16 + flags + 3) & ~(size_t)3);
+    if (flags && fb->chain_words.bytes < words * 4) {
+        TF_TRY(fb->chain_words.alloc(words * 4)); // (hipFree waits for whatever still uses the old one)
+        TF_HIP(hipMemsetAsync(fb->chain_words.p, 0, words * 4, stream()));
+        fb->ticket_base = 0;
+        fb->chain_epoch = 0;
+    }
+    if (!fb->chain_fault) {
+        TF_HIP(hipHostMalloc((void **)&fb->chain_fault, 64, hipHostMallocDefault));
+        *fb->chain_fault = 0;
+    }
+    return TF_OK;
+}
+
+// a wait inside an earlier launch gave up: its flow is wrong
+static int fb_check_fault(tf_fb *fb, const char *where)
+{
+    if (fb->chain_fault && *(volatile unsigned *)fb->chain_fault) {
+        *fb->chain_fault = 0;
+        return set_error(TF_ERR_HIP, "%s: a segment of k_flow_iter_pc waited more than 5 s for the column sums of the segment "
+                                     "above it; the flow of that call is invalid", where);
+    }
+    return TF_OK;
+}
+
+static int fb_carry_scan(tf_fb *fb, int w, int n_pairs, int segs, int k)
+{
+    const size_t n = (size_t)n_pairs * 5 * w;
+    return launch(lvl_name("fb_carry_scan", k), k_carry_scan, dim3(cdiv(n, 256)), dim3(256), 0, fb->col_carry.as<double>(), n, segs);
+}
+
 template <int M>
 static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, double scale, int k)
 {
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
     const unsigned strips = cdiv(w, OUTC);
-    // each segment re-sums its first window (2M+1 rows), so segments should be tall; but the launch
-    // should hold a few waves per resident slot (12 per CU) or its tail runs on a half-empty chip
-    // (measured at 4K x 16: 4096 / 8192 / 12288 / 16384 waves -> 5.03 / 4.92 / 4.88 / 4.86 ms for all levels)
-    static const long waves_wanted = tune("TF_BLUR_WAVES", 12288);
-    const long seg_min = 8;
-    long segs_wanted = std::max(1l, waves_wanted / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(256, std::max<long>(seg_min, (h + segs_wanted - 1) / segs_wanted));
-    if (tune("TF_BLUR_SEG", 0))
-        seg = std::max(8, (int)tune("TF_BLUR_SEG", 0));
-    dim3 grid(strips, cdiv(h, seg), n_pairs);
+    // one-wave workgroups, 12 resident per CU; a segment's carry comes from k_blur_carry (M is in memory: the pre-pass
+    // reads the entering and the leaving row of every step, a fraction of the march's own time), never from inside the launch
+    static const long slots = tune("TF_BLUR_SLOTS", 3072);
+    March mc = choose_march((long)strips * n_pairs, h, 0, slots, 12, 0.35, 8);
+    mc.mode = 0;
+    const double *carry = nullptr;
+    if (mc.segs > 1) {
+        TF_TRY(fb_carry_room(fb, (size_t)mc.segs * n_pairs * 5 * w, 0));
+        TF_TRY(launch(lvl_name("fb_blur_carry", k), k_blur_carry, dim3(cdiv(w, 64), 5 * mc.segs, n_pairs), dim3(64), 0,
+                      (const float *)fb->M.as<float>(), fb->col_carry.as<double>(), w, h, M, mc.seg));
+        TF_TRY(fb_carry_scan(fb, w, n_pairs, mc.segs, k));
+        carry = fb->col_carry.as<double>();
+    }
+    dim3 grid(strips, mc.segs, n_pairs);
     return launch(lvl_name("fb_blur_solve", k), k_blur_solve_wave<M>, grid, dim3(64), 0, (const float *)fb->M.as<float>(),
-                  flow_out, w, h, scale, seg);
+                  flow_out, w, h, scale, mc.seg, carry);
 }
 
 static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, int k = -1)
@@ -3152,10 +3389,21 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
     const int out_cols = BS_THREADS - 2 * m;
     const unsigned strips = cdiv(w, out_cols);
     long segs_wanted = std::max(1l, 1024 / std::max(1l, (long)strips * n_pairs));
-    int seg = (int)std::min<long>(128, std::max<long>(16, (h + segs_wanted - 1) / segs_wanted));
-    dim3 grid(strips, cdiv(h, seg), n_pairs);
+    if (option(OPT_FB_SEGS) > 0)
+        segs_wanted = option(OPT_FB_SEGS);
+    const int seg = (int)std::min<long>(h, std::max<long>(16, (h + segs_wanted - 1) / segs_wanted));
+    const int segs = (int)cdiv(h, seg);
+    const double *carry = nullptr;
+    if (segs > 1) {
+        TF_TRY(fb_carry_room(fb, (size_t)segs * n_pairs * 5 * w, 0));
+        TF_TRY(launch(lvl_name("fb_blur_carry", k), k_blur_carry, dim3(cdiv(w, 64), 5 * segs, n_pairs), dim3(64), 0,
+                      (const float *)fb->M.as<float>(), fb->col_carry.as<double>(), w, h, m, seg));
+        TF_TRY(fb_carry_scan(fb, w, n_pairs, segs, k));
+        carry = fb->col_carry.as<double>();
+    }
+    dim3 grid(strips, segs, n_pairs);
     return launch("fb_blur_solve_generic", k_blur_solve, grid, dim3(BS_THREADS), 0, (const float *)fb->M.as<float>(),
-                  flow_out, w, h, m, scale, seg);
+                  flow_out, w, h, m, scale, seg, carry);
 }
 
 // `up`: the first iteration of a level below the coarsest takes its flow from the coarser level (A5 fused)
@@ -3165,69 +3413,60 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
 {
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     const float *R = fb->Rk(k);
-#ifdef TF_PC_HALO_ODD
-    constexpr int OUTC = 128 - 2 * M;
-#else
-    constexpr int OUTC = 128 - 2 * ((M + 1) & ~1);
-#endif
+    constexpr int OUTC = 128 - 2 * ((M + 1) & ~1), WIN = 2 * M + 1;
     const unsigned strips = cdiv(w, OUTC);
     // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
-    // rounds of 768, each as long as a segment plus its 2M+1 warm-up / drain steps.  Pick the segment
-    // count that minimises rounds x steps (4K x 16: 4 segments = 2240 workgroups, 2.9 -> 3 rounds).
-    static const long forced = tune("TF_PC_BLOCKS", 0);
-    const long per_seg = (long)strips * n_pairs, slots = tune("TF_PC_SLOTS", 768);
-    long best_segs = 1;
-    double best_cost = 1e300;
-    for (long sg = 1; sg <= 64 && sg <= h; sg++) {
-        const long rows = (h + sg - 1) / sg;
-        if (rows < 2 * (2 * M + 1) && sg > 1)
-            break;
-        const long rounds = (per_seg * sg + slots - 1) / slots;
-        const double cost = (double)rounds * (double)(rows + 2 * M + 1);
-        if (cost < best_cost * 0.999) {
-            best_cost = cost;
-            best_segs = sg;
+    // rounds of 768, each as long as a segment plus its 2M+1 warm-up steps and the drain step (choose_march)
+    static const long slots = tune("TF_PC_SLOTS", 768);
+    static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 60) / 100.0;
+    const March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 2 * WIN);
+    FlowInit f;
+    memset(&f, 0, sizeof(f));
+    if (up)
+        f = *up;
+    f.rmap = fb->rmap_dev;
+    ColumnCarry cc;
+    memset(&cc, 0, sizeof(cc));
+    cc.mode = mc.mode;
+    cc.segs = mc.segs;
+    cc.pairs = n_pairs;
+    cc.strips = (int)strips;
+    dim3 grid(strips, mc.segs, n_pairs);
+    if (mc.segs > 1 && mc.mode == 1) {
+        const size_t items = (size_t)mc.segs * n_pairs * strips;
+        TF_TRY(fb_carry_room(fb, items * 5 * 128, items * 2));
+        if (++fb->chain_epoch == 0) { // 2^32 chained launches later: the flags start over
+            TF_HIP(hipMemsetAsync(fb->chain_words.as<unsigned>() + 16, 0, fb->chain_words.bytes - 64, stream()));
+            fb->chain_epoch = 1;
         }
+        cc.carry = fb->col_carry.as<double>();
+        cc.flags = fb->chain_words.as<unsigned>() + 16;
+        cc.epoch = fb->chain_epoch;
+        cc.ticket = fb->chain_words.as<unsigned>();
+        cc.ticket_base = fb->ticket_base;
+        cc.fault = fb->chain_fault;
+        fb->ticket_base += (unsigned)items;
+        grid = dim3((unsigned)items);
+    } else if (mc.segs > 1) {
+        TF_TRY(fb_carry_room(fb, (size_t)mc.segs * n_pairs * 5 * w, 0));
+        cc.carry = fb->col_carry.as<double>();
+        cc.fault = fb->chain_fault;
+        const dim3 pgrid(cdiv(w, 128), mc.segs, n_pairs);
+        if (up)
+            TF_TRY(launch(lvl_name("fb_flow_carry", k), k_flow_carry_pc<M, 2>, pgrid, dim3(128), 0, R, flow_in, w, h, mc.seg, f, f.yofs, f.yfrac, cc.carry));
+        else if (flow_in)
+            TF_TRY(launch(lvl_name("fb_flow_carry", k), k_flow_carry_pc<M, 1>, pgrid, dim3(128), 0, R, flow_in, w, h, mc.seg, f, f.yofs, f.yfrac, cc.carry));
+        else
+            TF_TRY(launch(lvl_name("fb_flow_carry", k), k_flow_carry_pc<M, 0>, pgrid, dim3(128), 0, R, flow_in, w, h, mc.seg, f, f.yofs, f.yfrac, cc.carry));
+        TF_TRY(fb_carry_scan(fb, w, n_pairs, mc.segs, k));
+    } else {
+        cc.mode = 0;
     }
-    if (forced)
-        best_segs = std::max(1l, forced / std::max(1l, per_seg));
-    const int seg = (int)((h + best_segs - 1) / best_segs);
-    dim3 grid(strips, cdiv(h, seg), n_pairs);
-    FlowInit none;
-    memset(&none, 0, sizeof(none));
-    none.rmap = fb->rmap_dev;
-#ifdef TF_PC_GRING
-    {
-        const size_t wgs = (size_t)grid.x * grid.y * grid.z + 8 * (size_t)n_pairs; // (+ the 1-D grid's padding)
-        const size_t need = wgs * (size_t)(2 * M + 1) * 5 * 128 * sizeof(float);
-        if (fb->gring.bytes < need)
-            TF_TRY(fb->gring.alloc(need));
-        none.gring = fb->gring.as<float>();
-    }
-#endif
-    static const long pairmap = tune("TF_PC_PAIRMAP", 0);
-    if (pairmap && n_pairs > 1) {
-        none.grid_strips = (int)grid.x;
-        none.grid_segs = (int)grid.y;
-        none.grid_pairs = n_pairs;
-        const unsigned groups = grid.x * grid.y, per_xcd = (groups + 7) / 8;
-        grid = dim3(per_xcd * 8 * n_pairs);
-    }
-    if (up) {
-        FlowInit f = *up;
-        f.rmap = fb->rmap_dev;
-        f.grid_strips = none.grid_strips;
-        f.grid_segs = none.grid_segs;
-        f.grid_pairs = none.grid_pairs;
-        f.gring = none.gring;
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), (size_t)tune("TF_PC_DYNLDS", 0), R, flow_in, flow_out, w, h, scale,
-                      seg, f);
-    }
+    if (up)
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
     if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), (size_t)tune("TF_PC_DYNLDS", 0), R, flow_in, flow_out, w, h, scale,
-                      seg, none);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale,
-                  seg, none);
+        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
 }
 
 // true if the fused iteration kernel exists for this window; launches it
@@ -3599,6 +3838,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     for (int i = 0; i < n_pairs; i++)
         TF_REQUIRE(prev_slots[i] >= 0 && prev_slots[i] < fb->slots && next_slots[i] >= 0 && next_slots[i] < fb->slots,
                    "tf_fb_calc_slots: pair %d uses a slot outside [0,%d)", i, fb->slots);
+    TF_TRY(fb_check_fault(fb, "tf_fb_calc_slots (an earlier call)"));
     if (fb->pairs_pending) { // the previous call's copy out of the staging buffer (long done in practice)
         TF_HIP(hipEventSynchronize(fb->pairs_copied));
         fb->pairs_pending = false;
@@ -3820,7 +4060,7 @@ TF_API int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out)
     TF_TRY(tf_fb_flow_ptr(fb, pair, &src));
     TF_HIP(hipMemcpyAsync(flow_out, src, (size_t)fb->W * fb->H * 8, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
-    return TF_OK;
+    return fb_check_fault(fb, "tf_fb_get_flow");
 }
 
 TF_API int tf_fb_set_initial_flow(tf_fb *fb, int pair, const float *flow)

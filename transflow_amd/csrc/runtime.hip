@@ -41,6 +41,8 @@ static OptDef g_opts[OPT_COUNT] = {
     {"remap_no_pack", 0, 0, 1},                // 1: the one-kernel remap step keeps its state as int32 x 4
     {"prof_levels", 0, 0, 1},                  // 1: profiler labels carry the pyramid level ("fb_polyexp.k2")
     {"fb_exact_sums", 0, 0, 1},                // 1: the box window's sums in OpenCV's own order (bit-identical flow, ~5x slower; read per call)
+    {"fb_chain", -1, -1, 1},                   // how a segmented march gets OpenCV's column sums: -1 the cheaper way per launch; 0 a pre-pass; 1 handed down inside the launch
+    {"fb_segs", 0, 0, 64},                     // > 0: row segments per column of the marching kernels (0: chosen per launch)
 };
 long option(Opt which) { return g_opts[which].value; }
 
