@@ -122,6 +122,13 @@ typedef struct tf_fb tf_fb;
 /* frame_slots: how many uint8 grey frames the handle keeps resident in HBM;
    max_pairs: how many frame pairs one tf_fb_calc_slots call may process. */
 int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params, int frame_slots, int max_pairs);
+/* A second lane for first's calls (no counterpart in the reference, whose one call per frame is synchronous,
+   cv.py:479-490): a handle of the same size and parameters that READS FIRST'S FRAME SLOTS and queues its calls on the
+   library's other call stream.  Batches sent alternately to the two handles are in flight together, so the launches of
+   one that leave the chip part-empty (coarse pyramid levels, the tail of every launch) run beside those of the other.
+   Everything else is per handle: results are read from the handle that ran the call.  Destroy the lane before `first`.
+   Not with tf_fb_keep_expansions. */
+int tf_fb_create_lane(tf_fb **out, tf_fb *first);
 void tf_fb_destroy(tf_fb *fb);
 
 /* One pair, host in / host out: flow_out is float32 [height][width][2] (x=dx, y=dy),

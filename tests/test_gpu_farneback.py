@@ -460,27 +460,18 @@ def test_unusual_parameter_values_close(FB):
         fb.close()
         d = np.abs(got - ref)
         assert np.isfinite(got).all(), kw
-        if kw.get("winsize", 15) >= 4:
-            assert d.max() <= flow_tol(ref), f"{kw}: max|d|={d.max()} tol={flow_tol(ref)}"
-            continue
-        # Windows of 1-3 pixels: 1-9 samples per 2x2 system, so G is close to singular wherever the
-        # image is locally one-dimensional, and a last-bit difference in the window sums (OpenCV slides
-        # them with float differences, the kernels add the samples) is amplified through the iterations
-        # and scales.  One iteration at one scale must agree; the full run in all but a few pixels.
-        assert (d > flow_tol(ref)).mean() < 0.01, f"{kw}: {(d > flow_tol(ref)).mean():.4f} of the pixels beyond tolerance"
-        one = dict(kw, levels=0, iterations=1)
-        ref1 = O.calc(a, b, **one)
-        fb = FB(w, h, **one)
-        err1 = np.abs(fb.calc(a, b) - ref1).max()
-        fb.close()
-        assert err1 <= flow_tol(ref1), f"{one}: max|d|={err1} tol={flow_tol(ref1)}"
+        # (Windows of 1-3 pixels -- 1-9 samples per 2x2 system, G close to singular wherever the image is locally
+        # one-dimensional -- amplified the last-bit difference between OpenCV's running sums and the kernels' direct sums
+        # through iterations and scales; rounds 1-3 allowed 1 % of their pixels beyond tolerance.  With OpenCV's column
+        # sums in the kernels they meet the bar like every other window.)
+        assert d.max() <= flow_tol(ref), f"{kw}: max|d|={d.max()} tol={flow_tol(ref)}"
 
 
 def test_frame_content_extremes_close(FB):
     """Flat frames, saturated frames, white noise, a one-pixel checkerboard, a displacement larger than
     the window (most gathers leave the frame at the fine scales), a pure ramp: one iteration at one scale
-    within tolerance everywhere; the default pyramid within tolerance on the smooth ones and in all but
-    a sliver of the pixels on the noise ones (no structure: nothing damps a last-bit difference)."""
+    and the default pyramid within tolerance everywhere (rounds 1-3 allowed the structureless ones -- noise, the
+    checkerboard -- 1 % of their pixels beyond it)."""
     h, w = 150, 200
     rng = np.random.default_rng(8)
     yy, xx = np.mgrid[0:h, 0:w]
@@ -505,10 +496,7 @@ def test_frame_content_extremes_close(FB):
             fb.close()
             d = np.abs(got - ref)
             assert np.isfinite(got).all(), name
-            if smooth or kw:
-                assert d.max() <= flow_tol(ref), f"{name} {kw}: max|d|={d.max()} tol={flow_tol(ref)}"
-            else:
-                assert (d > flow_tol(ref)).mean() < 0.01, f"{name}: {(d > flow_tol(ref)).mean():.4f} beyond tolerance"
+            assert d.max() <= flow_tol(ref), f"{name} {kw}: max|d|={d.max()} tol={flow_tol(ref)}"
 
 
 def test_strided_input_and_errors(FB):
@@ -718,31 +706,27 @@ def outliers(got, ref):
     return int((d > flow_tol(ref)).sum()), float(d.max())
 
 
-def assert_within_tolerance_up_to_border_flips(got, ref, what, winsize=15):
-    """The default mode's bar (bench.py's parity gate applies the same): every pixel within flow_tol(ref) of the oracle,
-    except that within 2 * (winsize + 8) pixels of a frame edge a few may miss it -- at most 1e-4 of the pixels, none
-    by more than 100 tolerances.  FarnebackUpdateMatrices' in-frame test is discontinuous in the flow; where a border
-    pixel's sample point sits within float resolution of the frame's last row / column, the ~1e-7 by which OpenCV's
-    image-long running sums and per-segment sums differ decides the branch (fb_exact_sums removes the difference and
-    is checked bit for bit next to every use of this)."""
-    h, w = ref.shape[:2]
+def assert_within_tolerance(got, ref, what):
+    """The default mode's bar since round 4 (bench.py's parity gate applies the same): EVERY pixel within flow_tol(ref) of
+    the oracle.  Rounds 2 and 3 excused a few pixels near the frame edges: FarnebackUpdateMatrices' in-frame test is
+    discontinuous in the flow, and the ~1e-7 by which per-segment window sums differed from OpenCV's image-long running
+    sums decided it where a sample point sat within float resolution of the frame's last row / column.  The marching
+    kernels now keep OpenCV's column sums (ColumnCarry in farneback.hip) and compute M without FMA contraction; what is
+    left between them and the oracle is the association of double additions.  Returns the number of pixels that differ
+    from the oracle at all."""
     d = np.abs(got - ref).max(axis=2)
     bad = d > flow_tol(ref)
-    band = 2 * (winsize + 8)
-    inner = bad[band:h - band, band:w - band]
     ys, xs = np.nonzero(bad)
     where = f"rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}" if bad.any() else "none"
-    assert not inner.any(), f"{what}: {int(inner.sum())} pixels beyond tolerance away from the frame edges ({where}), max|d|={d.max()}"
-    assert bad.sum() <= 1e-4 * h * w and d.max() <= 100 * flow_tol(ref), f"{what}: {int(bad.sum())} border pixels beyond tolerance ({where}), max|d|={d.max()}"
-    return int(bad.sum())
+    assert not bad.any(), f"{what}: {int(bad.sum())} pixels beyond tolerance ({where}), max|d|={d.max()}, tol={flow_tol(ref)}"
+    return int((d > 0).sum())
 
 
 def test_bench_shape_1080p_levels5_four_consecutive_pairs_forward_remap(FB, lib_option):
     """BASELINE configs[2] as benched: 1080p, levels=5, consecutive pairs of one call sharing their frames'
     expansions, levels 0-1 on the one-kernel iteration (the default above 4 M pixels per level over the batch), then per
     pair the FORWARD scatter and the remap step that finishes post_process in registers (clip_flow=2).  Flow within
-    tolerance everywhere but for the in-frame test's flips at the frame edges, and bit-identical with fb_exact_sums;
-    layer state, rgba and frame bit-exact."""
+    tolerance at every pixel, and bit-identical with fb_exact_sums; layer state, rgba and frame bit-exact."""
     from oracle import remap_ref as OR
     from transflow_amd.remap import CompImage, RemapLayer
     h, w, P = 1080, 1920, 4
@@ -754,7 +738,7 @@ def test_bench_shape_1080p_levels5_four_consecutive_pairs_forward_remap(FB, lib_
     fb.calc_slots(list(range(P)), list(range(1, P + 1)))
     flows = [fb.get_flow(i) for i in range(P)]
     for i in range(P):
-        assert_within_tolerance_up_to_border_flips(flows[i], refs[i], f"pair {i}")
+        assert_within_tolerance(flows[i], refs[i], f"pair {i}")
     pixmap = np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8)
     layer = RemapLayer(h, w)
     layer.set_sources([np.ones((h, w), np.uint8)])
@@ -790,7 +774,7 @@ def test_bench_shape_1080p_one_scale(FB, lib_option):
             fb.set_frame(i, f)
         fb.calc_slots(list(range(P)), list(range(1, P + 1)))
         for i in range(P):
-            assert_within_tolerance_up_to_border_flips(fb.get_flow(i), refs[i], f"fb_fused={fused} pair {i}")
+            assert_within_tolerance(fb.get_flow(i), refs[i], f"fb_fused={fused} pair {i}")
         fb.close()
     lib_option("fb_exact_sums", 1)
     fb = FB(w, h, levels=0, frame_slots=P + 1, max_pairs=P)
@@ -804,8 +788,8 @@ def test_bench_shape_1080p_one_scale(FB, lib_option):
 
 def test_bench_shape_4k_two_pairs_sharing_a_frame_fused_on_every_level(FB, lib_option):
     """BASELINE configs[3]/[4] as benched: 4K, levels=5, two pairs that share a frame (its expansion computed once),
-    the one-kernel iteration on every level.  Strict tolerance; where a pair shows outliers (the in-frame test's
-    branch flip) they must be few, and the exact mode must reproduce the oracle bit for bit."""
+    the one-kernel iteration on every level.  Every pixel within tolerance (round 3 saw 207 border pixels of such a pair
+    beyond it); the exact mode reproduces the oracle bit for bit."""
     h, w = 2160, 3840
     frames = clip_frames(h, w, 3, seed=900)
     refs = [O.calc(frames[i], frames[i + 1], levels=5) for i in range(2)]
@@ -821,7 +805,103 @@ def test_bench_shape_4k_two_pairs_sharing_a_frame_fused_on_every_level(FB, lib_o
         np.testing.assert_array_equal(fb.get_flow(i), refs[i])
     fb.close()
     for i in range(2):
-        assert_within_tolerance_up_to_border_flips(got[i], refs[i], f"pair {i}")
+        assert_within_tolerance(got[i], refs[i], f"pair {i}")
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_row_segments_keep_the_column_sums_of_the_whole_march(FB, lib_option, fused):
+    """A column of the marching kernels cut into row segments (option fb_segs) must give the flow of the column marched
+    whole: with the carries handed down inside the launch (fb_chain = 1; one-kernel iteration only) the column sums are the
+    same additions in the same order, so the flow is BIT-IDENTICAL; with the carries from a pre-pass (fb_chain = 0) the
+    sums differ by the association of double additions (~1e-16) and the flow may differ in a last bit here and there.
+    All of them: every pixel within tolerance of the oracle.  Heights that do not divide, segments shorter than the window."""
+    lib_option("fb_fused", fused)
+    for (h, w, kw, P) in [(270, 480, dict(levels=2), 3), (97, 211, dict(levels=1, winsize=11), 2), (61, 40, dict(levels=0, winsize=7, iterations=2), 1)]:
+        frames = clip_frames(h, w, P + 1, seed=1000 + h)
+        refs = [O.calc(frames[i], frames[i + 1], **kw) for i in range(P)]
+
+        def run(segs, chain):
+            lib_option("fb_segs", segs)
+            lib_option("fb_chain", chain)
+            fb = FB(w, h, frame_slots=P + 1, max_pairs=P, **kw)
+            for i, f in enumerate(frames):
+                fb.set_frame(i, f)
+            fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+            out = [fb.get_flow(i) for i in range(P)]
+            fb.close()
+            return out
+        whole = run(1, -1)
+        for i in range(P):
+            assert_within_tolerance(whole[i], refs[i], f"{h}x{w} whole pair {i}")
+        for segs in (2, 3, 7, 64):
+            for chain in ((1, 0) if fused else (0,)):
+                got = run(segs, chain)
+                for i in range(P):
+                    what = f"{h}x{w} fb_fused={fused} fb_segs={segs} fb_chain={chain} pair {i}"
+                    assert_within_tolerance(got[i], refs[i], what)
+                    if chain == 1:
+                        np.testing.assert_array_equal(got[i], whole[i], err_msg=what)
+                    else:
+                        assert (got[i] != whole[i]).any(axis=2).mean() < 1e-4, what
+
+
+def test_segment_handoff_at_a_size_that_fills_the_chip(FB, lib_option):
+    """The hand-off inside the launch where it is the default: 1080p x 12 pairs has 216 columns of workgroups, forced to 8
+    segments = 1728 workgroups for 768 slots, so later segments are dispatched while earlier ones run, wait for them and
+    take their sums.  Bit-identical to the whole march, twice (replay), and within tolerance of the oracle on a sample."""
+    h, w, P = 1080, 1920, 12
+    frames = clip_frames(h, w, P + 1, seed=1100)
+    lib_option("fb_fused", 1)
+
+    def run(segs, chain):
+        lib_option("fb_segs", segs)
+        lib_option("fb_chain", chain)
+        fb = FB(w, h, levels=1, frame_slots=P + 1, max_pairs=P)
+        for i, f in enumerate(frames):
+            fb.set_frame(i, f)
+        out = []
+        for _ in range(2):
+            fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+            out.append([fb.get_flow(i) for i in range(P)])
+        fb.close()
+        return out
+    whole = run(1, -1)[0]
+    for rep in run(8, 1):
+        for i in range(P):
+            np.testing.assert_array_equal(rep[i], whole[i], err_msg=f"pair {i}")
+    ref = O.calc(frames[5], frames[6], levels=1)
+    assert_within_tolerance(whole[5], ref, "pair 5")
+
+
+def test_two_lanes_give_the_results_of_one(FB):
+    """Farneback(lanes=2): calls alternate between a handle and its lane (tf_fb_create_lane: the same frame slots, the
+    library's other call stream), consecutive calls are in flight together, and every call's flow is what one handle
+    computes for it -- bit for bit, whichever lane ran it."""
+    h, w, P = 270, 480, 3
+    frames = clip_frames(h, w, 3 * P + 1, seed=1200)
+    calls = [(list(range(c * P, c * P + P)), list(range(c * P + 1, c * P + P + 1))) for c in range(3)] * 2
+    one = FB(w, h, frame_slots=len(frames), max_pairs=P)
+    two = FB(w, h, frame_slots=len(frames), max_pairs=P, lanes=2)
+    for i, f in enumerate(frames):
+        one.set_frame(i, f)
+        two.set_frame(i, f)
+    want = []
+    for prev, nxt in calls:
+        one.calc_slots(prev, nxt)
+        want.append([one.get_flow(i) for i in range(P)])
+    # issue two calls back to back (both lanes busy), then read the second; then interleave reading and issuing
+    two.calc_slots(*calls[0])
+    two.calc_slots(*calls[1])
+    for i in range(P):
+        np.testing.assert_array_equal(two.get_flow(i), want[1][i])
+    for c in range(2, len(calls)):
+        two.calc_slots(*calls[c])
+        for i in range(P):
+            np.testing.assert_array_equal(two.get_flow(i), want[c][i], err_msg=f"call {c} pair {i}")
+    with pytest.raises(ValueError):
+        two.keep_expansions(True)
+    one.close()
+    two.close()
 
 
 def test_bgr_frame_into_a_slot_matches_the_host_conversion_and_validates(FB):

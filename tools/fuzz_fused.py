@@ -101,7 +101,7 @@ for k, v in DEFAULTS.items():
 print(f"{n_cases} cases, {pairs} pairs: exact mode bit-identical to the oracle in {exact_identical}")
 for name, _ in FORMS:
     t = st[name]
-    print(f"  {name:36s}: bit-identical to the oracle in {t['identical']} pairs ({t['px_differ']} pixels differ in all), "
+    print(f"  {name:52s}: bit-identical to the oracle in {t['identical']} pairs ({t['px_differ']} pixels differ in all), "
           f"largest deviation {t['worst']:.2e} of the tolerance, {t['outlier_pairs']} pairs with a pixel beyond it")
 print(f"  the forms among themselves: at most {worst_between:.2e} of the tolerance apart; {bad} failures")
 sys.exit(1 if bad else 0)

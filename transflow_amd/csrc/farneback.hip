@@ -1559,20 +1559,40 @@ k_blur_solve(const float *__restrict__ Min, float2 *__restrict__ flow_out, int W
 // winsize 1 (m = 0).  FarnebackUpdateFlow_Blur primes its running sums with (m + 2) copies of the first
 // row / column and takes one back when row m enters; with m = 0 the row that "enters" at y = 0 is row 0
 // itself, the extra copy is never taken back, and every sum is first + current instead of current:
-// G(y, x) = M(0,0) + M(y,0) + M(0,x) + M(y,x) (scale 1).  A setting nobody uses; kept as OpenCV computes it.
-__global__ void k_blur_solve_w1(const float *__restrict__ Min, float2 *__restrict__ flow_out, int Wk, int Hk)
+// G(y, x) = M(0,0) + M(y,0) + M(0,x) + M(y,x) (scale 1).  A setting nobody uses; kept as OpenCV computes it --
+// including how: the column sums are OpenCV's chain (row 0 * 2 as a float product, then the float differences of
+// consecutive rows accumulated in double), whose roundings a 1 x 1 "window" does nothing to average out.
+// k_w1_vsum: one thread per column and channel walks the rows, V[pair][c][y][x]; k_w1_solve: per pixel.
+__global__ void __launch_bounds__(64)
+k_w1_vsum(const float *__restrict__ Min, double *__restrict__ V, int Wk, int Hk)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, pair = blockIdx.z;
+    if (x >= Wk)
+        return;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *P = Min + ((size_t)pair * 5 + c) * Nk + x;
+    double *o = V + ((size_t)pair * 5 + c) * Nk + x;
+    double vs = (double)(P[0] * 2.f); // vsum[x] = srow0[x] * (m + 2)
+    float prev = P[0];
+#pragma unroll 8
+    for (int y = 0; y < Hk; y++) {
+        const float cur = P[(size_t)y * Wk];
+        vs += (double)(cur - prev); // vsum[x] += srow1[x] - srow0[x]: rows y and max(y - 1, 0)
+        prev = cur;
+        o[(size_t)y * Wk] = vs;
+    }
+}
+__global__ void k_w1_solve(const double *__restrict__ V, float2 *__restrict__ flow_out, int Wk, int Hk)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= Wk)
         return;
     const size_t Nk = (size_t)Wk * Hk;
-    const float *Mi = Min + (size_t)blockIdx.z * 5 * Nk;
+    const double *Vp = V + (size_t)blockIdx.z * 5 * Nk + (size_t)y * Wk;
     double g[5];
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float *P = Mi + c * Nk;
-        g[c] = ((double)P[0] + (double)P[(size_t)y * Wk]) + ((double)P[x] + (double)P[(size_t)y * Wk + x]);
-    }
+    for (int c = 0; c < 5; c++)
+        g[c] = Vp[c * Nk] + Vp[c * Nk + x]; // the row's running sum: column 0 twice, then the differences of neighbours
     const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
     flow_out[(size_t)blockIdx.z * Nk + (size_t)y * Wk + x] =
         make_float2((float)((g[0] * g[4] - g[1] * g[3]) * idet), (float)((g[2] * g[3] - g[1] * g[4]) * idet));
@@ -2002,7 +2022,9 @@ __device__ __forceinline__ void wait_for_epoch(unsigned *flag, unsigned epoch, u
 // ---------------------------------------------------------------------------------
 // One column per lane, row after row of the 2x2 systems M (A3, with A5 on the fly): what the producer waves of
 // k_flow_iter_pc and the lanes of k_flow_carry_pc do.  The gathers of row e + 1 are in flight while row e is finished
-// (two or more rows ahead were measured slower), the flow of row e + 2 is the first load of a step, and for A5 the two
+// (two or three rows ahead were measured slower, on a full chip -- 2.94 -> 3.37 ms per level-0 launch at 4K x 32 -- and on a
+// part-empty one alike -- 0.92 -> 1.08 -> 2.5 ms at level 1: a lone wave issues an instruction every ~8 cycles, and that, not
+// memory latency, is what a step of ~130 instructions waits for), the flow of row e + 2 is the first load of a step, and for A5 the two
 // lerps of a row's flow run one step after its four coarse loads.
 // FLOW: where the iteration's input flow comes from -- 0: zero (coarsest scale), 1: flow_in, 2: A5 on the fly,
 // resize(coarser flow, INTER_LINEAR) * 1/pyr_scale through `fi` (the statements of k_flow_upsample; the column's
@@ -2947,6 +2969,8 @@ struct tf_fb {
     DevBuf chain_words;          // word 0: the ticket counter (never reset); from word 16 on: the hand-off flags
     unsigned chain_epoch = 0, ticket_base = 0;
     unsigned *chain_fault = nullptr; // pinned, device-visible: a wait for a carry gave up (k_flow_iter_pc)
+    tf_fb *lane_of = nullptr;    // tf_fb_create_lane: the handle whose frame slots these are
+    int lanes = 0;               // ... and how many lanes read this handle's
     bool use_initial() const { return (prm.flags & 4) != 0; }
     bool gaussian() const { return (prm.flags & 256) != 0; }
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
@@ -3382,9 +3406,15 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
     case 12: return launch_blur_solve_wave<12>(fb, w, h, n_pairs, flow_out, scale, k);
     default: break;
     }
-    if (m == 0)
-        return launch("fb_blur_solve_w1", k_blur_solve_w1, dim3(cdiv(w, 256), h, n_pairs), dim3(256), 0,
-                      (const float *)fb->M.as<float>(), flow_out, w, h);
+    if (m == 0) {
+        const size_t need = (size_t)n_pairs * 5 * w * h * sizeof(double);
+        if (fb->exact_vsum.bytes < need)
+            TF_TRY(fb->exact_vsum.alloc(need));
+        TF_TRY(launch("fb_w1_vsum", k_w1_vsum, dim3(cdiv(w, 64), 5, n_pairs), dim3(64), 0, (const float *)fb->M.as<float>(),
+                      fb->exact_vsum.as<double>(), w, h));
+        return launch("fb_w1_solve", k_w1_solve, dim3(cdiv(w, 256), h, n_pairs), dim3(256), 0,
+                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h);
+    }
     // any other window: the generic block-per-strip kernel
     const int out_cols = BS_THREADS - 2 * m;
     const unsigned strips = cdiv(w, out_cols);
@@ -3608,7 +3638,8 @@ static int fb_validate_params(const tf_fb_params *p, int width, int height)
     return TF_OK;
 }
 
-TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params, int frame_slots, int max_pairs)
+// `share`: the handle whose frame slots the new one uses (tf_fb_create_lane)
+static int fb_create(tf_fb **out, int width, int height, const tf_fb_params *params, int frame_slots, int max_pairs, tf_fb *share)
 {
     TF_REQUIRE(out && params, "tf_fb_create: null pointer");
     TF_TRY(fb_validate_params(params, width, height));
@@ -3689,7 +3720,9 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         return fail(rc);
     const size_t N0 = (size_t)width * height, P = (size_t)max_pairs;
     fb->nsets = (fb_overlap_enabled() && fb->K > 0) ? 2 : 1; // a single scale: every launch fills the chip anyway
-    if ((rc = fb->frames.alloc(N0 * frame_slots)) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
+    if (share)
+        fb->frames.borrow(share->frames.p, N0 * frame_slots);
+    if ((!share && (rc = fb->frames.alloc(N0 * frame_slots))) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
         (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
         (rc = fb->M.alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
@@ -3745,14 +3778,40 @@ TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *
         hipEventCreateWithFlags(&fb->pairs_copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->entry[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fb->entry[1], hipEventDisableTiming) != hipSuccess ||
-        side_stream(1, &fb->chain_stream) != TF_OK ||
+        side_stream(share ? 2 : 1, &fb->chain_stream) != TF_OK ||
         hipHostMalloc((void **)&fb->pairs_host, 3 * P * sizeof(int2), hipHostMallocDefault) != hipSuccess)
         return fail(set_error(TF_ERR_HIP, "creating the handle's events and staging buffer failed"));
+    if (share) {
+        fb->lane_of = share;
+        share->lanes++;
+    }
     *out = fb;
     return TF_OK;
 }
 
-TF_API void tf_fb_destroy(tf_fb *fb) { delete fb; }
+TF_API int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params, int frame_slots, int max_pairs)
+{
+    return fb_create(out, width, height, params, frame_slots, max_pairs, nullptr);
+}
+
+// A second lane for the calls of `first`: a handle of the same size and parameters that reads first's frame slots and
+// queues its calls on the library's OTHER call stream.  A caller that sends batches alternately to the two keeps two calls
+// in flight: the part-empty launches of one (the coarse levels; the tail of every launch) run beside the full ones of the
+// other.  Results are per handle, as ever: tf_fb_flow_ptr etc. on the handle that ran the call.
+TF_API int tf_fb_create_lane(tf_fb **out, tf_fb *first)
+{
+    TF_REQUIRE(out && first, "tf_fb_create_lane: null pointer");
+    TF_REQUIRE(!first->lane_of, "tf_fb_create_lane: the handle is itself a lane");
+    TF_REQUIRE(!first->keep, "tf_fb_create_lane: the handle keeps its expansions between calls (tf_fb_keep_expansions); lanes do not share them");
+    return fb_create(out, first->W, first->H, &first->prm, first->slots, first->max_pairs, first);
+}
+
+TF_API void tf_fb_destroy(tf_fb *fb)
+{
+    if (fb && fb->lane_of)
+        fb->lane_of->lanes--;
+    delete fb;
+}
 
 TF_API int tf_fb_level_count(tf_fb *fb, int *n_scales)
 {
@@ -3820,6 +3879,7 @@ TF_API int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev)
 TF_API int tf_fb_keep_expansions(tf_fb *fb, int on)
 {
     TF_REQUIRE(fb, "tf_fb_keep_expansions: null handle");
+    TF_REQUIRE(!on || (!fb->lane_of && fb->lanes == 0), "tf_fb_keep_expansions: not with lanes (tf_fb_create_lane): expansions are per handle");
     TF_REQUIRE(!on || fb->slots <= 2 * fb->max_pairs, "tf_fb_keep_expansions: %d frame slots need room for %d expansions, "
                                                       "the handle holds %d (2 x max_pairs)", fb->slots, fb->slots,
                2 * fb->max_pairs);

@@ -27,9 +27,16 @@ def _ptr(a: np.ndarray) -> C.c_void_p:
 class Farneback:
     def __init__(self, width: int, height: int, pyr_scale: float = 0.5, levels: int = 3, winsize: int = 15,
                  iterations: int = 3, poly_n: int = 5, poly_sigma: float = 1.2, flags: int = 0,
-                 frame_slots: int = 2, max_pairs: int = 1, device: int | None = None):
+                 frame_slots: int = 2, max_pairs: int = 1, device: int | None = None, lanes: int = 1):
+        """lanes = 2: calc_slots calls go alternately to two handles that share the frame slots and queue on the
+        library's two call streams (tf_fb_create_lane), so consecutive batches are in flight together; results
+        (get_flow, flow_ptr, post_process ...) are those of the latest call.  For callers that issue batch after
+        batch without reading each back first (the resident path); not with keep_expansions."""
+        if lanes not in (1, 2):
+            raise ValueError("lanes must be 1 or 2")
         self._lib = _lib.load()
         self._h = C.c_void_p()
+        self._h2 = C.c_void_p()
         if device is not None:
             check(self._lib.tf_init(int(device)))
         self.width, self.height = int(width), int(height)
@@ -39,8 +46,21 @@ class Farneback:
                          float(poly_sigma), int(flags))
         check(self._lib.tf_fb_create(C.byref(self._h), self.width, self.height, C.byref(prm),
                                      self.frame_slots, self.max_pairs))
+        self._handles = [self._h]
+        if lanes == 2:
+            check(self._lib.tf_fb_create_lane(C.byref(self._h2), self._h))
+            self._handles.append(self._h2)
+        self._calls = 0
+        self._last = self._h   # the handle whose results the reading methods return
+
+    @property
+    def _next(self):
+        return self._handles[self._calls % len(self._handles)]
 
     def close(self):
+        if getattr(self, "_h2", None) is not None and self._h2.value:
+            self._lib.tf_fb_destroy(self._h2)
+            self._h2 = C.c_void_p()
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.tf_fb_destroy(self._h)
             self._h = C.c_void_p()
@@ -74,6 +94,7 @@ class Farneback:
         else:
             flow = np.empty((self.height, self.width, 2), np.float32)
         check(self._lib.tf_fb_calc(self._h, _ptr(p), p.strides[0], _ptr(n), n.strides[0], _ptr(flow)))
+        self._last = self._h
         return flow
 
     # -- resident path ----------------------------------------------------------------
@@ -96,11 +117,11 @@ class Farneback:
         f = np.ascontiguousarray(flow, dtype=np.float32)
         if f.shape != (self.height, self.width, 2):
             raise ValueError(f"initial flow shape {f.shape} != {(self.height, self.width, 2)}")
-        check(self._lib.tf_fb_set_initial_flow(self._h, int(pair), _ptr(f)))
+        check(self._lib.tf_fb_set_initial_flow(self._next, int(pair), _ptr(f)))
 
     def initial_flow_ptr(self, pair: int) -> int:
         p = C.c_void_p()
-        check(self._lib.tf_fb_initial_flow_ptr(self._h, int(pair), C.byref(p)))
+        check(self._lib.tf_fb_initial_flow_ptr(self._next, int(pair), C.byref(p)))
         return p.value
 
     def stage_initial_flow(self, flow) -> np.ndarray:
@@ -121,26 +142,29 @@ class Farneback:
             raise ValueError("prev_slots and next_slots differ in length")
         a = (C.c_int * n)(*[int(v) for v in prev_slots])
         b = (C.c_int * n)(*[int(v) for v in next_slots])
-        check(self._lib.tf_fb_calc_slots(self._h, n, a, b))
+        h = self._next
+        check(self._lib.tf_fb_calc_slots(h, n, a, b))
+        self._calls += 1
+        self._last = h
 
     def get_flow(self, pair: int = 0) -> np.ndarray:
         flow = np.empty((self.height, self.width, 2), np.float32)
-        check(self._lib.tf_fb_get_flow(self._h, int(pair), _ptr(flow)))
+        check(self._lib.tf_fb_get_flow(self._last, int(pair), _ptr(flow)))
         return flow
 
     def get_flow_into(self, pair: int, out: np.ndarray) -> np.ndarray:
         if out.dtype != np.float32 or not out.flags.c_contiguous or out.shape != (self.height, self.width, 2):
             raise ValueError("get_flow_into needs a C-contiguous float32 array of shape (H, W, 2)")
-        check(self._lib.tf_fb_get_flow(self._h, int(pair), _ptr(out)))
+        check(self._lib.tf_fb_get_flow(self._last, int(pair), _ptr(out)))
         return out
 
     def flow_ptr(self, pair: int = 0) -> int:
         p = C.c_void_p()
-        check(self._lib.tf_fb_flow_ptr(self._h, int(pair), C.byref(p)))
+        check(self._lib.tf_fb_flow_ptr(self._last, int(pair), C.byref(p)))
         return p.value
 
     def post_process(self, pair: int, direction: int) -> None:
-        check(self._lib.tf_fb_post_process(self._h, int(pair), int(direction)))
+        check(self._lib.tf_fb_post_process(self._last, int(pair), int(direction)))
 
     def keep_expansions(self, on: bool = True) -> None:
         """Streaming: a slot's pyramid and polynomial expansion stay valid until set_frame writes it."""
@@ -150,7 +174,7 @@ class Farneback:
         """First half of FORWARD post_process: device address of the int32 [H, W] winner map
         (RemapLayer.step_dev(..., clip_flow=2) does the rest)."""
         p = C.c_void_p()
-        check(self._lib.tf_fb_post_process_scatter(self._h, int(pair), C.byref(p)))
+        check(self._lib.tf_fb_post_process_scatter(self._last, int(pair), C.byref(p)))
         return p.value
 
     def post_process_host(self, flow: np.ndarray, direction: int) -> np.ndarray:
@@ -196,7 +220,7 @@ class Farneback:
 
     def post_process_ex(self, pair: int, direction: int, ops=(), mask_dev: int | None = None) -> None:
         arr, n = self._ops_array(ops)
-        check(self._lib.tf_fb_post_process_ex(self._h, int(pair), int(direction), n, arr,
+        check(self._lib.tf_fb_post_process_ex(self._last, int(pair), int(direction), n, arr,
                                               C.c_void_p(mask_dev) if mask_dev else None))
 
     # -- geometry / stage entry points (parity tests) -----------------------------------
