@@ -18,7 +18,7 @@ for arg in sys.argv[3:]:
         reps = int(v)          # a longer run (tools/clock_watch.sh samples clocks and power beside it)
     else:
         _lib.set_option(k, int(v))
-job = bench.Job(bench.WORKLOADS[name], batch, bench.make_plan(batch + 1, batch, 0, 1), batch + 1, seed=2000, device=0)
+job = bench.Job(bench.WORKLOADS[name], batch, bench.make_plan(batch + 1, batch, 0, 1), batch + 1, seed=2000, device=0, lanes=1)
 for _ in range(2):
     job.step()
 job.sync()

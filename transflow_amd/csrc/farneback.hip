@@ -2487,17 +2487,27 @@ k_blur_carry(const float *__restrict__ Min, double *__restrict__ S, int Wk, int 
     S[(((size_t)by * gridDim.z + pair) * 5 + c) * Wk + x] = vs;
 }
 
-// S[s][i] (what segment s adds to the chain; S[0]: the chain after segment 0) -> the chain's value in front of segment s
+// S[s][i] (what segment s adds to the chain; S[0]: the chain after segment 0) -> the chain's value in front of segment s.
+// Sixteen segments' values are loaded together (the additions are a serial chain, the loads need not be: with up to 64
+// segments a load per addition made this the longest kernel of a small level).
 __global__ void k_carry_scan(double *__restrict__ S, size_t n, int segs)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
     double acc = S[i];
-    for (int s = 1; s < segs; s++) {
-        const double t = S[(size_t)s * n + i];
-        S[(size_t)s * n + i] = acc;
-        acc += t;
+    for (int s0 = 1; s0 < segs; s0 += 16) {
+        double t[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            t[j] = s0 + j < segs ? S[(size_t)(s0 + j) * n + i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (s0 + j < segs) {
+                S[(size_t)(s0 + j) * n + i] = acc;
+                acc += t[j];
+            }
+        }
     }
 }
 
@@ -3259,7 +3269,8 @@ static int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowIn
 //     segment count is the one that minimises rounds x steps.  With fewer columns the segments would only queue up
 //     behind each other, so the column is marched whole (one segment, no hand-off) on a part-empty chip.
 //   pre-pass (mode 0): segments side by side as before, for a second launch that makes the rows of M for their carries
-//     (prepass_cost x the march's time; k_blur_carry, which reads M, is cheap).
+//     (prepass_cost x the march's time; k_blur_carry, which reads M, is cheap) and a third that adds them up: two
+//     launches of a fixed cost each (prepass_steps, in steps of the march) that a short column does not repay.
 // Times are in units of one workgroup step at full residency; a step is faster on a part-empty chip (step_time).
 // ---------------------------------------------------------------------------------
 struct March {
@@ -3267,13 +3278,14 @@ struct March {
 };
 static double step_time(double wgs_per_cu, int slots_per_cu)
 {
-    // measured on MI355X for k_flow_iter_pc (3 slots per CU): one workgroup alone on its CU steps in ~0.6 of the time
-    // it takes beside two others
+    // measured on MI355X for k_flow_iter_pc (3 slots per CU): a step takes 0.69 / 0.83 / 0.88 us with 1.1 / 2.25 / 3
+    // workgroups per CU on average (a wave's ~130 instructions per step at one issue every ~8 cycles, not memory latency,
+    // set the pace, so company costs little)
     const double full = slots_per_cu, o = std::min(std::max(wgs_per_cu, 1.0), full);
-    static const double alone = tune("TF_STEP_ALONE_PCT", 60) / 100.0;
+    static const double alone = tune("TF_STEP_ALONE_PCT", 78) / 100.0;
     return full <= 1 ? 1.0 : alone + (1.0 - alone) * (o - 1.0) / (full - 1.0);
 }
-static March choose_march(long columns, int h, int warm, long slots, int slots_per_cu, double prepass_cost, int min_rows)
+static March choose_march(long columns, int h, int warm, long slots, int slots_per_cu, double prepass_cost, double prepass_steps, int min_rows)
 {
     const long forced_segs = option(OPT_FB_SEGS), forced_mode = option(OPT_FB_CHAIN);
     const long cus = std::max(1l, slots / slots_per_cu);
@@ -3309,7 +3321,7 @@ static March choose_march(long columns, int h, int warm, long slots, int slots_p
     } else if (forced_mode == 1 || (forced_mode < 0 && columns >= slots)) {
         m.mode = 1;
         m.segs = (int)best_segs;
-    } else if (forced_mode == 0 || forced_segs > 0 || best_cost * (1.0 + prepass_cost) < whole) {
+    } else if (forced_mode == 0 || forced_segs > 0 || best_cost * (1.0 + prepass_cost) + prepass_steps < whole) {
         m.mode = 0;
         m.segs = (int)best_segs;
     } else {
@@ -3363,11 +3375,25 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, float2 *
     constexpr int HALO = (M + 1) & ~1;
     constexpr int OUTC = 128 - 2 * HALO;
     const unsigned strips = cdiv(w, OUTC);
-    // one-wave workgroups, 12 resident per CU; a segment's carry comes from k_blur_carry (M is in memory: the pre-pass
-    // reads the entering and the leaving row of every step, a fraction of the march's own time), never from inside the launch
-    static const long slots = tune("TF_BLUR_SLOTS", 3072);
-    March mc = choose_march((long)strips * n_pairs, h, 0, slots, 12, 0.35, 8);
+    // One-wave workgroups, 12 resident per CU.  A lone wave takes ~0.9 us per row (load -> LDS -> solve -> store is one
+    // dependent chain), so even a small level is cut into segments: tall enough to repay the march's start, many enough
+    // for a few waves per resident slot (measured at 4K x 16: 4096 / 8192 / 12288 / 16384 waves -> 5.03 / 4.92 / 4.88 /
+    // 4.86 ms for all levels).  The segments' carries come from k_blur_carry + k_carry_scan (M is in memory: the pre-pass
+    // reads the entering and the leaving row of every step; ~17 us for the two launches at a small level), never from
+    // inside the launch; a level of <= 40 rows is marched whole (35 us against 31 us at 60 x 34).
+    static const long waves_wanted = tune("TF_BLUR_WAVES", 12288);
+    March mc;
     mc.mode = 0;
+    {
+        const long segs_wanted = std::max(1l, waves_wanted / std::max(1l, (long)strips * n_pairs));
+        int seg = (int)std::min<long>(256, std::max<long>(16, (h + segs_wanted - 1) / segs_wanted));
+        if (h <= 40)
+            seg = h;
+        if (option(OPT_FB_SEGS) > 0)
+            seg = std::max(1, (int)((h + option(OPT_FB_SEGS) - 1) / option(OPT_FB_SEGS)));
+        mc.seg = seg;
+        mc.segs = (int)cdiv(h, seg);
+    }
     const double *carry = nullptr;
     if (mc.segs > 1) {
         TF_TRY(fb_carry_room(fb, (size_t)mc.segs * n_pairs * 5 * w, 0));
@@ -3448,8 +3474,8 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
     // rounds of 768, each as long as a segment plus its 2M+1 warm-up steps and the drain step (choose_march)
     static const long slots = tune("TF_PC_SLOTS", 768);
-    static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 60) / 100.0;
-    const March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 2 * WIN);
+    static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 80) / 100.0; // k_flow_carry_pc: 0.76 of the march it serves (4K x 32, level 2)
+    const March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN); // (steps of ~0.9 us)
     FlowInit f;
     memset(&f, 0, sizeof(f));
     if (up)
