@@ -89,6 +89,18 @@ int tf_prof_set_filter(const char *substring);
 int tf_prof_reset(void);
 int tf_prof_report(char *buf, size_t buf_size);
 
+/* Page-locked host memory (hipHostMalloc): arrays the drop-in path hands across the boundary come from a pool of
+   these, so that the copies behind tf_fb_get_flow / tf_comp_download (transflow/flow/sources/cv.py:490's result,
+   transflow/output/ffmpeg.py:32-54's frame) and the upload of a flow into the compositor run at the link's rate
+   instead of through the driver's staging of pageable memory. */
+int tf_host_alloc(void **host, size_t bytes);
+int tf_host_free(void *host);
+/* The calling THREAD's library stream: 0 = the library stream (default), 1..3 = one of three further streams.
+   Everything the thread then queues through the library -- uploads, a flow source's calls and downloads -- is ordered
+   on that stream and runs beside other threads' work (the reference runs its flow source in a process of its own,
+   transflow/pipeline.py:56-64; a prefetching flow source in a worker thread gets the same concurrency here). */
+int tf_thread_stream(int which);
+
 /* Raw device buffers, for harnesses that keep inputs resident in HBM. */
 int tf_dev_alloc(void **dev, size_t bytes);
 int tf_dev_free(void *dev);

@@ -254,6 +254,70 @@ def test_flow_source_over_bgr_frames_ingests_on_the_device(direction, src_size, 
                 assert (flow == np.rint(flow)).all() and (flow != exp[t]).any(axis=2).mean() < 0.01
 
 
+def test_prefetching_flow_source_yields_the_same_flows_from_pinned_arrays():
+    """FlowConfig.hip_prefetch: the source runs ahead of its consumer in a worker thread with a library stream of its own
+    (what the reference's child process + queue give it, pipeline.py:56-64, 85-86) while the consumer's thread works the
+    compositor; flows, their order and the end of the iteration are those of the plain source, the compositor's frames
+    too.  Arrays handed out come from the page-locked pool and stay intact while the caller holds them."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import FlowConfig, LayerConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 180, 256
+    frames = _bgr_frames(h, w, 9)
+    pix = np.random.default_rng(3).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+    class Src:
+        introduction_mask = np.ones((h, w), bool)
+
+        def next(self, timeout=1):
+            return pix
+
+    def run(cfg):
+        comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
+        comp.set_sources({0: [Src()]})
+        flows, images, held = [], [], []
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
+            for flow in source:
+                held.append(flow)                 # keep every array: the pool must never hand one out again
+                flows.append(flow.copy())
+                comp.update(flow)
+                images.append(comp.render().copy())
+            with pytest.raises(StopIteration):
+                next(source)
+        for a, b in zip(held, flows):
+            np.testing.assert_array_equal(a, b)
+        return flows, images
+    plain = run(None)
+    ahead = run(FlowConfig(hip_prefetch=3))
+    assert len(plain[0]) == len(ahead[0]) == 8
+    for a, b in zip(plain[0] + plain[1], ahead[0] + ahead[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_prefetching_flow_source_passes_errors_on_and_stops_cleanly():
+    """An exception in the worker thread (a provider that fails) surfaces in the consumer's thread at the flow it belongs
+    to; closing a source whose worker is blocked on a full queue returns."""
+    from transflow_amd.config import FlowConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 64, 96
+    frames = _bgr_frames(h, w, 12)
+
+    class Failing(ArrayFrameProvider):
+        def read(self):
+            if self.pos == 4:
+                raise OSError("decoder died")
+            return ArrayFrameProvider.read(self)
+    with HipFlowSource.from_args(Failing(frames, 25.0), direction="backward", cv_config=FlowConfig(hip_prefetch=2)) as source:
+        got = []
+        with pytest.raises(OSError, match="decoder died"):
+            for flow in source:
+                got.append(flow)
+        assert len(got) == 3
+    source = HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=FlowConfig(hip_prefetch=1)).__enter__()
+    next(source)                                  # the worker now sits on a full queue
+    source.close()
+
+
 def test_flow_source_host_path_ingests_on_the_device_too(lib_option):
     """A lock expression makes __next__ take the public next() / post_process() pair (host arrays): the frames still
     become grey on the device, and the flows equal the resident path's."""

@@ -5,7 +5,10 @@ This is the PCIe-inclusive rate DESIGN.md section 5 quotes; it is never bench.py
 source reads are decoded BGR frames, as a video capture hands them over (cv.py:461-466): the upload of the colour
 frame and its conversion to grey on the device are inside the measured time (`grey` as a third argument feeds
 ready-made grey frames instead, the form the round-2 figures were taken with).
-Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact]"""
+`prefetch` lets the flow source run two flows ahead in a worker thread with a stream of its own (FlowConfig.hip_prefetch --
+what the reference's child process + queue give it, pipeline.py:56-64): flow t + 1 is computed while the compositor
+works on flow t.
+Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch]"""
 import os
 import sys
 import time
@@ -21,10 +24,11 @@ from transflow_amd.flow import ArrayFrameProvider, HipFlowSource  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "1080p"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 w, h = {"1080p": (1920, 1080), "4k": (3840, 2160)}[name]
-clip = bench.ClipSynth(h, w, n + 1, 2000)
-frames = [clip.frame(t) for t in range(n + 1)]
+clip = bench.ClipSynth(h, w, n + 6, 2000)
+frames = [clip.frame(t) for t in range(n + 6)]
 kind = sys.argv[3] if len(sys.argv) > 3 else "bgr"
-exact = len(sys.argv) > 4 and sys.argv[4] == "exact"     # flows bit-identical to the CPU path's (option fb_exact_sums)
+exact = "exact" in sys.argv[4:]          # flows bit-identical to the CPU path's (option fb_exact_sums)
+prefetch = "prefetch" in sys.argv[4:]
 if kind == "bgr":   # three channels around the texture, so that the grey value still carries it
     frames = [np.stack([f // 2 + 20, f, 255 - (255 - f) // 2], axis=2).astype(np.uint8) for f in frames]
 pix = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -41,14 +45,15 @@ comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
 comp.set_sources({0: [Src()]})
 t_flow = t_comp = 0.0
 cfg = None
-if exact:
+if exact or prefetch:
     from transflow_amd.config import FlowConfig  # noqa: E402
-    cfg = FlowConfig(hip_exact_sums=True)
+    cfg = FlowConfig(hip_exact_sums=exact, hip_prefetch=2 if prefetch else 0)
 with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backward", cv_config=cfg) as source:
     it = iter(source)
-    flow = next(it)                      # warm-up: handle creation, first launches
-    comp.update(flow)
-    comp.render()
+    for _ in range(6):                   # warm-up: handle creation, first launches, the pools of page-locked arrays
+        flow = next(it)
+        comp.update(flow)
+        comp.render()
     k = 0
     while True:
         t0 = time.perf_counter()
@@ -63,5 +68,5 @@ with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backwa
         t_flow += t1 - t0
         t_comp += t2 - t1
         k += 1
-print(f"{name} ({kind} frames in{', exact sums' if exact else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
+print(f"{name} ({kind} frames in{', exact sums' if exact else ''}{', flow source prefetching' if prefetch else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
       f"{k / (t_flow + t_comp):.1f} frames/s end to end through host arrays (one process)")

@@ -78,6 +78,9 @@ PROTOTYPES = {
     "tf_dev_copy": (_I, [_P, _P, C.c_size_t]),
     "tf_dev_stream_copy": (_I, [_P, _P, C.c_size_t]),
     "tf_fb_create": (_I, [_PP, _I, _I, C.POINTER(TfFbParams), _I, _I]),
+    "tf_host_alloc": (_I, [_PP, C.c_size_t]),
+    "tf_host_free": (_I, [_P]),
+    "tf_thread_stream": (_I, [_I]),
     "tf_fb_create_lane": (_I, [_PP, _P]),
     "tf_fb_destroy": (None, [_P]),
     "tf_fb_calc": (_I, [_P, _P, C.c_ssize_t, _P, C.c_ssize_t, _P]),

@@ -274,7 +274,7 @@ class HipCompositor:
             layer.render_into(comp)
         if self._frame_pool is None:
             from .device import ArrayPool
-            self._frame_pool = ArrayPool((self.height, self.width, 3), np.uint8)
+            self._frame_pool = ArrayPool((self.height, self.width, 3), np.uint8, pinned=True)
         return comp.download(self._frame_pool.take())
 
     @classmethod

@@ -96,6 +96,10 @@ class FlowConfig:
         # the Farnebäck time).  The reference ignores keys it does not know only if they are not there: leave it out
         # of files the reference itself must read.
         self.hip_exact_sums = parse_bool_arg(kwargs.pop("hip_exact_sums", None), False)
+        # "hip_prefetch": n > 0 lets the flow source run up to n flows ahead of its consumer in a worker thread with a
+        # library stream of its own (what the reference gets from running the source in a child process behind a
+        # queue, pipeline.py:56-64, for a source used in-process).  Its position attributes then run ahead by as much.
+        self.hip_prefetch = int(kwargs.pop("hip_prefetch", 0) or 0)
         self.extra = dict(kwargs)  # hs_*, lk_*, show_window ...: not used by this backend
 
     def fb_kwargs(self) -> dict:
@@ -109,6 +113,8 @@ class FlowConfig:
         d.update(self.extra)
         if self.hip_exact_sums:
             d["hip_exact_sums"] = True
+        if self.hip_prefetch:
+            d["hip_prefetch"] = self.hip_prefetch
         return d
 
     def to_file(self, path: str):

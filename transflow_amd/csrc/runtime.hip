@@ -47,9 +47,13 @@ static OptDef g_opts[OPT_COUNT] = {
 long option(Opt which) { return g_opts[which].value; }
 
 static thread_local hipStream_t g_override = nullptr;
+// tf_thread_stream: the calling thread's own "library stream" (a flow source prefetching in a worker thread queues its
+// uploads, kernels and downloads there, beside the compositor's on the library stream proper)
+static thread_local hipStream_t g_thread_main = nullptr;
+static hipStream_t g_thread_streams[3] = {nullptr, nullptr, nullptr};
 
-hipStream_t stream() { return g_override ? g_override : g_stream; }
-hipStream_t main_stream() { return g_stream; }
+hipStream_t main_stream() { return g_thread_main ? g_thread_main : g_stream; }
+hipStream_t stream() { return g_override ? g_override : main_stream(); }
 
 // Side streams are the library's, not a handle's: HIP multiplexes streams onto a few hardware queues
 // (four by default), and streams that share a queue serialise -- with per-handle side streams a second
@@ -332,6 +336,41 @@ TF_API int tf_prof_report(char *buf, size_t buf_size)
             return set_error(TF_ERR_ARG, "tf_prof_report: buffer too small");
         off += (size_t)n;
     }
+    return TF_OK;
+}
+
+TF_API int tf_thread_stream(int which)
+{
+    TF_REQUIRE(which >= 0 && which <= 3, "tf_thread_stream: stream %d not in 0..3", which);
+    TF_TRY(ensure_init());
+    if (which == 0) {
+        g_thread_main = nullptr;
+        return TF_OK;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_thread_streams[which - 1]) {
+            int least = 0, greatest = 0;
+            TF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            TF_HIP(hipStreamCreateWithPriority(&g_thread_streams[which - 1], hipStreamNonBlocking, greatest));
+        }
+    }
+    g_thread_main = g_thread_streams[which - 1];
+    return TF_OK;
+}
+
+TF_API int tf_host_alloc(void **host, size_t bytes)
+{
+    TF_REQUIRE(host, "tf_host_alloc: null pointer");
+    TF_TRY(ensure_init());
+    TF_HIP(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
+    return TF_OK;
+}
+
+TF_API int tf_host_free(void *host)
+{
+    if (host)
+        TF_HIP(hipHostFree(host));
     return TF_OK;
 }
 

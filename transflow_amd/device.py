@@ -52,13 +52,45 @@ class DevBuffer:
             pass
 
 
+class _Pinned:
+    """One page-locked host allocation (tf_host_alloc); freed when the last array over it is gone."""
+
+    def __init__(self, nbytes: int):
+        self._lib = _lib.load()
+        p = C.c_void_p()
+        check(self._lib.tf_host_alloc(C.byref(p), int(nbytes)))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._lib.tf_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """numpy.empty over page-locked memory: copies to and from the device run at the link's rate and asynchronously
+    (transflow/output/ffmpeg.py:32-54 writes such a frame to the encoder; cv.py:490's flow is one).  The allocation
+    lives as long as any array or view over it."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    own = _Pinned(max(1, n))
+    buf = (C.c_char * max(1, n)).from_address(own.ptr)
+    buf._owner = own                      # the array's base keeps the ctypes view, the view keeps the allocation
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class ArrayPool:
     """Host arrays handed out again once nobody else holds them.  A fresh 66 MB numpy array costs
     ~5 ms of page faults at 4K -- four times the copy that fills it -- so per-frame outputs (flows,
-    rendered frames) come from a small pool; an array the caller still references is never reused."""
+    rendered frames) come from a small pool; an array the caller still references is never reused.
+    `pinned`: the arrays are page-locked (pinned_empty)."""
 
-    def __init__(self, shape, dtype, limit: int = 4):
+    def __init__(self, shape, dtype, limit: int = 4, pinned: bool = False):
         self.shape, self.dtype, self.limit = tuple(shape), np.dtype(dtype), int(limit)
+        self.pinned = bool(pinned)
         self._arrays: list = []
 
     def take(self) -> np.ndarray:
@@ -66,7 +98,7 @@ class ArrayPool:
         for a in self._arrays:
             if sys.getrefcount(a) == 3:      # the list, the loop variable, getrefcount's argument
                 return a
-        a = np.empty(self.shape, self.dtype)
+        a = pinned_empty(self.shape, self.dtype) if self.pinned else np.empty(self.shape, self.dtype)
         if len(self._arrays) < self.limit:
             self._arrays.append(a)
         return a

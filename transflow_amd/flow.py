@@ -460,6 +460,65 @@ class Cv2FrameProvider:
         self.capture.release()
 
 
+class _Prefetch:
+    """A worker thread that iterates a flow source ahead of its consumer (HipFlowSource.__next__)."""
+
+    def __init__(self, source, depth: int):
+        import queue
+        import threading
+        self.source = source
+        self.queue = queue.Queue(maxsize=max(1, int(depth)))
+        self.halt = threading.Event()
+        self.finished = None                       # ("stop", None) or ("error", exception) once the worker has ended
+        self.thread = threading.Thread(target=self._run, name="tfhip-flow-prefetch", daemon=True)
+        self.thread.start()
+
+    def _put(self, item) -> bool:
+        import queue
+        while not self.halt.is_set():
+            try:
+                self.queue.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self):
+        from . import _lib
+        try:
+            _lib.check(_lib.load().tf_thread_stream(1))
+            while not self.halt.is_set():
+                try:
+                    flow = FlowSource.__next__(self.source)
+                except StopIteration:
+                    self._put(("stop", None))
+                    return
+                if not self._put(("flow", flow)):
+                    return
+        except BaseException as err:            # noqa: BLE001 -- re-raised in the consumer's thread
+            self._put(("error", err))
+
+    def get(self):
+        if self.finished is None:
+            kind, value = self.queue.get()
+            if kind == "flow":
+                return value
+            self.finished = (kind, value)
+        if self.finished[0] == "error":
+            raise self.finished[1]
+        raise StopIteration
+
+    def stop(self):
+        import queue
+        self.halt.set()
+        while self.thread.is_alive():
+            try:
+                self.queue.get_nowait()
+            except queue.Empty:
+                pass
+            self.thread.join(timeout=0.05)
+
+
 class HipFlowSource(FlowSource):
     """CvFlowSource's Farnebäck branch on the GPU (cv.py:434-521)."""
 
@@ -501,6 +560,7 @@ class HipFlowSource(FlowSource):
         self._pending = None     # array handed out by read_next_flow whose flow is still on the device
         self._mask_dev = None
         self._flow_pool = None
+        self._prefetch = None
         FlowSource.__init__(self, *args, **kwargs)
 
     def validate(self):
@@ -608,7 +668,7 @@ class HipFlowSource(FlowSource):
         self.input_frame_index += 1
         if self._flow_pool is None:
             from .device import ArrayPool
-            self._flow_pool = ArrayPool((self.height, self.width, 2), np.float32)
+            self._flow_pool = ArrayPool((self.height, self.width, 2), np.float32, limit=4 + self.config.hip_prefetch, pinned=True)
         self._pending = self._flow_pool.take()       # filled by post_process
         return self._pending
 
@@ -634,7 +694,23 @@ class HipFlowSource(FlowSource):
         self._advance()
         return self._handle().get_flow(0)
 
+    # ---- prefetch (FlowConfig.hip_prefetch) ----------------------------------------------------
+    # The reference runs its flow source in a child process that fills a queue (pipeline.py:56-64, 85-86), so flow
+    # t + 1 is computed while the compositor works on flow t.  A source iterated in-process gets the same from a
+    # worker thread: it runs FlowSource.__next__ -- the whole recurrence, locks and rewinds included -- up to
+    # `hip_prefetch` flows ahead, queueing everything it launches on a library stream of its own (tf_thread_stream),
+    # beside the compositor's uploads, kernels and downloads.  ctypes releases the GIL inside every library call.
+    def __next__(self):
+        if not getattr(self.config, "hip_prefetch", 0):
+            return FlowSource.__next__(self)
+        if self._prefetch is None:
+            self._prefetch = _Prefetch(self, self.config.hip_prefetch)
+        return self._prefetch.get()
+
     def close(self):
+        if self._prefetch is not None:
+            self._prefetch.stop()
+            self._prefetch = None
         if self._mask_dev is not None:
             self._mask_dev.close()
             self._mask_dev = None
