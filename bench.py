@@ -482,6 +482,22 @@ def gather_leg(job, host, rccl, plans, reps=3):
     job.sync()
     host.barrier()
     dt_in = host.max_over_ranks(time.perf_counter() - t0) / n
+    # ... and with the gather on the communicator's own stream, beside the next step's Farneback call: the library stream
+    # only waits for it (on the device) before the next step's remap writes the frames' buffer again
+    host.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        job.calc_pass(job.n_steps)
+        job.n_steps += 1
+        rccl.gather_end()
+        for i in range(job.batch):
+            job.remap_pair(job.layer, job.comps[i], i)
+        rccl.gather_begin(job.out_frames.ptr, counts[rank], None if recv is None else recv.ptr,
+                          counts if rank == 0 else None)
+    rccl.gather_end()
+    job.sync()
+    host.barrier()
+    dt_beside = host.max_over_ranks(time.perf_counter() - t0) / n
     if recv is not None:
         recv.close()
     into_root = total - counts[0]
@@ -489,7 +505,8 @@ def gather_leg(job, host, rccl, plans, reps=3):
                     "one tf_batch_gather (RCCL send/recv into the root, per-rank byte counts)",
             "frames_per_gather": sum(per_pass), "frames_per_rank": per_pass, "bytes_into_root": into_root,
             "ms": dt * 1e3, "GBs_into_root": into_root / dt / 1e9 if dt > 0 else None, "verified_crc": bool(ok),
-            "frames_per_s_with_gather_every_step": sum(per_pass) / dt_in}
+            "frames_per_s_with_gather_every_step": sum(per_pass) / dt_in,
+            "frames_per_s_with_gather_beside_the_next_step": sum(per_pass) / dt_beside}
 
 
 def run_with_timeout(fn, seconds):
@@ -517,6 +534,35 @@ def run_with_timeout(fn, seconds):
 
 STUCK_THREADS = False
 EXIT_CODE = 0
+
+
+def line_skeleton(args, wl, world, plans):
+    """The part of the result line that does not depend on a measurement (the dry run prints it with nulls)."""
+    w, h = wl["w"], wl["h"]
+    pairs_per_step = sum(p["pairs_per_pass"] for p in plans)
+    return {
+        "metric": "frames/sec (Farneback+remap)", "value": None, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: one clip of T={args.clip_frames} {w}x{h} uint8 frames sharded over the ranks "
+                               f"(rank r owns pairs shard_range({args.clip_frames - 1}, r, {world}) + a one-frame halo), "
+                               f"Farneback pyr_scale=0.5 levels={wl['levels']} winsize=15 iterations=3 poly_n=5 poly_sigma=1.2 "
+                               f"flags=0, {'FORWARD' if wl['direction'] == 0 else 'BACKWARD'} post_process, moveref layer "
+                               f"(reset {'random p=0.5 through a float mask, u drawn on the GPU' if wl['reset'] else 'off'}), "
+                               "1 RGB pixmap source, render",
+                   "clip_frames": args.clip_frames,
+                   "frame_pairs_per_step_per_gpu": [p["pairs_per_pass"] for p in plans],
+                   "frame_pairs_per_step": pairs_per_step,
+                   "equal_batches": bool(args.equal_batches),
+                   "lanes": args.lanes,
+                   "pairs_per_rank": [p["n_pairs"] for p in plans],
+                   "frame_expansions": "pairs t and t+1 of a step share frame t+1: its pyramid levels and polynomial "
+                                       "expansion (A1+A2, functions of the frame alone) are computed once per step and "
+                                       "read by both; nothing is kept between steps",
+                   "parallelism": f"frame pairs of one clip sharded over {world} GPU(s), one remap stream per GPU, "
+                                  "no data-path collective"},
+    }
 
 
 def main():
@@ -562,7 +608,12 @@ def main():
     plans = host.allgather(plan)
     if args.dry_run:
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "clip_frames": args.clip_frames, "plans": plans}))
+            line = line_skeleton(args, wl, world, plans)     # the keys of a measured line, nulls where a GPU would speak
+            line.update({"rccl_ranks": None, "rccl_version": None, "per_rank_frames_per_s": None,
+                         "parity_gate": "skipped (--dry-run)", "roofline": None, "cpu_baseline": None,
+                         "kernels_ms_per_step": None, "remap_out_of_frame": None, "gather": None,
+                         "dry_run": True, "clip_frames": args.clip_frames, "plans": plans})
+            print(json.dumps(line))
         host.close()
         return
 
@@ -727,28 +778,9 @@ def main():
                       + rf.remap_bytes(w, h, reset_mask=wl["reset"], forward=wl["direction"] == 0))
     step_built = rf.built_step_bytes(w, h, wl["levels"], P, reset_mask=wl["reset"], forward=wl["direction"] == 0)
     per_gpu_s = args.steps / elapsed
-    out = {
-        "metric": "frames/sec (Farneback+remap)", "value": fps, "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload}: one clip of T={args.clip_frames} {w}x{h} uint8 frames sharded over the ranks "
-                               f"(rank r owns pairs shard_range({args.clip_frames - 1}, r, {world}) + a one-frame halo), "
-                               f"Farneback pyr_scale=0.5 levels={wl['levels']} winsize=15 iterations=3 poly_n=5 poly_sigma=1.2 "
-                               f"flags=0, {'FORWARD' if wl['direction'] == 0 else 'BACKWARD'} post_process, moveref layer "
-                               f"(reset {'random p=0.5 through a float mask, u drawn on the GPU' if wl['reset'] else 'off'}), "
-                               "1 RGB pixmap source, render",
-                   "clip_frames": args.clip_frames,
-                   "frame_pairs_per_step_per_gpu": [p["pairs_per_pass"] for p in plans],
-                   "frame_pairs_per_step": pairs_per_step,
-                   "equal_batches": bool(args.equal_batches),
-                   "lanes": args.lanes,
-                   "pairs_per_rank": [p["n_pairs"] for p in plans],
-                   "frame_expansions": "pairs t and t+1 of a step share frame t+1: its pyramid levels and polynomial "
-                                       "expansion (A1+A2, functions of the frame alone) are computed once per step and "
-                                       "read by both; nothing is kept between steps",
-                   "parallelism": f"frame pairs of one clip sharded over {world} GPU(s), one remap stream per GPU, "
-                                  "no data-path collective"},
+    out = line_skeleton(args, wl, world, plans)
+    out.update({"value": fps, "ms_per_step": elapsed / args.steps * 1e3})
+    out.update({
         "rccl_ranks": world if rccl_version is not None else 0, "rccl_version": rccl_version,
         "per_rank_frames_per_s": rank_fps,
         "parity_gate": gate if gate is not None else "skipped (--no-gate)",
@@ -783,7 +815,7 @@ def main():
                                     "model_frac": step_model * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS}},
         "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
         "remap_out_of_frame": any(oob),
-    }
+    })
     if rccl_error:
         out["rccl_error"] = rccl_error
     if options:

@@ -424,6 +424,13 @@ int tf_batch_broadcast(tf_batch *batch, void *dev, size_t bytes, int root);
    (all its inbound links at once), not a ring. */
 int tf_batch_gather(tf_batch *batch, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
                     int root);
+/* The same gather beside the library stream's next work (transflow/pipeline.py:518 takes one frame at a time; a batch of
+   finished frames need not hold up the next batch): _begin starts it, on a stream of the communicator's own, once the
+   library stream has reached the point of the call; _end makes the library stream wait for it on the device.  One at
+   a time; call _end before the send buffer is written again. */
+int tf_batch_gather_begin(tf_batch *batch, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                          int root);
+int tf_batch_gather_end(tf_batch *batch);
 /* values[n] (host) := sum (op 0) or max (op 1) over ranks; n <= 63.  Waits for the library stream on
    every rank: with n = 0 it is the barrier a timed region is bracketed with. */
 int tf_batch_reduce(tf_batch *batch, double *values, int n, int op);

@@ -184,6 +184,14 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == world and len(d["plans"]) == world
+    # the dry-run line carries the keys of a measured line (the driver's contract + this bench's own), null where a GPU
+    # would have spoken, and the workload's configuration as the measured line states it
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_gate", "rccl_ranks", "gather",
+                "per_rank_frames_per_s", "kernels_ms_per_step"):
+        assert key in d, key
+    assert d["value"] is None and d["scaling"] == "weak" and d["config"]["clip_frames"] == 256
+    assert d["config"]["frame_pairs_per_step"] == sum(p["pairs_per_pass"] for p in d["plans"])
     pairs = [tuple(p["pairs"]) for p in d["plans"]]
     assert pairs == [shard_range(255, r, world) for r in range(world)]
     for r, p in enumerate(d["plans"]):

@@ -34,6 +34,15 @@ def test_rccl_group_of_one_rank_through_the_c_abi():
     _lib.check(_lib.load().tf_sync())
     np.testing.assert_array_equal(out.download(a.shape, np.uint8), a)
     g.gather_dev(buf.ptr, a.nbytes, out.ptr)                 # equal counts form
+    # the gather beside the library stream's next work: begin -> (other work) -> end, one at a time
+    out2 = DevBuffer(a.nbytes)
+    g.gather_begin(buf.ptr, a.nbytes, out2.ptr, [a.nbytes])
+    with pytest.raises(ValueError):
+        g.gather_begin(buf.ptr, a.nbytes, out2.ptr, [a.nbytes])    # the previous one has not been ended
+    g.gather_end()
+    g.gather_end()                                                 # nothing pending: a no-op
+    _lib.check(_lib.load().tf_sync())
+    np.testing.assert_array_equal(out2.download(a.shape, np.uint8), a)
     assert g.reduce([1.5, -2.0], "max") == [1.5, -2.0]
     assert g.reduce([1.5, -2.0], "sum") == [1.5, -2.0]
     g.barrier()
@@ -58,6 +67,7 @@ def test_bench_runs_its_rccl_legs_with_one_rank():
     assert d["parity_gate"]["ok"] and d["parity_gate"]["remap_bit_exact"]
     assert d["gather"]["verified_crc"] is True and d["gather"]["frames_per_gather"] == 7
     assert d["gather"]["frames_per_rank"] == [7]
+    assert d["gather"]["frames_per_s_with_gather_beside_the_next_step"] > 0
     assert d["config"]["pairs_per_rank"] == [39] and d["config"]["frame_pairs_per_step_per_gpu"] == [7]
     assert d["value"] > 0
 
@@ -131,3 +141,22 @@ def test_a_lost_side_leg_never_loses_the_line(fault, rc, needle):
     d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d["value"] > 0 and d["parity_gate"]["ok"] and "gather" not in d
     assert needle in d["side_leg_errors"]["gather"]
+
+
+def test_bench_on_two_gpus_with_real_rccl_when_the_box_has_them():
+    """`bench.py --gpus 2` end to end with a communicator of two ranks on two devices: broadcast of the shared inputs,
+    sharded clip, barriers, the per-pass gather with its CRC check, one JSON line.  The test box has one GPU (RCCL
+    refuses two ranks on one device): skipped there, run wherever tf_device_count reports two."""
+    from transflow_amd import _lib
+    n = C.c_int()
+    _lib.check(_lib.load().tf_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip(f"{n.value} GPU visible: RCCL needs one device per rank")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "640x360", "--clip-frames", "41",
+                          "--batch", "20", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "rccl_error" not in d and "side_leg_errors" not in d
+    assert d["parity_gate"]["ok"]
+    assert d["gather"]["verified_crc"] is True and d["gather"]["frames_per_rank"] == [20, 20]

@@ -350,6 +350,18 @@ class RcclGroup:
         self._check(self._lib.tf_batch_gather(self._h, C.c_void_p(send_ptr) if send_ptr else None, int(send_bytes),
                                               C.c_void_p(recv_ptr) if recv_ptr else None, counts, int(root)))
 
+    def gather_begin(self, send_ptr: int, send_bytes: int, recv_ptr: int | None = None, recv_bytes=None, root: int = 0) -> None:
+        """gather_dev beside what the library stream does next (tf_batch_gather_begin); gather_end() before the send
+        buffer is written again."""
+        counts = None
+        if recv_bytes is not None:
+            counts = (C.c_size_t * self.world)(*[int(v) for v in recv_bytes])
+        self._check(self._lib.tf_batch_gather_begin(self._h, C.c_void_p(send_ptr) if send_ptr else None, int(send_bytes),
+                                                    C.c_void_p(recv_ptr) if recv_ptr else None, counts, int(root)))
+
+    def gather_end(self) -> None:
+        self._check(self._lib.tf_batch_gather_end(self._h))
+
     def reduce(self, values, op: str = "max"):
         vals = [float(v) for v in values]
         arr = (C.c_double * max(1, len(vals)))(*vals)

@@ -100,6 +100,19 @@ struct tf_batch {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     DevBuf scratch; // the reduction's few doubles
+    // tf_batch_gather_begin / _end: a gather beside the next pass
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t gather_from = nullptr, gather_done = nullptr;
+    bool gather_pending = false;
+    ~tf_batch()
+    {
+        if (gather_from)
+            (void)hipEventDestroy(gather_from);
+        if (gather_done)
+            (void)hipEventDestroy(gather_done);
+        if (gather_stream)
+            (void)hipStreamDestroy(gather_stream);
+    }
 };
 
 TF_API int tf_batch_unique_id(uint8_t *id)
@@ -144,6 +157,8 @@ TF_API void tf_batch_destroy(tf_batch *b)
     if (!b)
         return;
     (void)hipStreamSynchronize(main_stream());
+    if (b->gather_stream)
+        (void)hipStreamSynchronize(b->gather_stream);
     if (b->comm && g_rccl.CommDestroy)
         (void)g_rccl.CommDestroy(b->comm);
     delete b;
@@ -175,21 +190,15 @@ TF_API int tf_batch_broadcast(tf_batch *b, void *dev, size_t bytes, int root)
 
 // Rank r's `send_bytes` land at recv_dev + sum(recv_bytes[0..r)) on root.  A gather to one root uses
 // all of the root's inbound xGMI links at once (point-to-point sends, not a ring: SURVEY.md §8e).
-TF_API int tf_batch_gather(tf_batch *b, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
-                           int root)
+static int gather_on(tf_batch *b, hipStream_t s, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                     int root)
 {
-    TF_REQUIRE(b, "tf_batch_gather: null handle");
-    TF_REQUIRE(root >= 0 && root < b->world, "tf_batch_gather: root %d of %d", root, b->world);
-    TF_REQUIRE(send_dev || send_bytes == 0, "tf_batch_gather: null send buffer");
-    TF_TRY(ensure_init());
-    hipStream_t s = main_stream();
     if (b->rank == root) {
         TF_REQUIRE(recv_dev, "tf_batch_gather: root needs a receive buffer");
         if (recv_bytes)
             TF_REQUIRE(recv_bytes[root] == send_bytes, "tf_batch_gather: root's own count %zu != what it sends (%zu)",
                        recv_bytes[root], send_bytes);
     }
-    ProfScope ps("batch_gather");
     if (b->rank != root) {
         if (send_bytes)
             TF_RCCL(g_rccl.Send(send_dev, send_bytes, ncclUint8, root, b->comm, s));
@@ -220,6 +229,52 @@ TF_API int tf_batch_gather(tf_batch *b, const void *send_dev, size_t send_bytes,
         }
     }
     TF_RCCL(g_rccl.GroupEnd());
+    return TF_OK;
+}
+
+TF_API int tf_batch_gather(tf_batch *b, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                           int root)
+{
+    TF_REQUIRE(b, "tf_batch_gather: null handle");
+    TF_REQUIRE(root >= 0 && root < b->world, "tf_batch_gather: root %d of %d", root, b->world);
+    TF_REQUIRE(send_dev || send_bytes == 0, "tf_batch_gather: null send buffer");
+    TF_TRY(ensure_init());
+    ProfScope ps("batch_gather");
+    return gather_on(b, main_stream(), send_dev, send_bytes, recv_dev, recv_bytes, root);
+}
+
+// The same gather BESIDE what the library stream does next: it starts when the library stream reaches the point of this
+// call (the pass whose frames it sends is finished) and runs on a stream of the communicator's own, so the next pass's
+// Farneback call and remap need not wait for the frames to cross the links.  tf_batch_gather_end makes the library stream
+// wait for it (on the device, not the host): call it before the send buffer is written again.
+TF_API int tf_batch_gather_begin(tf_batch *b, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                                 int root)
+{
+    TF_REQUIRE(b, "tf_batch_gather_begin: null handle");
+    TF_REQUIRE(root >= 0 && root < b->world, "tf_batch_gather_begin: root %d of %d", root, b->world);
+    TF_REQUIRE(send_dev || send_bytes == 0, "tf_batch_gather_begin: null send buffer");
+    TF_REQUIRE(!b->gather_pending, "tf_batch_gather_begin: the previous gather has not been ended (tf_batch_gather_end)");
+    TF_TRY(ensure_init());
+    if (!b->gather_stream) {
+        TF_HIP(hipStreamCreateWithFlags(&b->gather_stream, hipStreamNonBlocking));
+        TF_HIP(hipEventCreateWithFlags(&b->gather_from, hipEventDisableTiming));
+        TF_HIP(hipEventCreateWithFlags(&b->gather_done, hipEventDisableTiming));
+    }
+    TF_HIP(hipEventRecord(b->gather_from, main_stream()));
+    TF_HIP(hipStreamWaitEvent(b->gather_stream, b->gather_from, 0));
+    TF_TRY(gather_on(b, b->gather_stream, send_dev, send_bytes, recv_dev, recv_bytes, root));
+    TF_HIP(hipEventRecord(b->gather_done, b->gather_stream));
+    b->gather_pending = true;
+    return TF_OK;
+}
+
+TF_API int tf_batch_gather_end(tf_batch *b)
+{
+    TF_REQUIRE(b, "tf_batch_gather_end: null handle");
+    if (!b->gather_pending)
+        return TF_OK;
+    TF_HIP(hipStreamWaitEvent(main_stream(), b->gather_done, 0));
+    b->gather_pending = false;
     return TF_OK;
 }
 
