@@ -509,6 +509,9 @@ def gather_leg(job, host, rccl, plans, reps=3):
             "frames_per_s_with_gather_beside_the_next_step": sum(per_pass) / dt_beside}
 
 
+GATHER_LEG = gather_leg     # (a name of its own: tests replace it to see what a failing or hanging side leg does to the line)
+
+
 def run_with_timeout(fn, seconds):
     """fn() on a helper thread; TimeoutError if it has not returned after `seconds` (the thread is then left behind:
     the process must end with os._exit)."""
@@ -741,12 +744,7 @@ def main():
         rccl_version = rccl.rccl_version
 
         def leg():
-            fault = os.environ.get("TF_BENCH_TEST_FAULT")      # tests only: what a failing / hanging leg does to the line
-            if fault == "gather-raises":
-                raise RuntimeError("injected failure of the gather leg")
-            if fault == "gather-hangs":
-                time.sleep(3600)
-            g = gather_leg(job, host, rccl, plans)
+            g = GATHER_LEG(job, host, rccl, plans)
             rccl.close()
             return g
 
@@ -836,6 +834,25 @@ def main():
             out["roofline"]["measured_copy_ceiling_GBs"] = ceiling
             # above the copy kernel's rate the byte model would be wrong: flagged in the line, never a lost line
             out["roofline"]["exceeds_copy_ceiling"] = bool(max(achieved, out["roofline"]["alone"]["achieved"]) > ceiling * 1.02)
+            if world == 1:
+                # the checking mode's rate on the same workload (option fb_exact_sums: the window summed in OpenCV's own
+                # order along the rows too; its flow was compared bit for bit with the oracle's in the gate)
+                from transflow_amd import _lib as L
+                saved = L.get_option("fb_exact_sums")
+                L.set_option("fb_exact_sums", 1)
+                try:
+                    job.step()
+                    job.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        job.step()
+                    job.sync()
+                    out["exact_mode"] = {"frames_per_s": 2 * job.batch / (time.perf_counter() - t0),
+                                         "bit_identical": None if gate is None else bool(gate["exact_bit_identical"]),
+                                         "what": "the timed workload with option fb_exact_sums, untimed region; the default mode "
+                                                 "differs from the same oracle in parity_gate.flow_pixels_differing pixels"}
+                finally:
+                    L.set_option("fb_exact_sums", saved)
             extra = {}
             for name in (("1080p", "1080p-1level") if world == 1 else ()):
                 if name == args.workload:
@@ -883,10 +900,14 @@ def main():
         EXIT_CODE = 5
 
 
-if __name__ == "__main__":
+def run_as_main():
     main()
     sys.stdout.flush()
     sys.stderr.flush()
     if STUCK_THREADS:      # a helper thread is still inside a call that never returned: leave without joining it,
         os._exit(4)        # and say so (the result line, if this is rank 0, has been printed)
     sys.exit(EXIT_CODE)
+
+
+if __name__ == "__main__":
+    run_as_main()

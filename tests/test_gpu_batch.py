@@ -133,8 +133,17 @@ def test_a_lost_side_leg_never_loses_the_line(fault, rc, needle):
     """The result line is complete before any untimed leg starts: a leg that raises is reported under side_leg_errors
     (exit code 0), one that never returns is abandoned after its time limit, the line is printed all the same and the
     process leaves with exit code 4."""
-    env = dict(os.environ, TF_BENCH_TEST_FAULT=fault, TF_BENCH_LEG_TIMEOUT="5")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl", "--size", "640x360", "--clip-frames",
+    env = dict(os.environ, TF_BENCH_LEG_TIMEOUT="5")
+    # bench.py with its gather leg replaced (bench.GATHER_LEG): the fault lives here, not in the benchmark
+    driver = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+              "def faulty(*a, **k):\n"
+              "    if %r == 'gather-raises':\n"
+              "        raise RuntimeError('injected failure of the gather leg')\n"
+              "    time.sleep(3600)\n"
+              "bench.GATHER_LEG = faulty\n"
+              "sys.argv = ['bench.py'] + sys.argv[1:]\n"
+              "bench.run_as_main()\n") % (ROOT, fault)
+    out = subprocess.run([sys.executable, "-c", driver, "--rccl", "--size", "640x360", "--clip-frames",
                           "9", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == rc, out.stderr[-2000:]

@@ -237,9 +237,10 @@ def test_flow_source_over_bgr_frames_ingests_on_the_device(direction, src_size, 
     for t in range(2):
         prev, nxt = (greys[t], greys[t + 1]) if direction == "forward" else (greys[t + 1], greys[t])
         exp.append(R.post_process(OF.calc(prev, nxt), d))
+    from transflow_amd.config import FlowConfig
     for exact in (1, 0):
-        lib_option("fb_exact_sums", exact)
-        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0, size=size), direction=direction) as source:
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0, size=size), direction=direction,
+                                     cv_config=FlowConfig(hip_exact_sums=bool(exact))) as source:
             assert (source.width, source.height, source.length) == (w, h, 2)
             np.testing.assert_array_equal(source.prev_gray, greys[0])      # what cv.py:456 keeps
             flows = [f.copy() for f in source]
@@ -346,6 +347,12 @@ def test_flow_config_can_ask_for_opencv_identical_flows(lib_option):
     assert cfg.to_dict()["hip_exact_sums"] is True and FlowConfig(**cfg.to_dict()).hip_exact_sums
     with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
         flows = [f.copy() for f in source]
+        assert _lib.get_option("fb_exact_sums") == 1   # the source's, while it is open ...
+    assert _lib.get_option("fb_exact_sums") == 0       # ... and what it found, once it is closed
+    lib_option("fb_exact_sums", 1)
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward") as source:
+        next(source)
+        assert _lib.get_option("fb_exact_sums") == 0   # a source whose configuration does not ask for it turns it off
     assert _lib.get_option("fb_exact_sums") == 1
     for t, flow in enumerate(flows):
         exp = R.post_process(OF.calc(frames[t + 1], frames[t], levels=2), R.BACKWARD)

@@ -3413,8 +3413,9 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
     if (option(OPT_FB_EXACT_SUMS)) { // OpenCV's own running sums, in its order (k_exact_vsum's note)
         const size_t need = (size_t)n_pairs * 5 * w * h * sizeof(double);
-        if (fb->exact_vsum.bytes < need)
-            TF_TRY(fb->exact_vsum.alloc(need));
+        if (fb->exact_vsum.bytes < need && fb->exact_vsum.alloc(need) != TF_OK)
+            return set_error(TF_ERR_HIP, "fb_exact_sums: no room for the column sums of %d pairs of %d x %d pixels (%zu bytes of doubles; "
+                                         "fewer pairs per call need less)", n_pairs, w, h, need);
         TF_TRY(launch(lvl_name("fb_exact_vsum", k), k_exact_vsum, dim3(cdiv(w, 64), 5, n_pairs), dim3(64), 0,
                       (const float *)fb->M.as<float>(), fb->exact_vsum.as<double>(), w, h, m));
         return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve, dim3(cdiv(h, 64), 1, n_pairs), dim3(64), 0,
@@ -3925,6 +3926,8 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         TF_REQUIRE(prev_slots[i] >= 0 && prev_slots[i] < fb->slots && next_slots[i] >= 0 && next_slots[i] < fb->slots,
                    "tf_fb_calc_slots: pair %d uses a slot outside [0,%d)", i, fb->slots);
     TF_TRY(fb_check_fault(fb, "tf_fb_calc_slots (an earlier call)"));
+    if (!option(OPT_FB_EXACT_SUMS) && fb->exact_vsum.p && fb->prm.winsize / 2 != 0)
+        fb->exact_vsum.release(); // the checking mode's column sums (40 bytes per pixel and pair): not kept once it is off
     if (fb->pairs_pending) { // the previous call's copy out of the staging buffer (long done in practice)
         TF_HIP(hipEventSynchronize(fb->pairs_copied));
         fb->pairs_pending = false;

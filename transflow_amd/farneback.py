@@ -75,7 +75,7 @@ class Farneback:
         a = np.asarray(frame)
         if a.dtype != np.uint8 or a.shape != (self.height, self.width):
             raise ValueError(f"expected uint8 grey frame {(self.height, self.width)}, got {a.dtype} {a.shape}")
-        if a.strides[1] != 1:
+        if a.strides[1] != 1 or a.strides[0] < a.shape[1]:
             a = np.ascontiguousarray(a)
         return a
 
@@ -108,8 +108,8 @@ class Farneback:
         a = np.asarray(frame)
         if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
             raise ValueError(f"expected a uint8 BGR frame (H, W, 3), got {a.dtype} {a.shape}")
-        if a.strides[2] != 1 or a.strides[1] != 3:
-            a = np.ascontiguousarray(a)
+        if a.strides[2] != 1 or a.strides[1] != 3 or a.strides[0] < 3 * a.shape[1]:
+            a = np.ascontiguousarray(a)   # (a vertically flipped view, frame[::-1], or a broadcast row: rows that do not advance)
         check(self._lib.tf_fb_set_frame_bgr(self._h, int(slot), _ptr(a), a.shape[1], a.shape[0], a.strides[0]))
 
     def set_initial_flow(self, pair: int, flow) -> None:
