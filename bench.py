@@ -539,6 +539,22 @@ STUCK_THREADS = False
 EXIT_CODE = 0
 
 
+def level_fracs(rf, dominant, by_level, wl, pairs):
+    """The dominant kernel's launches level by level (timed alone): a level that fills the chip and one that does not
+    are different stories."""
+    if dominant != "fb_flow_iter":
+        return None
+    per = rf.built_flow_iter_level_bytes(wl["w"], wl["h"], wl["levels"], pairs)
+    out = {}
+    for name, (cnt, ms) in sorted(by_level.items()):
+        k = int(name.rsplit(".k", 1)[1])
+        if k in per and cnt:
+            steps = cnt / 3.0                                  # three launches of a level per step
+            gbs = per[k] * steps / (ms * 1e-3) / 1e9
+            out[f"level{k}"] = {"launches": cnt, "avg_launch_ms": ms / cnt, "achieved": gbs, "frac": gbs / rf.HBM_PEAK_GBS}
+    return out
+
+
 def line_skeleton(args, wl, world, plans):
     """The part of the result line that does not depend on a measurement (the dry run prints it with nulls)."""
     w, h = wl["w"], wl["h"]
@@ -726,13 +742,17 @@ def main():
     # the same kernel with nothing beside it: a few steps with a synchronisation after each, so neither the other lane's
     # batch nor the previous batch's remap shares the chip with it (in the timed region they do: that is what two lanes
     # are for, and a launch's duration there includes the time it shares)
+    from transflow_amd import _lib as _L
     job.prof_reset()
+    _L.set_option("prof_levels", 1)          # labels carry the pyramid level: "fb_flow_iter.k0"
     job.prof(True, dominant)
     for _ in range(3):
         job.step()
         job.sync()
     job.prof(False)
-    alone_cnt, alone_ms = job.prof_report()[dominant]
+    _L.set_option("prof_levels", 0)
+    by_level = {k: v for k, v in job.prof_report().items() if k.startswith(dominant + ".k")}
+    alone_cnt, alone_ms = sum(v[0] for v in by_level.values()), sum(v[1] for v in by_level.values())
     rank_fps = host.gather(args.steps * job.batch / t_rank)
     oob = host.gather(bool(job.layer.out_of_frame()))
 
@@ -799,6 +819,7 @@ def main():
                      "alone": {"what": "the same launches in steps that are synchronised one by one (no other lane, no remap "
                                        "beside them), measured right after the timed region",
                                "launches": alone_cnt, "avg_launch_ms": alone_ms / max(1, alone_cnt),
+                               "by_level": level_fracs(rf, dominant, by_level, wl, P),
                                "achieved": built / max(1, dom_cnt) * alone_cnt / (alone_ms * 1e-3) / 1e9,
                                "frac": built / max(1, dom_cnt) * alone_cnt / (alone_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS},
                      "model_work_rate": {"what": "SURVEY Appendix C stage-once bytes of the reference's stages (96 B/px per "

@@ -3285,7 +3285,8 @@ static double step_time(double wgs_per_cu, int slots_per_cu)
     static const double alone = tune("TF_STEP_ALONE_PCT", 78) / 100.0;
     return full <= 1 ? 1.0 : alone + (1.0 - alone) * (o - 1.0) / (full - 1.0);
 }
-static March choose_march(long columns, int h, int warm, long slots, int slots_per_cu, double prepass_cost, double prepass_steps, int min_rows)
+static March choose_march(long columns, int h, int warm, long slots, int slots_per_cu, double prepass_cost, double prepass_steps, int min_rows,
+                          bool has_company = false)
 {
     const long forced_segs = option(OPT_FB_SEGS), forced_mode = option(OPT_FB_CHAIN);
     const long cus = std::max(1l, slots / slots_per_cu);
@@ -3312,6 +3313,10 @@ static March choose_march(long columns, int h, int warm, long slots, int slots_p
         best_segs = std::min<long>(forced_segs, h);
         rounds_cost(best_segs, &best_cost);
     }
+    // A handle with a lane (tf_fb_create_lane) has the other lane's batch for company: what a whole-column march leaves idle
+    // is not lost, while a pre-pass's second making of M is work the chip does not get back -- the pre-pass must win by more
+    // (measured at 4K x 8, two lanes: 1444 frames/s with whole columns, 1124 with the pre-pass the lone-launch model picks)
+    static const double company = tune("TF_PC_COMPANY_PCT", 70) / 100.0;
     March m;
     double whole;
     rounds_cost(1, &whole);
@@ -3321,7 +3326,7 @@ static March choose_march(long columns, int h, int warm, long slots, int slots_p
     } else if (forced_mode == 1 || (forced_mode < 0 && columns >= slots)) {
         m.mode = 1;
         m.segs = (int)best_segs;
-    } else if (forced_mode == 0 || forced_segs > 0 || best_cost * (1.0 + prepass_cost) + prepass_steps < whole) {
+    } else if (forced_mode == 0 || forced_segs > 0 || best_cost * (1.0 + prepass_cost) + prepass_steps < whole * (has_company ? company : 1.0)) {
         m.mode = 0;
         m.segs = (int)best_segs;
     } else {
@@ -3476,7 +3481,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     // rounds of 768, each as long as a segment plus its 2M+1 warm-up steps and the drain step (choose_march)
     static const long slots = tune("TF_PC_SLOTS", 768);
     static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 80) / 100.0; // k_flow_carry_pc: 0.76 of the march it serves (4K x 32, level 2)
-    const March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN); // (steps of ~0.9 us)
+    const March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN, fb->lane_of || fb->lanes); // (steps of ~0.9 us)
     FlowInit f;
     memset(&f, 0, sizeof(f));
     if (up)

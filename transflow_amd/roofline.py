@@ -158,6 +158,17 @@ def built_kernel_bytes(name, width, height, levels, pairs, iterations=3, fused=-
     return total
 
 
+def built_flow_iter_level_bytes(width, height, levels, pairs, iterations=3, fused=-1) -> dict:
+    """built_kernel_bytes("fb_flow_iter") level by level: {level: bytes of its `iterations` launches} (fused levels only)."""
+    n, _ = _levels(width, height, levels)
+    out = {}
+    for k in range(len(n)):
+        nc = n[k + 1] if k + 1 < len(n) else 0
+        if level_is_fused(n[k], pairs, fused):
+            out[k] = pairs * (48 * n[k] + (8 * nc if nc else 0) + (iterations - 1) * 56 * n[k])
+    return out
+
+
 BUILT_FB_KERNELS = ("fb_flow_iter", "fb_update_matrices", "fb_blur_solve", "fb_level_polyexp", "fb_level_rowpass",
                     "fb_level_colpass", "fb_polyexp")
 
