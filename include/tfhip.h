@@ -176,6 +176,15 @@ int tf_fb_keep_expansions(tf_fb *fb, int on);
 int tf_fb_frame_ptr(tf_fb *fb, int slot, void **dev);
 int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const int *next_slots);
 int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out);
+/* Streaming callers, one new frame and one flow per call (cv.py:460-490): with async io on, tf_fb_set_frame / _bgr put
+   the frame up on a copy stream of the library's (they still return with the frame in place, but do not wait for the
+   handle's kernels in flight), and tf_fb_get_flow_begin / _end bring the last call's flow down on another copy stream:
+   _begin queues the copy behind what the caller's stream holds at that moment (its post_process), *token names the
+   transfer; _end returns once flow_out is filled.  So frame t + 1 goes up and flow t - 1 comes down while pair t is being
+   computed.  flow_out should be page-locked (tf_host_alloc) and stay untouched between _begin and _end. */
+int tf_fb_async_io(tf_fb *fb, int on);
+int tf_fb_get_flow_begin(tf_fb *fb, int pair, float *flow_out, int *token);
+int tf_fb_get_flow_end(tf_fb *fb, int token);
 int tf_fb_flow_ptr(tf_fb *fb, int pair, void **dev);
 
 /* FlowSource.post_process (transflow/flow/sources/source.py:337-363) without the

@@ -904,6 +904,46 @@ def test_two_lanes_give_the_results_of_one(FB):
     two.close()
 
 
+def test_async_io_keeps_a_frame_going_up_and_a_flow_coming_down_beside_the_kernels(FB):
+    """tf_fb_async_io for a streaming caller (cv.py:460-490 per frame): frames go up on the library's upload stream, flows
+    come down on its download stream.  A two-deep pipeline -- issue pair t + 1 (new frame into the slot the older frame
+    held, expansions kept), THEN end pair t's download -- yields the flows of the plain sequence bit for bit, and the
+    arrays handed out stay intact."""
+    from transflow_amd.device import pinned_empty
+    h, w, n = 270, 480, 7
+    frames = clip_frames(h, w, n + 1, seed=1300)
+    plain = FB(w, h, frame_slots=2, max_pairs=2)
+    plain.keep_expansions(True)
+    plain.set_frame(0, frames[0])
+    want = []
+    for t in range(n):
+        plain.set_frame((t + 1) & 1, frames[t + 1])
+        plain.calc_slots([(t + 1) & 1], [t & 1])
+        want.append(plain.get_flow(0))
+    plain.close()
+    fb = FB(w, h, frame_slots=2, max_pairs=2)
+    fb.keep_expansions(True)
+    fb.async_io(True)
+    with pytest.raises(ValueError):
+        FB(w, h).get_flow_begin(0, np.empty((h, w, 2), np.float32))    # async io is off on that handle
+    fb.set_frame(0, frames[0])
+    outs = [pinned_empty((h, w, 2), np.float32) for _ in range(n)]
+    held = None
+    for t in range(n):
+        fb.set_frame((t + 1) & 1, frames[t + 1])
+        fb.calc_slots([(t + 1) & 1], [t & 1])
+        tok = fb.get_flow_begin(0, outs[t])
+        if held is not None:
+            fb.get_flow_end(held)
+        held = tok
+    fb.get_flow_end(held)
+    fb.get_flow_end(held)                                              # nothing pending: a no-op
+    for t in range(n):
+        np.testing.assert_array_equal(outs[t], want[t], err_msg=f"pair {t}")
+    fb.async_io(False)
+    fb.close()
+
+
 def test_bgr_frame_into_a_slot_matches_the_host_conversion_and_validates(FB):
     """tf_fb_set_frame_bgr (cv.py:461-466 on the device): a strided BGR view, a frame of another size (nearest resize),
     and its argument checks; the flow computed from slots filled that way equals the flow from the oracle's grey frames."""

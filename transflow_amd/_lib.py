@@ -82,6 +82,9 @@ PROTOTYPES = {
     "tf_host_free": (_I, [_P]),
     "tf_thread_stream": (_I, [_I]),
     "tf_fb_create_lane": (_I, [_PP, _P]),
+    "tf_fb_async_io": (_I, [_P, _I]),
+    "tf_fb_get_flow_begin": (_I, [_P, _I, _P, _PI]),
+    "tf_fb_get_flow_end": (_I, [_P, _I]),
     "tf_fb_destroy": (None, [_P]),
     "tf_fb_calc": (_I, [_P, _P, C.c_ssize_t, _P, C.c_ssize_t, _P]),
     "tf_fb_set_frame": (_I, [_P, _I, _P, C.c_ssize_t]),

@@ -2208,6 +2208,8 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket), per_seg = (unsigned)(cc.pairs * cc.strips);
         __syncthreads(); // every wave has read it
         by = t / per_seg;
+        if (by >= (unsigned)cc.segs)
+            return; // (a ticket outside this launch: the counter and the host's count of it have parted -- touch nothing)
         const unsigned rem = t - by * per_seg;
         pair = (int)(rem / (unsigned)cc.strips);
         bx = rem - (unsigned)pair * (unsigned)cc.strips;
@@ -2979,6 +2981,16 @@ struct tf_fb {
     DevBuf chain_words;          // word 0: the ticket counter (never reset); from word 16 on: the hand-off flags
     unsigned chain_epoch = 0, ticket_base = 0;
     unsigned *chain_fault = nullptr; // pinned, device-visible: a wait for a carry gave up (k_flow_iter_pc)
+    // tf_fb_async_io: uploads of frames and downloads of results on copy streams of their own, so that a streaming
+    // caller's next frame goes up and its previous flow comes down while the current pair is being computed
+    bool async_io = false;
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    hipEvent_t call_done[2] = {nullptr, nullptr};      // end of a call's kernels, by the call's number mod 2
+    hipEvent_t result_ready[2] = {nullptr, nullptr};   // the library stream's position when a download of result set s was asked for
+    hipEvent_t download_done[2] = {nullptr, nullptr};  // ... and its end
+    bool download_pending[2] = {false, false};
+    std::vector<long> slot_read_call;                  // the last call that read each slot's frame bytes (expanded it)
+    long n_calls = 0;
     tf_fb *lane_of = nullptr;    // tf_fb_create_lane: the handle whose frame slots these are
     int lanes = 0;               // ... and how many lanes read this handle's
     bool use_initial() const { return (prm.flags & 4) != 0; }
@@ -3009,6 +3021,10 @@ struct tf_fb {
             (void)hipHostFree(pairs_host);
         if (chain_fault)
             (void)hipHostFree(chain_fault);
+        for (int i = 0; i < 2; i++)
+            for (hipEvent_t e : {call_done[i], result_ready[i], download_done[i]})
+                if (e)
+                    (void)hipEventDestroy(e);
         for (auto e : entry)
             if (e)
                 (void)hipEventDestroy(e);
@@ -3507,7 +3523,6 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
         cc.ticket = fb->chain_words.as<unsigned>();
         cc.ticket_base = fb->ticket_base;
         cc.fault = fb->chain_fault;
-        fb->ticket_base += (unsigned)items;
         grid = dim3((unsigned)items);
     } else if (mc.segs > 1) {
         TF_TRY(fb_carry_room(fb, (size_t)mc.segs * n_pairs * 5 * w, 0));
@@ -3524,11 +3539,16 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     } else {
         cc.mode = 0;
     }
+    int rc;
     if (up)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
-    if (flow_in)
-        return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
-    return launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+        rc = launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+    else if (flow_in)
+        rc = launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+    else
+        rc = launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+    if (rc == TF_OK && cc.mode == 1)
+        fb->ticket_base += grid.x; // the tickets this launch's workgroups draw (only once it is really queued)
+    return rc;
 }
 
 // true if the fused iteration kernel exists for this window; launches it
@@ -3861,6 +3881,46 @@ TF_API int tf_fb_level_size(tf_fb *fb, int level, int *w, int *h)
     return TF_OK;
 }
 
+// tf_fb_async_io: a frame goes up on the upload stream, which first waits for the last call that read the slot's old
+// frame (a streaming caller's slot was read two calls ago: no wait in practice).  Without async io: nothing to do, the
+// upload is ordered on the caller's stream.
+static int fb_upload_scope_begin(tf_fb *fb, int slot)
+{
+    if (!fb->async_io)
+        return TF_OK;
+    const long last = fb->slot_read_call[(size_t)slot];
+    if (last >= 0 && fb->call_done[last & 1])
+        TF_HIP(hipStreamWaitEvent(fb->up_stream, fb->call_done[last & 1], 0)); // (that call's event, or a later call's of the same parity)
+    return TF_OK;
+}
+
+// Streaming callers (transflow/flow/sources/cv.py:460-490 per frame): with async io on, tf_fb_set_frame / _bgr put the
+// frame up on a copy stream of the library's (they still return with the frame in place, but no longer wait for the
+// handle's kernels in flight), and tf_fb_get_flow_begin / _end bring a result down on another, beside the next call.
+TF_API int tf_fb_async_io(tf_fb *fb, int on)
+{
+    TF_REQUIRE(fb, "tf_fb_async_io: null handle");
+    TF_TRY(ensure_init());
+    if (on && !fb->up_stream) {
+        TF_TRY(side_stream(3, &fb->up_stream));
+        TF_TRY(side_stream(4, &fb->down_stream));
+        for (int i = 0; i < 2; i++) {
+            TF_HIP(hipEventCreateWithFlags(&fb->call_done[i], hipEventDisableTiming));
+            TF_HIP(hipEventCreateWithFlags(&fb->result_ready[i], hipEventDisableTiming));
+            TF_HIP(hipEventCreateWithFlags(&fb->download_done[i], hipEventDisableTiming));
+        }
+        fb->slot_read_call.assign((size_t)fb->slots, -1);
+    }
+    if (!on)
+        for (int i = 0; i < 2; i++)
+            if (fb->download_pending[i]) {
+                TF_HIP(hipEventSynchronize(fb->download_done[i]));
+                fb->download_pending[i] = false;
+            }
+    fb->async_io = on != 0;
+    return TF_OK;
+}
+
 TF_API int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t stride)
 {
     TF_REQUIRE(fb && grey, "tf_fb_set_frame: null pointer");
@@ -3870,6 +3930,8 @@ TF_API int tf_fb_set_frame(tf_fb *fb, int slot, const uint8_t *grey, ptrdiff_t s
     uint8_t *dst = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
     if (fb->keep)
         fb->expanded[slot] = 0;
+    TF_TRY(fb_upload_scope_begin(fb, slot));
+    StreamScope up(fb->async_io ? fb->up_stream : stream());
     TF_HIP(hipMemcpy2DAsync(dst, fb->W, grey, (size_t)stride, fb->W, fb->H, hipMemcpyHostToDevice, stream()));
     TF_HIP(hipStreamSynchronize(stream())); // the host frame is borrowed for this call only
     return TF_OK;
@@ -3892,6 +3954,8 @@ TF_API int tf_fb_set_frame_bgr(tf_fb *fb, int slot, const uint8_t *bgr, int src_
     uint8_t *dst = fb->frames.as<uint8_t>() + (size_t)slot * fb->W * fb->H;
     if (fb->keep)
         fb->expanded[slot] = 0;
+    TF_TRY(fb_upload_scope_begin(fb, slot));
+    StreamScope up(fb->async_io ? fb->up_stream : stream());
     TF_HIP(hipMemcpy2DAsync(fb->bgr_stage.p, row, bgr, (size_t)stride, row, src_height, hipMemcpyHostToDevice, stream()));
     TF_TRY(tf_frame_grey_dev(fb->bgr_stage.p, src_width, src_height, dst, fb->W, fb->H));
     TF_HIP(hipStreamSynchronize(stream())); // the host frame is borrowed for this call only
@@ -4013,6 +4077,13 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
     }
     // Frames: tf_fb_set_frame returns with the frame in place; a caller writing frames on the device
     // orders that itself (tfhip.h).
+    if (fb->async_io) {
+        if (fb->download_pending[set]) // this call's result takes the place of the one still on its way down
+            TF_HIP(hipStreamWaitEvent(cs, fb->download_done[set], 0));
+        for (const Run &run : runs) // the slots whose frame bytes this call reads
+            for (int j = 0; j < run.n; j++)
+                fb->slot_read_call[(size_t)image_slot[run.list0 + j]] = fb->n_calls;
+    }
     TF_HIP(hipMemcpyAsync(fb->pairs.p, fb->pairs_host, (size_t)3 * P * sizeof(int2), hipMemcpyHostToDevice, cs));
     TF_HIP(hipEventRecord(fb->pairs_copied, cs));
     fb->pairs_pending = true;
@@ -4132,6 +4203,9 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         TF_HIP(hipEventRecord(fb->chain_done, cs));
         TF_HIP(hipStreamWaitEvent(main_stream(), fb->chain_done, 0));
     }
+    if (fb->async_io)
+        TF_HIP(hipEventRecord(fb->call_done[fb->n_calls & 1], cs));
+    fb->n_calls++;
     fb->cur = (set + 1) % fb->nsets;
     fb->last_pairs = n_pairs;
     return TF_OK;
@@ -4155,6 +4229,39 @@ TF_API int tf_fb_get_flow(tf_fb *fb, int pair, float *flow_out)
     TF_HIP(hipMemcpyAsync(flow_out, src, (size_t)fb->W * fb->H * 8, hipMemcpyDeviceToHost, stream()));
     TF_HIP(hipStreamSynchronize(stream()));
     return fb_check_fault(fb, "tf_fb_get_flow");
+}
+
+// The flow of `pair` on its way to `flow_out` beside whatever is queued next: the copy starts when the caller's stream
+// reaches this point (after its post_process), on the library's download stream; *token names the transfer for
+// tf_fb_get_flow_end, which returns once the array is filled.  flow_out should be page-locked (tf_host_alloc).
+TF_API int tf_fb_get_flow_begin(tf_fb *fb, int pair, float *flow_out, int *token)
+{
+    TF_REQUIRE(fb && flow_out && token, "tf_fb_get_flow_begin: null pointer");
+    TF_REQUIRE(fb->async_io, "tf_fb_get_flow_begin: tf_fb_async_io is off");
+    TF_REQUIRE(pair >= 0 && pair < fb->last_pairs, "tf_fb_get_flow_begin: pair %d was not computed by the last call", pair);
+    TF_TRY(ensure_init());
+    const int set = (fb->cur + fb->nsets - 1) % fb->nsets; // the last call's result set
+    TF_REQUIRE(!fb->download_pending[set], "tf_fb_get_flow_begin: the previous download of this result set has not been ended");
+    void *src;
+    TF_TRY(tf_fb_flow_ptr(fb, pair, &src));
+    TF_HIP(hipEventRecord(fb->result_ready[set], stream()));
+    TF_HIP(hipStreamWaitEvent(fb->down_stream, fb->result_ready[set], 0));
+    TF_HIP(hipMemcpyAsync(flow_out, src, (size_t)fb->W * fb->H * 8, hipMemcpyDeviceToHost, fb->down_stream));
+    TF_HIP(hipEventRecord(fb->download_done[set], fb->down_stream));
+    fb->download_pending[set] = true;
+    *token = set;
+    return TF_OK;
+}
+
+TF_API int tf_fb_get_flow_end(tf_fb *fb, int token)
+{
+    TF_REQUIRE(fb, "tf_fb_get_flow_end: null handle");
+    TF_REQUIRE(token == 0 || token == 1, "tf_fb_get_flow_end: token %d", token);
+    if (fb->download_pending[token]) {
+        TF_HIP(hipEventSynchronize(fb->download_done[token]));
+        fb->download_pending[token] = false;
+    }
+    return fb_check_fault(fb, "tf_fb_get_flow_end");
 }
 
 TF_API int tf_fb_set_initial_flow(tf_fb *fb, int pair, const float *flow)

@@ -58,15 +58,15 @@ hipStream_t stream() { return g_override ? g_override : main_stream(); }
 // Side streams are the library's, not a handle's: HIP multiplexes streams onto a few hardware queues
 // (four by default), and streams that share a queue serialise -- with per-handle side streams a second
 // handle in the process cost the first its overlap (measured: -17 % at 1080p with an idle 4K handle).
-static hipStream_t g_side[3] = {nullptr, nullptr, nullptr};
+static hipStream_t g_side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 int side_stream(int which, hipStream_t *out)
 {
-    TF_REQUIRE(which >= 0 && which <= 2, "side_stream: bad index");
+    TF_REQUIRE(which >= 0 && which <= 4, "side_stream: bad index");
     TF_TRY(ensure_init());
     if (!g_side[which]) {
         int least = 0, greatest = 0;
         TF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        TF_HIP(hipStreamCreateWithPriority(&g_side[which], hipStreamNonBlocking, which == 0 ? least : greatest));
+        TF_HIP(hipStreamCreateWithPriority(&g_side[which], hipStreamNonBlocking, (which == 0 || which >= 3) ? least : greatest));
     }
     *out = g_side[which];
     return TF_OK;

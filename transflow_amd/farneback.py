@@ -158,6 +158,23 @@ class Farneback:
         check(self._lib.tf_fb_get_flow(self._last, int(pair), _ptr(out)))
         return out
 
+    def async_io(self, on: bool = True) -> None:
+        """Frames go up and flows come down on copy streams of the library's (tf_fb_async_io): for a caller that streams
+        one frame per call and reads each flow back."""
+        check(self._lib.tf_fb_async_io(self._h, int(bool(on))))
+
+    def get_flow_begin(self, pair: int, out: np.ndarray) -> int:
+        """Start the download of the last call's flow into `out` (page-locked, C-contiguous float32 (H, W, 2)) beside
+        whatever is queued next; returns the token for get_flow_end.  `out` must not be touched in between."""
+        if out.dtype != np.float32 or not out.flags.c_contiguous or out.shape != (self.height, self.width, 2):
+            raise ValueError("get_flow_begin needs a C-contiguous float32 array of shape (H, W, 2)")
+        tok = C.c_int()
+        check(self._lib.tf_fb_get_flow_begin(self._last, int(pair), _ptr(out), C.byref(tok)))
+        return tok.value
+
+    def get_flow_end(self, token: int) -> None:
+        check(self._lib.tf_fb_get_flow_end(self._last, int(token)))
+
     def flow_ptr(self, pair: int = 0) -> int:
         p = C.c_void_p()
         check(self._lib.tf_fb_flow_ptr(self._last, int(pair), C.byref(p)))

@@ -487,14 +487,34 @@ class _Prefetch:
         from . import _lib
         try:
             _lib.check(_lib.load().tf_thread_stream(1))
+            # Flow t's download (started by post_process) runs beside frame t + 1's upload and kernels: the worker issues
+            # t + 1 first and only then waits for t's transfer and hands the array over.
+            held = None                              # (flow, token of its download) not yet handed over
+
+            def hand_over():
+                nonlocal held
+                if held is None:
+                    return True
+                flow, token = held
+                held = None
+                if token is not None:
+                    self.source._fb.get_flow_end(token)
+                return self._put(("flow", flow))
             while not self.halt.is_set():
                 try:
+                    self.source._download_token = None
                     flow = FlowSource.__next__(self.source)
                 except StopIteration:
-                    self._put(("stop", None))
+                    if hand_over():
+                        self._put(("stop", None))
                     return
-                if not self._put(("flow", flow)):
+                except BaseException:
+                    hand_over()                      # the flows before the failure still reach the consumer, in order
+                    raise
+                token = self.source._download_token
+                if not hand_over():
                     return
+                held = (flow, token)
         except BaseException as err:            # noqa: BLE001 -- re-raised in the consumer's thread
             self._put(("error", err))
 
@@ -561,6 +581,7 @@ class HipFlowSource(FlowSource):
         self._mask_dev = None
         self._flow_pool = None
         self._prefetch = None
+        self._download_token = None
         FlowSource.__init__(self, *args, **kwargs)
 
     def validate(self):
@@ -579,6 +600,8 @@ class HipFlowSource(FlowSource):
             _lib.set_option("fb_exact_sums", 1 if getattr(self.config, "hip_exact_sums", False) else 0)
             self._fb = Farneback(self.width, self.height, device=self.device, **self.config.fb_kwargs())
             self._fb.keep_expansions(True)  # the frame that was "next" stays expanded for its turn as "prev"
+            if getattr(self.config, "hip_prefetch", 0):
+                self._fb.async_io(True)     # the next frame up and the previous flow down beside this pair's kernels
             self._pp = self._fb  # one handle serves both calls
         return self._fb
 
@@ -687,7 +710,12 @@ class HipFlowSource(FlowSource):
                     np.ascontiguousarray(self.mask, dtype=np.float32).reshape(self.height, self.width))
             mask_dev = self._mask_dev.ptr
         fb.post_process_ex(0, self.direction.value, ops, mask_dev)
-        fb.get_flow_into(0, raw)
+        if self._prefetch is not None:
+            # the worker thread: the flow starts its way down and the worker goes on to the next frame; it hands this
+            # array to the consumer only once the transfer has ended (_Prefetch._run)
+            self._download_token = fb.get_flow_begin(0, raw)
+        else:
+            fb.get_flow_into(0, raw)
         return raw
 
     def next(self):
@@ -712,6 +740,8 @@ class HipFlowSource(FlowSource):
         if self._prefetch is not None:
             self._prefetch.stop()
             self._prefetch = None
+            if self._fb is not None:
+                self._fb.async_io(False)    # waits for a download the worker left on its way
         if self._mask_dev is not None:
             self._mask_dev.close()
             self._mask_dev = None
