@@ -4,7 +4,9 @@ shapes, window widths, level counts, iteration counts, polynomial radii and batc
   * the one-kernel iteration (option fb_fused = 1) with its columns cut into 1 / 3 row segments, the segments' column sums
     handed down inside the launch (fb_chain = 1) or computed by a pre-pass (fb_chain = 0),
   * the two-kernel iteration (fb_fused = 0) whole and in 3 segments (pre-pass),
-  * the exact mode (fb_exact_sums = 1: the window summed in OpenCV's own order, along the rows too),
+  * the exact mode (fb_exact_sums = 1: the window summed in OpenCV's own order, along the rows too) three ways: the
+    two-kernel iteration with its column / row walkers, and the one-kernel iteration with the rows' sums handed from strip
+    to strip, whole columns and 3 segments,
 and the oracle.  Since round 4 every form keeps FarnebackUpdateFlow_Blur's column sums (one running sum per column from row
 0, float-differenced), so what is left between a default form and the oracle is the association of double additions
 (~1e-16 in a sum).  What must hold:
@@ -37,6 +39,9 @@ FORMS = [("one-kernel whole", dict(fb_fused=1, fb_segs=1, fb_chain=-1)),
          ("two-kernel whole", dict(fb_fused=0, fb_segs=1, fb_chain=-1)),
          ("two-kernel 3 segments", dict(fb_fused=0, fb_segs=3, fb_chain=-1)),
          ("default choice", dict(fb_fused=-1, fb_segs=0, fb_chain=-1))]
+EXACT_FORMS = [("two kernels + column / row walkers", dict(fb_fused=0)),
+               ("one kernel, whole columns", dict(fb_fused=1, fb_segs=1)),
+               ("one kernel, 3 segments", dict(fb_fused=1, fb_segs=3, fb_chain=1))]
 DEFAULTS = dict(fb_fused=-1, fb_segs=0, fb_chain=-1, fb_exact_sums=0)
 
 
@@ -65,18 +70,20 @@ for case in range(n_cases):
         continue
     frames = [synth_pair(h, w, seed=h * 1000 + w, shift=(0.7 * i, -0.4 * i))[1] for i in range(n + 1)]
     got = {name: run(opts, w, h, n, frames, kw) for name, opts in FORMS}
-    exact = run(dict(fb_exact_sums=1), w, h, n, frames, kw)
+    exact = {name: run(dict(opts, fb_exact_sums=1), w, h, n, frames, kw) for name, opts in EXACT_FORMS}
     for i in range(n):
         ref = O.calc(frames[i + 1], frames[i], **kw)
         scale = max(1.0, float(np.abs(ref).max()))
         pairs += 1
-        same = bool(np.array_equal(exact[i], ref))
+        same = True
+        for name, _ in EXACT_FORMS:
+            if not np.array_equal(exact[name][i], ref):
+                same = False
+                bad += 1
+                de = np.abs(exact[name][i] - ref).max(axis=2)
+                print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: exact mode ({name}) differs from the oracle in "
+                      f"{int((de > 0).sum())} pixels, max|d| {de.max():.3g}")
         exact_identical += same
-        if not same:
-            bad += 1
-            de = np.abs(exact[i] - ref).max(axis=2)
-            print(f"FAIL case {case}: {h}x{w} {kw} pair {i} of {n}: exact mode differs from the oracle in {int((de > 0).sum())} "
-                  f"pixels, max|d| {de.max():.3g}")
         for name, _ in FORMS:
             d = np.abs(got[name][i] - ref).max(axis=2)
             n_out = int((d > 1e-4 * scale).sum())
@@ -98,7 +105,7 @@ for case in range(n_cases):
                 print(f"FAIL case {case} {h}x{w} {kw} pair {i}: {name} is {db:.2f} tolerances from the one-kernel form")
 for k, v in DEFAULTS.items():
     _lib.set_option(k, v)
-print(f"{n_cases} cases, {pairs} pairs: exact mode bit-identical to the oracle in {exact_identical}")
+print(f"{n_cases} cases, {pairs} pairs: exact mode (three forms) bit-identical to the oracle in {exact_identical}")
 for name, _ in FORMS:
     t = st[name]
     print(f"  {name:52s}: bit-identical to the oracle in {t['identical']} pairs ({t['px_differ']} pixels differ in all), "

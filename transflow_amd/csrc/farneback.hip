@@ -1993,6 +1993,11 @@ struct ColumnCarry {
     unsigned *ticket;     // mode 1: one counter per handle, never reset: this launch owns tickets ticket_base .. ticket_base + workgroups - 1
     unsigned ticket_base;
     unsigned *fault;      // host-visible word (pinned): set if a wait for a carry gave up
+    // k_flow_iter_pc<.., EXACT = true> (option fb_exact_sums; mode 1 only): the ROW sums in OpenCV's order too -- one running
+    // sum per row from column 0 -- handed from strip to strip, row by row: the consumer of strip b stores the sum after
+    // its last column of row y as two 8-byte granules {epoch, 32 bits} per channel at hsum[(((pair * strips + b) * Hk + y)
+    // * 5 + c) * 2 ..]; the consumer of strip b + 1 (a later ticket of the same segment) reads them until the tags match.
+    unsigned long long *hsum;
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -2178,7 +2183,7 @@ struct RowProducer {
 #define TF_PC_CONS 2 // consumer waves per workgroup: they take turns by row (1: 1701, 2: 1723 frames/s at 4K x 32)
 #endif
 #define TF_PC_THREADS (128 + 64 * TF_PC_CONS)
-template <int M, int FLOW>
+template <int M, int FLOW, bool EXACT>
 __global__ void __launch_bounds__(TF_PC_THREADS)
 k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
                int Hk, double scale, int seg, FlowInit fi, const int *__restrict__ rows_ofs, const float *__restrict__ rows_frac,
@@ -2192,7 +2197,8 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     constexpr int OUTC = 128 - 2 * HALO, WIN = 2 * M + 1;
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
-    __shared__ double s_p[TF_PC_CONS][5][64]; // each consumer's pair sums
+    constexpr int CONS = TF_PC_CONS;
+    __shared__ double s_p[CONS][5][64]; // each consumer's pair sums (EXACT: half a strip of row sums)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
     int pair;
@@ -2328,9 +2334,146 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const double eps = 1e-3 / (scale * scale);
         constexpr int kk = (M + 1) / 2;
         const int lo = max(lane - kk, 0), hi = min(lane + kk, 63);
+        if (EXACT) {
+            // fb_exact_sums: FarnebackUpdateFlow_Blur's ROW sums as well.  OpenCV slides one running sum per row from column
+            // 0: g = vsum[0] * (m + 2) + vsum[1 .. m-1], then for every x: g += vsum[x + m] - vsum[x - m - 1] (a double
+            // difference, then a double addition), and solves from g * scale with an IEEE division.  Here: every lane forms
+            // its two columns' differences out of s_v before the step's barrier; after it, half a strip at a time, the
+            // differences go to LDS, lane c (< 5) runs channel c's chain over them IN ORDER -- starting from the sum the
+            // strip to the left handed over for this row (strip 0: the priming) -- and leaves the sums in their place,
+            // every lane solves its two pixels from them, and lane c hands the last sum on to the strip on the right.
+            // Same operations, same operands, same order as the CPU path: with the column sums already OpenCV's and M
+            // computed without contraction, the flow is bit-identical.
+            // The hand-over is ten 8-byte granules per row, {epoch, 32 bits of a sum} each (two per channel): the data is the
+            // flag, so the receiver needs ONE round trip -- which it starts at the end of its previous turn, two rows early --
+            // and the sender no drain of its stores (cdna_hip_programming.md, guideline 16, R2).
+            constexpr int HALF = OUTC / 2; // columns per half: their sums fit the consumer's 5 x 64 doubles of s_p
+            static_assert(HALF <= 64 && first_out * 2 == HALO, "half a strip's sums per consumer (read eight at a time: up to 64)");
+            const int x0 = (int)bx * OUTC, ncols = min(OUTC, Wk - x0); // this strip's output columns
+            const size_t row_base = ((size_t)pair * cc.strips + bx) * Hk;
+            gu64 *hand = (gu64 *)cc.hsum;
+            const int ch = lane < 5 ? lane : 0; // the channel whose chain this lane runs (lanes 0 .. 4)
+            auto ask = [&](int row, unsigned long long &lo, unsigned long long &hi) { // the left strip's sum of `row` (may not be there yet)
+                const gu64 *g = hand + ((row_base - Hk + row) * 5 + ch) * 2;
+                lo = __hip_atomic_load(g, TF_RLX_AGENT);
+                hi = __hip_atomic_load(g + 1, TF_RLX_AGENT);
+            };
+            unsigned long long in_lo = 0, in_hi = 0;
+            int asked = -1; // the row in_lo / in_hi were asked for
+            // Every wave meets every step's barrier, so what a consumer does between two barriers is what a step waits
+            // for: a row's work (~700 instructions of one wave: two serial chains of 56 additions, four IEEE divisions per
+            // lane) is spread over the consumer's two steps -- the first half of the strip after the barrier of the step
+            // that read the row, the second half (and the hand-over) after the next.
+            static_assert(CONS == 2, "a consumer's turn is two steps: one half of the strip each");
+            double d0[5], d1[5], g = 0.0;
+            int turn_y = -1; // the row of the turn in progress
+            auto do_half = [&](int half, int y) {
+                const int lane0 = first_out + half * (HALF / 2), j = 2 * (lane - lane0); // this lane's place in the half
+                const bool in_half = lane >= lane0 && lane < lane0 + HALF / 2;
+                if (in_half) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        sp[c][j] = d0[c];
+                        sp[c][j + 1] = d1[c];
+                    }
+                }
+                lds_wave_sync();
+                if (lane < 5) {
+                    // all of the half's differences are read together, then added one after the other (g's additions are
+                    // the serial part: a read per addition, or per eight, puts LDS round trips between them)
+                    const int n = min(HALF, ncols - half * HALF);
+                    double v[64];
+#pragma unroll
+                    for (int q = 0; q < 64; q++)
+                        v[q] = q < HALF ? sp[lane][q] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 64; q++) {
+                        if (q < HALF) {
+                            if (q < n)
+                                g += v[q];
+                            v[q] = g;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 64; q++)
+                        if (q < HALF)
+                            sp[lane][q] = v[q];
+                }
+                if (half == 1 && (int)bx + 1 < cc.strips && lane < 5) { // the row's sum goes on before this half is solved
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(g), tag = (unsigned long long)cc.epoch << 32;
+                    gu64 *o = hand + ((row_base + y) * 5 + lane) * 2;
+                    __hip_atomic_store(o, tag | (bits & 0xffffffffull), TF_RLX_AGENT);
+                    __hip_atomic_store(o + 1, tag | (bits >> 32), TF_RLX_AGENT);
+                }
+                lds_wave_sync();
+                if (in_half && c0 < Wk) {
+                    float2 f[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const double g11 = sp[0][j + q] * scale, g12 = sp[1][j + q] * scale, g22 = sp[2][j + q] * scale,
+                                     h1 = sp[3][j + q] * scale, h2 = sp[4][j + q] * scale;
+                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                        f[q] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                    }
+                    float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
+                    o[0] = f[0];
+                    if (c0 + 1 < Wk)
+                        o[1] = f[1];
+                }
+                lds_wave_sync();
+            };
+            for (int s = 0; s <= nsteps; s++) { // (one trip more than there are barriers: the last turn's second half)
+                const int y = r0 + (s - 1) - WIN;
+                const bool mine = s < nsteps && (s % CONS) == who && y >= r0; // wave-uniform: a turn starts
+                if (mine) {
+                    const double(*sv)[128] = s_v[(s - 1) & 1];
+                    if (lane >= first_out && lane <= last_out) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) {
+                            d0[c] = sv[c][2 * lane + M] - sv[c][2 * lane - M - 1];
+                            d1[c] = sv[c][2 * lane + 1 + M] - sv[c][2 * lane - M];
+                        }
+                    }
+                    if (lane < 5 && bx == 0) { // the priming: column 0 (m + 2) times, then columns 1 .. m - 1
+                        g = sv[lane][HALO] * (double)(M + 2);
+                        for (int x = 1; x < M; x++)
+                            g += sv[lane][HALO + x];
+                    }
+                }
+                if (s < nsteps)
+                    lds_barrier();
+                if (mine) {
+                    turn_y = y;
+                    if (bx > 0) { // the row's running sum as the strip on the left left it
+                        if (asked != y)
+                            ask(y, in_lo, in_hi);
+                        const unsigned long long t0 = wall_clock64();
+                        while (!__all(lane >= 5 || ((unsigned)(in_lo >> 32) == cc.epoch && (unsigned)(in_hi >> 32) == cc.epoch))) {
+                            __builtin_amdgcn_s_sleep(4);
+                            ask(y, in_lo, in_hi);
+                            if (wall_clock64() - t0 > 500000000ull) { // ~5 s: give up (the host turns the fault word into an error)
+                                __hip_atomic_store(cc.fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                break;
+                            }
+                        }
+                        g = __longlong_as_double((long long)((in_hi << 32) | (in_lo & 0xffffffffull)));
+                    }
+                    do_half(0, y);
+                } else if (turn_y >= 0) { // the step after: the second half of the turn's row
+                    do_half(1, turn_y);
+                    // this consumer's next row: ask for it now, the answer has a step to arrive
+                    if (bx > 0 && turn_y + CONS < r1) {
+                        ask(turn_y + CONS, in_lo, in_hi);
+                        asked = turn_y + CONS;
+                    }
+                    turn_y = -1;
+                }
+            }
+            return;
+        }
         for (int s = 0; s < nsteps; s++) {
             const int y = r0 + (s - 1) - WIN; // the row whose window the producers completed in step s - 1
-            const bool mine = (s % TF_PC_CONS) == who && y >= r0; // wave-uniform
+            const bool mine = (s % CONS) == who && y >= r0; // wave-uniform
             double p[5], left[5], right[5];
             if (mine) {
                 const double(*sv)[128] = s_v[(s - 1) & 1];
@@ -2979,6 +3122,7 @@ struct tf_fb {
     // OpenCV's column sums across row segments (ColumnCarry)
     DevBuf col_carry;            // the chain's value in front of every segment of the launch being issued
     DevBuf chain_words;          // word 0: the ticket counter (never reset); from word 16 on: the hand-off flags
+    DevBuf row_sums;             // fb_exact_sums in the one-kernel iteration: the rows' running sums from strip to strip (ColumnCarry::hsum)
     unsigned chain_epoch = 0, ticket_base = 0;
     unsigned *chain_fault = nullptr; // pinned, device-visible: a wait for a carry gave up (k_flow_iter_pc)
     // tf_fb_async_io: uploads of frames and downloads of results on copy streams of their own, so that a streaming
@@ -3497,7 +3641,15 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     // rounds of 768, each as long as a segment plus its 2M+1 warm-up steps and the drain step (choose_march)
     static const long slots = tune("TF_PC_SLOTS", 768);
     static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 80) / 100.0; // k_flow_carry_pc: 0.76 of the march it serves (4K x 32, level 2)
-    const March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN, fb->lane_of || fb->lanes); // (steps of ~0.9 us)
+    March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN, fb->lane_of || fb->lanes); // (steps of ~0.9 us)
+    // fb_exact_sums: the rows' sums travel from strip to strip inside the launch, so the workgroups need their tickets
+    // (a strip's left neighbour must be resident before it), and the column sums must be the chain itself, not a pre-pass's
+    const bool exact = option(OPT_FB_EXACT_SUMS) != 0;
+    if (exact && mc.mode == 0) {
+        mc.mode = 1;
+        mc.segs = 1;
+        mc.seg = h;
+    }
     FlowInit f;
     memset(&f, 0, sizeof(f));
     if (up)
@@ -3510,19 +3662,31 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     cc.pairs = n_pairs;
     cc.strips = (int)strips;
     dim3 grid(strips, mc.segs, n_pairs);
-    if (mc.segs > 1 && mc.mode == 1) {
+    if ((mc.segs > 1 && mc.mode == 1) || exact) {
         const size_t items = (size_t)mc.segs * n_pairs * strips;
         TF_TRY(fb_carry_room(fb, items * 5 * 128, items * 2));
+        if (exact) {
+            const size_t rows = (size_t)n_pairs * strips * h;
+            if (fb->row_sums.bytes < rows * 80) { // ten granules per row
+                if (fb->row_sums.alloc(rows * 80) != TF_OK)
+                    return set_error(TF_ERR_HIP, "fb_exact_sums: no room for the row sums' hand-off (%zu rows of %d strips)", rows, (int)strips);
+                TF_HIP(hipMemsetAsync(fb->row_sums.p, 0, fb->row_sums.bytes, stream()));
+            }
+        }
         if (++fb->chain_epoch == 0) { // 2^32 chained launches later: the flags start over
             TF_HIP(hipMemsetAsync(fb->chain_words.as<unsigned>() + 16, 0, fb->chain_words.bytes - 64, stream()));
+            if (fb->row_sums.p)
+                TF_HIP(hipMemsetAsync(fb->row_sums.p, 0, fb->row_sums.bytes, stream()));
             fb->chain_epoch = 1;
         }
+        cc.mode = 1;
         cc.carry = fb->col_carry.as<double>();
         cc.flags = fb->chain_words.as<unsigned>() + 16;
         cc.epoch = fb->chain_epoch;
         cc.ticket = fb->chain_words.as<unsigned>();
         cc.ticket_base = fb->ticket_base;
         cc.fault = fb->chain_fault;
+        cc.hsum = fb->row_sums.as<unsigned long long>();
         grid = dim3((unsigned)items);
     } else if (mc.segs > 1) {
         TF_TRY(fb_carry_room(fb, (size_t)mc.segs * n_pairs * 5 * w, 0));
@@ -3540,12 +3704,16 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
         cc.mode = 0;
     }
     int rc;
-    if (up)
-        rc = launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 2>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
-    else if (flow_in)
-        rc = launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 1>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+    const int kind = up ? 2 : (flow_in ? 1 : 0);
+    const char *name = lvl_name(exact ? "fb_flow_iter_exact" : "fb_flow_iter", k);
+#define TF_PC_LAUNCH(FLOWK, EX)                                                                                                \
+    launch(name, k_flow_iter_pc<M, FLOWK, EX>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, \
+           f.yfrac, cc)
+    if (exact)
+        rc = kind == 2 ? TF_PC_LAUNCH(2, true) : (kind == 1 ? TF_PC_LAUNCH(1, true) : TF_PC_LAUNCH(0, true));
     else
-        rc = launch(lvl_name("fb_flow_iter", k), k_flow_iter_pc<M, 0>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, f.yfrac, cc);
+        rc = kind == 2 ? TF_PC_LAUNCH(2, false) : (kind == 1 ? TF_PC_LAUNCH(1, false) : TF_PC_LAUNCH(0, false));
+#undef TF_PC_LAUNCH
     if (rc == TF_OK && cc.mode == 1)
         fb->ticket_base += grid.x; // the tickets this launch's workgroups draw (only once it is really queued)
     return rc;
@@ -4145,7 +4313,11 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
-        const bool fused_here = fusable && !fb->gaussian() && !option(OPT_FB_EXACT_SUMS) && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
+        // fb_exact_sums: the one-kernel form hands the rows' sums from strip to strip, a serial wavefront across the level --
+        // worth it where many columns of workgroups stand side by side (4K x 32, level 0: 11.0 ms per launch against 16.3 as
+        // update-matrices + column walker + row walker; one 4K pair: 5.7 against ~3), the walkers otherwise
+        const bool exact_one_kernel = !option(OPT_FB_EXACT_SUMS) || fb->fused > 0 || (long)cdiv(L.W, 112) * n_pairs >= 400;
+        const bool fused_here = fusable && !fb->gaussian() && exact_one_kernel && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;
