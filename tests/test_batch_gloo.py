@@ -286,6 +286,49 @@ def test_host_group_ignores_a_stranger_and_parses_nothing_it_sends(tmp_path):
     g1.close()
 
 
+def test_host_group_takes_a_rank_that_comes_again_and_carries_plain_data_only(tmp_path):
+    """A rank whose first connection failed on ITS side after rank 0 had accepted it (a timeout, a reset) retries with the
+    right token: its new connection takes the old one's place instead of being turned away until both give up.  Messages:
+    dict keys must be strings (JSON would silently turn others into strings), an array is not a scalar."""
+    import struct
+    import threading
+    import time
+    import numpy as np
+    from transflow_amd.batch import HostGroup, _encode
+    path = str(tmp_path / "rdzv")
+    box = {}
+    t = threading.Thread(target=lambda: box.setdefault("g", HostGroup(0, 3, path=path, timeout=60)))
+    t.start()
+    deadline = time.monotonic() + 30
+    while not os.path.exists(path) and time.monotonic() < deadline:
+        time.sleep(0.01)
+    where, hello, answer = open(path).read().split()
+    host, port = where.rsplit(":", 1)
+    first = socket.create_connection((host, int(port)))                # rank 1's first attempt: accepted ...
+    first.sendall(hello.encode() + struct.pack("<i", 1))
+    assert first.recv(len(answer)).decode() == answer
+    first.close()                                                      # ... then lost on rank 1's side
+    g1 = HostGroup(1, 3, path=path, timeout=60)                        # it comes again
+    g2 = HostGroup(2, 3, path=path, timeout=60)
+    t.join(60)
+    g0 = box["g"]
+    res = {}
+    th = [threading.Thread(target=lambda g=g, k=k: res.setdefault(k, g.allgather(k))) for g, k in ((g0, "a"), (g2, "c"))]
+    for x in th:
+        x.start()
+    assert g1.allgather("b") == ["a", "b", "c"]
+    for x in th:
+        x.join(30)
+    assert res["a"] == res["c"] == ["a", "b", "c"]
+    for g in (g0, g1, g2):
+        g.close()
+    with pytest.raises(TypeError):
+        _encode({1: "x"})
+    with pytest.raises(TypeError):
+        _encode(np.arange(3))
+    assert _encode({"k": np.float32(1.5), "t": (1, 2)}) == {"k": 1.5, "t": [1, 2]}
+
+
 def test_host_group_survives_a_stale_rendezvous_file(tmp_path):
     """A launch that died leaves its file behind; the next one with the same key must not trip over the dead port in it."""
     import threading

@@ -134,12 +134,15 @@ def _encode(obj):
     if isinstance(obj, (bytes, bytearray)):
         return {"__bytes__": bytes(obj).hex()}
     if isinstance(obj, dict):
-        return {str(k): _encode(v) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
+        for k in obj:
+            if not isinstance(k, str):        # JSON would turn the key into a string and the receiver would see another dict
+                raise TypeError(f"HostGroup carries dicts with string keys only, not {type(k).__name__} keys")
+        return {k: _encode(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):        # (a tuple arrives as a list)
         return [_encode(v) for v in obj]
     if obj is None or isinstance(obj, (bool, int, float, str)):
         return obj
-    if hasattr(obj, "item"):                  # numpy scalars
+    if getattr(obj, "ndim", None) == 0 and hasattr(obj, "item"):   # numpy scalars (an array of any size is not one)
         return _encode(obj.item())
     raise TypeError(f"HostGroup cannot carry a {type(obj).__name__}")
 
@@ -222,19 +225,24 @@ class HostGroup:
                     raise TimeoutError("rendezvous: not every rank arrived")
                 conn, _ = srv.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(10.0)
+                conn.settimeout(1.0)            # a local peer sends its 36 bytes at once; a silent one holds the loop a second
                 try:
                     head = _recv_exact(conn, len(hello) + 4)
                     token, peer = head[:len(hello)].decode("ascii", "replace"), struct.unpack("<i", head[len(hello):])[0]
-                    if not secrets.compare_digest(token, hello) or not (0 < peer < self.world) or self.peers[peer] is not None:
+                    if not secrets.compare_digest(token, hello) or not (0 < peer < self.world):
                         raise ConnectionError("bad token or rank")
                     conn.sendall(answer.encode())
                 except (OSError, ConnectionError, struct.error):
                     conn.close()                # a stranger on the port: dropped, nothing of it was parsed
                     continue
                 conn.settimeout(timeout)
+                if self.peers[peer] is not None:
+                    # the rank knows the token and comes again: its first attempt failed on its side (a timeout, a reset)
+                    # after we had accepted it -- the new connection takes the old one's place
+                    self.peers[peer].close()
+                else:
+                    joined += 1
                 self.peers[peer] = conn
-                joined += 1
             srv.close()
             try:
                 os.unlink(self.path)            # everyone is in: the file has done its job
