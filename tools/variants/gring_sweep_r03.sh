@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 3: drives the TF_PC_GRING variant of k_flow_iter_pc_r03.hip.txt; kept with it for the record, not runnable against the current kernel)
 # usage (GPU box): sweep workgroups per CU (via dynamic LDS padding) and the launcher's slot count for the global-ring build
 run() { echo "--- $*"; env "$@" bash tools/variant_bench.sh 4k 32 gring | grep -E "ms/step in|flow_iter.k0|flow_iter.k1"; }
 echo "=== base"; bash tools/variant_bench.sh 4k 32 base | grep -E "ms/step in|flow_iter.k0|flow_iter.k1"
