@@ -2381,23 +2381,36 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
                 if (lane < 5) {
                     // all of the half's differences are read together, then added one after the other (g's additions are
                     // the serial part: a read per addition, or per eight, puts LDS round trips between them)
+                    // (a quarter of the strip at a time: its differences are read together -- 56 registers --, the sums form
+                    // in place, one dependent addition per column, and go back together; reading the whole half at once
+                    // cost the kernel its occupancy: 256 VGPRs)
                     const int n = min(HALF, ncols - half * HALF);
-                    double v[64];
+                    constexpr int Q = HALF / 2;
+                    static_assert(HALF % 2 == 0, "two quarters per half");
 #pragma unroll
-                    for (int q = 0; q < 64; q++)
-                        v[q] = q < HALF ? sp[lane][q] : 0.0;
+                    for (int part = 0; part < 2; part++) {
+                        double v[Q];
 #pragma unroll
-                    for (int q = 0; q < 64; q++) {
-                        if (q < HALF) {
-                            if (q < n)
-                                g += v[q];
-                            v[q] = g;
+                        for (int q = 0; q < Q; q++)
+                            v[q] = sp[lane][part * Q + q];
+                        if (n >= (part + 1) * Q) { // (every strip but the level's last)
+                            v[0] = g + v[0];
+#pragma unroll
+                            for (int q = 1; q < Q; q++)
+                                v[q] = v[q - 1] + v[q];
+                            g = v[Q - 1];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < Q; q++) {
+                                if (part * Q + q < n)
+                                    g += v[q];
+                                v[q] = g;
+                            }
                         }
-                    }
 #pragma unroll
-                    for (int q = 0; q < 64; q++)
-                        if (q < HALF)
-                            sp[lane][q] = v[q];
+                        for (int q = 0; q < Q; q++)
+                            sp[lane][part * Q + q] = v[q];
+                    }
                 }
                 if (half == 1 && (int)bx + 1 < cc.strips && lane < 5) { // the row's sum goes on before this half is solved
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(g), tag = (unsigned long long)cc.epoch << 32;
