@@ -944,42 +944,40 @@ def test_async_io_keeps_a_frame_going_up_and_a_flow_coming_down_beside_the_kerne
     fb.close()
 
 
-def test_exact_sums_in_the_one_kernel_iteration_rows_handed_from_strip_to_strip(FB, lib_option):
-    """fb_exact_sums in k_flow_iter_pc: the column sums are OpenCV's chain (handed down the segments), the ROW sums are
-    OpenCV's chain too -- handed from strip to strip, row by row, inside the launch -- and the solve is the CPU path's.
-    Bit-identical to the oracle with whole columns and with segments, for several strips across (widths past 112 and
-    224 columns, a last strip of one column), every window of the one-kernel form, a batch, and twice (replay)."""
+def test_exact_sums_with_the_column_sums_straight_from_the_expansions(FB, lib_option):
+    """fb_exact_sums where the iteration never stores M (fb_fused = 1: k_flow_carry_pc<.., STORE> marches every column once
+    and stores OpenCV's chain at every row, k_exact_hsolve runs the rows): bit-identical to the oracle for widths that are
+    not whole waves or whole 64-column chunks (113, 225, 339), heights that are not whole groups of three rows (97, 64),
+    every window of the one-kernel form, the three sources of the flow (zero, the previous iteration, the coarser
+    level), a batch, and twice (replay)."""
     lib_option("fb_exact_sums", 1)
     lib_option("fb_fused", 1)
     for (h, w, kw, P) in [(120, 113, dict(levels=1), 1), (97, 339, dict(levels=2, winsize=11), 2), (64, 225, dict(levels=0, winsize=7, iterations=2), 3),
                           (270, 480, dict(levels=2), 2)]:
         frames = clip_frames(h, w, P + 1, seed=1400 + w)
         refs = [O.calc(frames[i], frames[i + 1], **kw) for i in range(P)]
-        for segs in (1, 3):
-            lib_option("fb_segs", segs)
-            lib_option("fb_chain", 1)
-            fb = FB(w, h, frame_slots=P + 1, max_pairs=P, **kw)
-            for i, f in enumerate(frames):
-                fb.set_frame(i, f)
-            for rep in range(2):
-                fb.calc_slots(list(range(P)), list(range(1, P + 1)))
-                for i in range(P):
-                    np.testing.assert_array_equal(fb.get_flow(i), refs[i], err_msg=f"{h}x{w} {kw} fb_segs={segs} pair {i} run {rep}")
-            fb.close()
+        fb = FB(w, h, frame_slots=P + 1, max_pairs=P, **kw)
+        for i, f in enumerate(frames):
+            fb.set_frame(i, f)
+        for rep in range(2):
+            fb.calc_slots(list(range(P)), list(range(1, P + 1)))
+            for i in range(P):
+                np.testing.assert_array_equal(fb.get_flow(i), refs[i], err_msg=f"{h}x{w} {kw} pair {i} run {rep}")
+        fb.close()
 
 
-def test_exact_sums_at_a_size_where_the_one_kernel_form_is_the_default(FB, lib_option):
-    """1080p x 24 pairs: 432 columns of workgroups at level 0, above the threshold where fb_exact_sums takes the one-kernel
-    form by itself (rows handed across 18 strips, columns down 2+ segments, ~900 workgroups for 768 slots): a sample of
-    the pairs bit-identical to the oracle."""
+def test_exact_sums_at_a_size_where_that_form_is_the_default(FB, lib_option):
+    """1080p x 32 pairs: 576 columns of workgroups at level 0, above the threshold where fb_exact_sums takes its column sums
+    straight from the expansions by itself; level 1 goes through M in memory: a sample of the pairs bit-identical to the
+    oracle."""
     lib_option("fb_exact_sums", 1)
-    h, w, P = 1080, 1920, 24
+    h, w, P = 1080, 1920, 32
     frames = clip_frames(h, w, P + 1, seed=1500)
     fb = FB(w, h, levels=1, frame_slots=P + 1, max_pairs=P)
     for i, f in enumerate(frames):
         fb.set_frame(i, f)
     fb.calc_slots(list(range(P)), list(range(1, P + 1)))
-    for i in (0, 11, 23):
+    for i in (0, 13, 31):
         np.testing.assert_array_equal(fb.get_flow(i), O.calc(frames[i], frames[i + 1], levels=1), err_msg=f"pair {i}")
     fb.close()
 

@@ -39,9 +39,8 @@ FORMS = [("one-kernel whole", dict(fb_fused=1, fb_segs=1, fb_chain=-1)),
          ("two-kernel whole", dict(fb_fused=0, fb_segs=1, fb_chain=-1)),
          ("two-kernel 3 segments", dict(fb_fused=0, fb_segs=3, fb_chain=-1)),
          ("default choice", dict(fb_fused=-1, fb_segs=0, fb_chain=-1))]
-EXACT_FORMS = [("two kernels + column / row walkers", dict(fb_fused=0)),
-               ("one kernel, whole columns", dict(fb_fused=1, fb_segs=1)),
-               ("one kernel, 3 segments", dict(fb_fused=1, fb_segs=3, fb_chain=1))]
+EXACT_FORMS = [("M in memory + column / row walkers", dict(fb_fused=0)),
+               ("column sums straight from the expansions + row walker", dict(fb_fused=1))]
 DEFAULTS = dict(fb_fused=-1, fb_segs=0, fb_chain=-1, fb_exact_sums=0)
 
 

@@ -1609,9 +1609,18 @@ __global__ void k_w1_solve(const double *__restrict__ V, float2 *__restrict__ fl
 // what decides FarnebackUpdateMatrices' discontinuous in-frame test for the rare border pixel whose sample
 // point sits within that distance of the last row / column.  These two kernels repeat
 // OpenCV's order exactly -- the same operations on the same operands, so the flow is bit-identical to the
-// CPU path's -- at the price of its serial dependences: one thread per column walks all rows, then one
-// thread per row walks all columns.  A checking mode, ~5x slower than the default.
-// vsum layout: [pair][channel][x][y] (y fastest): both kernels then read coalesced.
+// CPU path's -- at the price of its serial dependences.  (On a launch with many columns side by side the column sums come
+// from k_flow_carry_pc<.., STORE> instead, straight from the expansions: launch_flow_iter.)
+//   k_exact_vsum: one thread per column and channel walks all rows (coalesced across the wave: lanes are columns) and
+//          stores every row's sums, vsum[pair][channel][y][x].
+//   k_exact_hsolve: one WAVE takes ROWS rows and walks them together from column 0, 64 columns at a time: every lane
+//          forms its column's double differences vsum[x + m] - vsum[x - m - 1] (coalesced loads, the next 64 columns'
+//          loads in flight meanwhile) into LDS, lane r * 5 + c then runs the sum of row r, channel c over them IN ORDER
+//          (its running sum stays in a register from chunk to chunk) and leaves the sums in their place, and every
+//          lane solves its column's pixels of the ROWS rows (IEEE division, as the CPU path).  The serial part is 64
+//          dependent additions per 64 x ROWS pixels; the rows of LDS are 65 doubles apart (conflict-free both ways).
+// (Until round 4 the second kernel ran one THREAD per row -- 64 rows' lines per load -- over sums stored transposed, which
+// the first kernel then wrote 8 bytes per line: 1.3 + 2.5 ms per iteration of one 4K pair.)
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_exact_vsum(const float *__restrict__ Min, double *__restrict__ vsum, int Wk, int Hk, int m)
@@ -1621,7 +1630,7 @@ k_exact_vsum(const float *__restrict__ Min, double *__restrict__ vsum, int Wk, i
         return;
     const size_t Nk = (size_t)Wk * Hk;
     const float *P = Min + ((size_t)pair * 5 + c) * Nk + x;
-    double *V = vsum + ((size_t)pair * 5 + c) * Nk + (size_t)x * Hk;
+    double *V = vsum + ((size_t)pair * 5 + c) * Nk + x;
     double vs = (double)(P[0] * (float)(m + 2)); // vsum[x] = srow0[x] * (m + 2): a float product
     for (int y = 1; y < m; y++)
         vs += (double)P[(size_t)min(y, Hk - 1) * Wk];
@@ -1629,36 +1638,92 @@ k_exact_vsum(const float *__restrict__ Min, double *__restrict__ vsum, int Wk, i
     for (int y = 0; y < Hk; y++) {
         const float in = P[(size_t)min(y + m, Hk - 1) * Wk], out = P[(size_t)max(y - m - 1, 0) * Wk];
         vs += (double)(in - out); // vsum[x] += srow1[x] - srow0[x]
-        V[y] = vs;
+        V[(size_t)y * Wk] = vs;
     }
 }
 
+template <int ROWS>
 __global__ void __launch_bounds__(64)
 k_exact_hsolve(const double *__restrict__ vsum, float2 *__restrict__ flow_out, int Wk, int Hk, int m, double scale)
 {
-    const int y = blockIdx.x * 64 + threadIdx.x, pair = blockIdx.z;
-    if (y >= Hk)
-        return;
+    constexpr int NCH = ROWS * 5, LDW = 65, GRP = 16;
+    static_assert(NCH <= 64, "one chain per lane");
+    __shared__ double D[NCH][LDW];
+    const int lane = threadIdx.x, pair = blockIdx.z, y0 = blockIdx.x * ROWS;
     const size_t Nk = (size_t)Wk * Hk;
-    const double *V = vsum + (size_t)pair * 5 * Nk + y; // column x of channel c: V[c * Nk + x * Hk]
-    float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk;
-    double g[5];
+    const double *V = vsum + (size_t)pair * 5 * Nk + (size_t)y0 * Wk;
+    float2 *out = flow_out + (size_t)pair * Nk + (size_t)y0 * Wk;
+    const int nrows = min(ROWS, Hk - y0);
+    const int kr = lane / 5, kc = lane - kr * 5; // the chain this lane runs: row kr, channel kc
+    const bool chain = lane < nrows * 5;
+    double g = 0.0;
+    if (chain) { // the priming: column 0 (m + 2) times, then columns 1 .. m - 1
+        const double *row = V + (size_t)kc * Nk + (size_t)kr * Wk;
+        g = row[0] * (double)(m + 2);
+        for (int x = 1; x < m; x++)
+            g += row[min(x, Wk - 1)];
+    }
+    // the differences of the chunk at x0, one column per lane (rows past the level's last: row 0 of the tile again, unused)
+    double d[NCH];
+    auto fetch = [&](int x0) {
+        const int xa = min(x0 + lane + m, Wk - 1), xb = min(max(x0 + lane - m - 1, 0), Wk - 1);
 #pragma unroll
-    for (int c = 0; c < 5; c++)
-        g[c] = V[c * Nk] * (double)(m + 2); // the border columns are copies of column 0 / W - 1
-    for (int x = 1; x < m; x++)
+        for (int r = 0; r < ROWS; r++) {
+            const double *row = V + (size_t)(r < nrows ? r : 0) * Wk;
 #pragma unroll
-        for (int c = 0; c < 5; c++)
-            g[c] += V[c * Nk + (size_t)min(x, Wk - 1) * Hk];
-#pragma unroll 2 // (4: the ten loads of a step times four need more registers than pay: 3.8 against 2.5 ms at 4K x 8)
-    for (int x = 0; x < Wk; x++) {
-        const size_t a = (size_t)min(x + m, Wk - 1) * Hk, b = (size_t)max(x - m - 1, 0) * Hk;
+            for (int c = 0; c < 5; c++)
+                d[r * 5 + c] = row[(size_t)c * Nk + xa] - row[(size_t)c * Nk + xb];
+        }
+    };
+    fetch(0);
+    for (int x0 = 0; x0 < Wk; x0 += 64) {
 #pragma unroll
-        for (int c = 0; c < 5; c++)
-            g[c] += V[c * Nk + a] - V[c * Nk + b];
-        const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale, h1 = g[3] * scale, h2 = g[4] * scale;
-        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-        o[x] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+        for (int k = 0; k < NCH; k++)
+            D[k][lane] = d[k];
+        if (x0 + 64 < Wk)
+            fetch(x0 + 64); // in flight while this chunk is summed and solved
+        lds_wave_sync();
+        if (chain) {
+            const int n = min(64, Wk - x0);
+#pragma unroll
+            for (int j0 = 0; j0 < 64; j0 += GRP) {
+                double v[GRP];
+#pragma unroll
+                for (int q = 0; q < GRP; q++)
+                    v[q] = D[lane][j0 + q];
+                if (j0 + GRP <= n) {
+                    v[0] = g + v[0];
+#pragma unroll
+                    for (int q = 1; q < GRP; q++)
+                        v[q] = v[q - 1] + v[q];
+                    g = v[GRP - 1];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < GRP; q++) {
+                        if (j0 + q < n)
+                            g += v[q];
+                        v[q] = g;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < GRP; q++)
+                    D[lane][j0 + q] = v[q];
+            }
+        }
+        lds_wave_sync();
+        if (x0 + lane < Wk) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                if (r < nrows) {
+                    const double g11 = D[r * 5 + 0][lane] * scale, g12 = D[r * 5 + 1][lane] * scale, g22 = D[r * 5 + 2][lane] * scale,
+                                 h1 = D[r * 5 + 3][lane] * scale, h2 = D[r * 5 + 4][lane] * scale;
+                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    out[(size_t)r * Wk + x0 + lane] =
+                        make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                }
+            }
+        }
+        lds_wave_sync();
     }
 }
 
@@ -1993,11 +2058,6 @@ struct ColumnCarry {
     unsigned *ticket;     // mode 1: one counter per handle, never reset: this launch owns tickets ticket_base .. ticket_base + workgroups - 1
     unsigned ticket_base;
     unsigned *fault;      // host-visible word (pinned): set if a wait for a carry gave up
-    // k_flow_iter_pc<.., EXACT = true> (option fb_exact_sums; mode 1 only): the ROW sums in OpenCV's order too -- one running
-    // sum per row from column 0 -- handed from strip to strip, row by row: the consumer of strip b stores the sum after
-    // its last column of row y as two 8-byte granules {epoch, 32 bits} per channel at hsum[(((pair * strips + b) * Hk + y)
-    // * 5 + c) * 2 ..]; the consumer of strip b + 1 (a later ticket of the same segment) reads them until the tags match.
-    unsigned long long *hsum;
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -2183,7 +2243,7 @@ struct RowProducer {
 #define TF_PC_CONS 2 // consumer waves per workgroup: they take turns by row (1: 1701, 2: 1723 frames/s at 4K x 32)
 #endif
 #define TF_PC_THREADS (128 + 64 * TF_PC_CONS)
-template <int M, int FLOW, bool EXACT>
+template <int M, int FLOW>
 __global__ void __launch_bounds__(TF_PC_THREADS)
 k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, float2 *__restrict__ flow_out, int Wk,
                int Hk, double scale, int seg, FlowInit fi, const int *__restrict__ rows_ofs, const float *__restrict__ rows_frac,
@@ -2198,7 +2258,7 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     __shared__ float ring[WIN][5][128];   // the window's rows of M, one column per producer lane
     __shared__ double s_v[2][5][128];     // vertical window sums of the row just produced (double-buffered by step parity)
     constexpr int CONS = TF_PC_CONS;
-    __shared__ double s_p[CONS][5][64]; // each consumer's pair sums (EXACT: half a strip of row sums)
+    __shared__ double s_p[CONS][5][64]; // each consumer's pair sums
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned bx, by;
     int pair;
@@ -2334,156 +2394,6 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
         const double eps = 1e-3 / (scale * scale);
         constexpr int kk = (M + 1) / 2;
         const int lo = max(lane - kk, 0), hi = min(lane + kk, 63);
-        if (EXACT) {
-            // fb_exact_sums: FarnebackUpdateFlow_Blur's ROW sums as well.  OpenCV slides one running sum per row from column
-            // 0: g = vsum[0] * (m + 2) + vsum[1 .. m-1], then for every x: g += vsum[x + m] - vsum[x - m - 1] (a double
-            // difference, then a double addition), and solves from g * scale with an IEEE division.  Here: every lane forms
-            // its two columns' differences out of s_v before the step's barrier; after it, half a strip at a time, the
-            // differences go to LDS, lane c (< 5) runs channel c's chain over them IN ORDER -- starting from the sum the
-            // strip to the left handed over for this row (strip 0: the priming) -- and leaves the sums in their place,
-            // every lane solves its two pixels from them, and lane c hands the last sum on to the strip on the right.
-            // Same operations, same operands, same order as the CPU path: with the column sums already OpenCV's and M
-            // computed without contraction, the flow is bit-identical.
-            // The hand-over is ten 8-byte granules per row, {epoch, 32 bits of a sum} each (two per channel): the data is the
-            // flag, so the receiver needs ONE round trip -- which it starts at the end of its previous turn, two rows early --
-            // and the sender no drain of its stores (cdna_hip_programming.md, guideline 16, R2).
-            constexpr int HALF = OUTC / 2; // columns per half: their sums fit the consumer's 5 x 64 doubles of s_p
-            static_assert(HALF <= 64 && first_out * 2 == HALO, "half a strip's sums per consumer (read eight at a time: up to 64)");
-            const int x0 = (int)bx * OUTC, ncols = min(OUTC, Wk - x0); // this strip's output columns
-            const size_t row_base = ((size_t)pair * cc.strips + bx) * Hk;
-            gu64 *hand = (gu64 *)cc.hsum;
-            const int ch = lane < 5 ? lane : 0; // the channel whose chain this lane runs (lanes 0 .. 4)
-            auto ask = [&](int row, unsigned long long &lo, unsigned long long &hi) { // the left strip's sum of `row` (may not be there yet)
-                const gu64 *g = hand + ((row_base - Hk + row) * 5 + ch) * 2;
-                lo = __hip_atomic_load(g, TF_RLX_AGENT);
-                hi = __hip_atomic_load(g + 1, TF_RLX_AGENT);
-            };
-            unsigned long long in_lo = 0, in_hi = 0;
-            int asked = -1; // the row in_lo / in_hi were asked for
-            // Every wave meets every step's barrier, so what a consumer does between two barriers is what a step waits
-            // for: a row's work (~700 instructions of one wave: two serial chains of 56 additions, four IEEE divisions per
-            // lane) is spread over the consumer's two steps -- the first half of the strip after the barrier of the step
-            // that read the row, the second half (and the hand-over) after the next.
-            static_assert(CONS == 2, "a consumer's turn is two steps: one half of the strip each");
-            double d0[5], d1[5], g = 0.0;
-            int turn_y = -1; // the row of the turn in progress
-            auto do_half = [&](int half, int y) {
-                const int lane0 = first_out + half * (HALF / 2), j = 2 * (lane - lane0); // this lane's place in the half
-                const bool in_half = lane >= lane0 && lane < lane0 + HALF / 2;
-                if (in_half) {
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        sp[c][j] = d0[c];
-                        sp[c][j + 1] = d1[c];
-                    }
-                }
-                lds_wave_sync();
-                if (lane < 5) {
-                    // all of the half's differences are read together, then added one after the other (g's additions are
-                    // the serial part: a read per addition, or per eight, puts LDS round trips between them)
-                    // (a quarter of the strip at a time: its differences are read together -- 56 registers --, the sums form
-                    // in place, one dependent addition per column, and go back together; reading the whole half at once
-                    // cost the kernel its occupancy: 256 VGPRs)
-                    const int n = min(HALF, ncols - half * HALF);
-                    constexpr int Q = HALF / 2;
-                    static_assert(HALF % 2 == 0, "two quarters per half");
-#pragma unroll
-                    for (int part = 0; part < 2; part++) {
-                        double v[Q];
-#pragma unroll
-                        for (int q = 0; q < Q; q++)
-                            v[q] = sp[lane][part * Q + q];
-                        if (n >= (part + 1) * Q) { // (every strip but the level's last)
-                            v[0] = g + v[0];
-#pragma unroll
-                            for (int q = 1; q < Q; q++)
-                                v[q] = v[q - 1] + v[q];
-                            g = v[Q - 1];
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < Q; q++) {
-                                if (part * Q + q < n)
-                                    g += v[q];
-                                v[q] = g;
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < Q; q++)
-                            sp[lane][part * Q + q] = v[q];
-                    }
-                }
-                if (half == 1 && (int)bx + 1 < cc.strips && lane < 5) { // the row's sum goes on before this half is solved
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(g), tag = (unsigned long long)cc.epoch << 32;
-                    gu64 *o = hand + ((row_base + y) * 5 + lane) * 2;
-                    __hip_atomic_store(o, tag | (bits & 0xffffffffull), TF_RLX_AGENT);
-                    __hip_atomic_store(o + 1, tag | (bits >> 32), TF_RLX_AGENT);
-                }
-                lds_wave_sync();
-                if (in_half && c0 < Wk) {
-                    float2 f[2];
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const double g11 = sp[0][j + q] * scale, g12 = sp[1][j + q] * scale, g22 = sp[2][j + q] * scale,
-                                     h1 = sp[3][j + q] * scale, h2 = sp[4][j + q] * scale;
-                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                        f[q] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
-                    }
-                    float2 *o = flow_out + (size_t)pair * Nk + (size_t)y * Wk + c0;
-                    o[0] = f[0];
-                    if (c0 + 1 < Wk)
-                        o[1] = f[1];
-                }
-                lds_wave_sync();
-            };
-            for (int s = 0; s <= nsteps; s++) { // (one trip more than there are barriers: the last turn's second half)
-                const int y = r0 + (s - 1) - WIN;
-                const bool mine = s < nsteps && (s % CONS) == who && y >= r0; // wave-uniform: a turn starts
-                if (mine) {
-                    const double(*sv)[128] = s_v[(s - 1) & 1];
-                    if (lane >= first_out && lane <= last_out) {
-#pragma unroll
-                        for (int c = 0; c < 5; c++) {
-                            d0[c] = sv[c][2 * lane + M] - sv[c][2 * lane - M - 1];
-                            d1[c] = sv[c][2 * lane + 1 + M] - sv[c][2 * lane - M];
-                        }
-                    }
-                    if (lane < 5 && bx == 0) { // the priming: column 0 (m + 2) times, then columns 1 .. m - 1
-                        g = sv[lane][HALO] * (double)(M + 2);
-                        for (int x = 1; x < M; x++)
-                            g += sv[lane][HALO + x];
-                    }
-                }
-                if (s < nsteps)
-                    lds_barrier();
-                if (mine) {
-                    turn_y = y;
-                    if (bx > 0) { // the row's running sum as the strip on the left left it
-                        if (asked != y)
-                            ask(y, in_lo, in_hi);
-                        const unsigned long long t0 = wall_clock64();
-                        while (!__all(lane >= 5 || ((unsigned)(in_lo >> 32) == cc.epoch && (unsigned)(in_hi >> 32) == cc.epoch))) {
-                            __builtin_amdgcn_s_sleep(4);
-                            ask(y, in_lo, in_hi);
-                            if (wall_clock64() - t0 > 500000000ull) { // ~5 s: give up (the host turns the fault word into an error)
-                                __hip_atomic_store(cc.fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                break;
-                            }
-                        }
-                        g = __longlong_as_double((long long)((in_hi << 32) | (in_lo & 0xffffffffull)));
-                    }
-                    do_half(0, y);
-                } else if (turn_y >= 0) { // the step after: the second half of the turn's row
-                    do_half(1, turn_y);
-                    // this consumer's next row: ask for it now, the answer has a step to arrive
-                    if (bx > 0 && turn_y + CONS < r1) {
-                        ask(turn_y + CONS, in_lo, in_hi);
-                        asked = turn_y + CONS;
-                    }
-                    turn_y = -1;
-                }
-            }
-            return;
-        }
         for (int s = 0; s < nsteps; s++) {
             const int y = r0 + (s - 1) - WIN; // the row whose window the producers completed in step s - 1
             const bool mine = (s % CONS) == who && y >= r0; // wave-uniform
@@ -2566,7 +2476,10 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
 // after its last row (primed as OpenCV primes it), the others the sum of their rows' increments from zero; k_carry_scan
 // turns that into each segment's carry.  S: [segment][pair][channel][Wk].
 // ---------------------------------------------------------------------------------
-template <int M, int FLOW>
+// STORE (option fb_exact_sums on a large launch): one segment = the whole column, and what leaves is not the segment's
+// last value but the chain's value at EVERY row, V[pair][channel][y][x] -- k_exact_vsum's output without M ever being in
+// memory (k_exact_hsolve takes it from there).
+template <int M, int FLOW, bool STORE = false>
 __global__ void __launch_bounds__(128)
 k_flow_carry_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, int Wk, int Hk, int seg, FlowInit fi,
                 const int *__restrict__ rows_ofs, const float *__restrict__ rows_frac, double *__restrict__ S)
@@ -2602,6 +2515,7 @@ k_flow_carry_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in,
         }
         slot = slot + 1 == WIN ? 0 : slot + 1;
     }
+    double *V = S + (size_t)pair * 5 * Nk + (size_t)r0 * Wk + x; // (STORE)
     for (int s = WIN; s < n_rows; s++) {
         float m[5];
         P.template next<false>(e0 + s, m);
@@ -2610,10 +2524,13 @@ k_flow_carry_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in,
             const float old = ring[slot][c][col];
             ring[slot][c][col] = m[c];
             vs[c] += (double)(m[c] - old);
+            if (STORE && xr < Wk)
+                V[(size_t)c * Nk] = vs[c];
         }
+        V += Wk;
         slot = slot + 1 == WIN ? 0 : slot + 1;
     }
-    if (xr < Wk) {
+    if (!STORE && xr < Wk) {
         double *o = S + (((size_t)by * gridDim.z + pair) * 5) * Wk + xr;
 #pragma unroll
         for (int c = 0; c < 5; c++)
@@ -3131,11 +3048,10 @@ struct tf_fb {
     AreaTabs area{};
     DevBuf gauss_taps;           // winsize / 2 + 1 taps of the Gaussian window (flag 256)
     DevBuf bgr_stage;            // tf_fb_set_frame_bgr: the decoded frame on its way to a slot
-    DevBuf exact_vsum;           // option fb_exact_sums: OpenCV's column sums of the level being solved, [pair][5][x][y] doubles
+    DevBuf exact_vsum;           // option fb_exact_sums: OpenCV's column sums of the level being solved, [pair][5][y][x] doubles
     // OpenCV's column sums across row segments (ColumnCarry)
     DevBuf col_carry;            // the chain's value in front of every segment of the launch being issued
     DevBuf chain_words;          // word 0: the ticket counter (never reset); from word 16 on: the hand-off flags
-    DevBuf row_sums;             // fb_exact_sums in the one-kernel iteration: the rows' running sums from strip to strip (ColumnCarry::hsum)
     unsigned chain_epoch = 0, ticket_base = 0;
     unsigned *chain_fault = nullptr; // pinned, device-visible: a wait for a carry gave up (k_flow_iter_pc)
     // tf_fb_async_io: uploads of frames and downloads of results on copy streams of their own, so that a streaming
@@ -3585,6 +3501,24 @@ static int launch_blur_solve_wave(tf_fb *fb, int w, int h, int n_pairs, float2 *
                   flow_out, w, h, scale, mc.seg, carry);
 }
 
+// The row walker of option fb_exact_sums over fb->exact_vsum (k_exact_hsolve).
+static int fb_exact_hsolve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, int k)
+{
+    const int m = fb->prm.winsize / 2;
+    const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
+    // rows per wave (12 rows' differences in flight take all 512 registers of a lane: one wave per SIMD)
+    static const int rows_forced = (int)tune("TF_EXACT_ROWS", 0);
+    const int rows = rows_forced ? rows_forced : 3;
+    if (rows == 12)
+        return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve<12>, dim3(cdiv(h, 12), 1, n_pairs), dim3(64), 0,
+                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
+    if (rows == 6)
+        return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve<6>, dim3(cdiv(h, 6), 1, n_pairs), dim3(64), 0,
+                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
+    return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve<3>, dim3(cdiv(h, 3), 1, n_pairs), dim3(64), 0,
+                  (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
+}
+
 static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out, int k = -1)
 {
     const int m = fb->prm.winsize / 2;
@@ -3596,8 +3530,7 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
                                          "fewer pairs per call need less)", n_pairs, w, h, need);
         TF_TRY(launch(lvl_name("fb_exact_vsum", k), k_exact_vsum, dim3(cdiv(w, 64), 5, n_pairs), dim3(64), 0,
                       (const float *)fb->M.as<float>(), fb->exact_vsum.as<double>(), w, h, m));
-        return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve, dim3(cdiv(h, 64), 1, n_pairs), dim3(64), 0,
-                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
+        return fb_exact_hsolve(fb, w, h, n_pairs, flow_out, k);
     }
     switch (m) {
     case 2: return launch_blur_solve_wave<2>(fb, w, h, n_pairs, flow_out, scale, k);
@@ -3650,24 +3583,36 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     const float *R = fb->Rk(k);
     constexpr int OUTC = 128 - 2 * ((M + 1) & ~1), WIN = 2 * M + 1;
     const unsigned strips = cdiv(w, OUTC);
-    // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
-    // rounds of 768, each as long as a segment plus its 2M+1 warm-up steps and the drain step (choose_march)
-    static const long slots = tune("TF_PC_SLOTS", 768);
-    static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 80) / 100.0; // k_flow_carry_pc: 0.76 of the march it serves (4K x 32, level 2)
-    March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN, fb->lane_of || fb->lanes); // (steps of ~0.9 us)
-    // fb_exact_sums: the rows' sums travel from strip to strip inside the launch, so the workgroups need their tickets
-    // (a strip's left neighbour must be resident before it), and the column sums must be the chain itself, not a pre-pass's
-    const bool exact = option(OPT_FB_EXACT_SUMS) != 0;
-    if (exact && mc.mode == 0) {
-        mc.mode = 1;
-        mc.segs = 1;
-        mc.seg = h;
-    }
     FlowInit f;
     memset(&f, 0, sizeof(f));
     if (up)
         f = *up;
     f.rmap = fb->rmap_dev;
+    if (option(OPT_FB_EXACT_SUMS)) {
+        // fb_exact_sums on a large launch: the column sums of EVERY row straight from R0, R1 and the flow (the pre-pass
+        // kernel with one segment, storing as it goes: M is never in memory), then the row walker.  4K x 32, level 0: 4.3 +
+        // 2.7 ms against 3.3 + 3.1 + 2.8 through update-matrices (and 9.0 for an exact form of k_flow_iter_pc whose
+        // consumers handed the rows' sums from strip to strip, tried in round 4: profiles/NOTES.md)
+        const size_t need = (size_t)n_pairs * 5 * w * h * sizeof(double);
+        if (fb->exact_vsum.bytes < need && fb->exact_vsum.alloc(need) != TF_OK)
+            return set_error(TF_ERR_HIP, "fb_exact_sums: no room for the column sums of %d pairs of %d x %d pixels (%zu bytes of doubles; "
+                                         "fewer pairs per call need less)", n_pairs, w, h, need);
+        const dim3 pgrid(cdiv(w, 128), 1, n_pairs);
+        double *V = fb->exact_vsum.as<double>();
+        const char *name = lvl_name("fb_flow_vsum", k);
+        if (up)
+            TF_TRY(launch(name, k_flow_carry_pc<M, 2, true>, pgrid, dim3(128), 0, R, flow_in, w, h, h, f, f.yofs, f.yfrac, V));
+        else if (flow_in)
+            TF_TRY(launch(name, k_flow_carry_pc<M, 1, true>, pgrid, dim3(128), 0, R, flow_in, w, h, h, f, f.yofs, f.yfrac, V));
+        else
+            TF_TRY(launch(name, k_flow_carry_pc<M, 0, true>, pgrid, dim3(128), 0, R, flow_in, w, h, h, f, f.yofs, f.yfrac, V));
+        return fb_exact_hsolve(fb, w, h, n_pairs, flow_out, k);
+    }
+    // 3 workgroups per CU are resident (768 on the chip) and all take the same time: the launch runs in
+    // rounds of 768, each as long as a segment plus its 2M+1 warm-up steps and the drain step (choose_march)
+    static const long slots = tune("TF_PC_SLOTS", 768);
+    static const double prepass_cost = tune("TF_PC_PREPASS_PCT", 80) / 100.0; // k_flow_carry_pc: 0.76 of the march it serves (4K x 32, level 2)
+    March mc = choose_march((long)strips * n_pairs, h, WIN, slots, 3, prepass_cost, 14, 2 * WIN, fb->lane_of || fb->lanes); // (steps of ~0.9 us)
     ColumnCarry cc;
     memset(&cc, 0, sizeof(cc));
     cc.mode = mc.mode;
@@ -3675,21 +3620,11 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     cc.pairs = n_pairs;
     cc.strips = (int)strips;
     dim3 grid(strips, mc.segs, n_pairs);
-    if ((mc.segs > 1 && mc.mode == 1) || exact) {
+    if (mc.segs > 1 && mc.mode == 1) {
         const size_t items = (size_t)mc.segs * n_pairs * strips;
         TF_TRY(fb_carry_room(fb, items * 5 * 128, items * 2));
-        if (exact) {
-            const size_t rows = (size_t)n_pairs * strips * h;
-            if (fb->row_sums.bytes < rows * 80) { // ten granules per row
-                if (fb->row_sums.alloc(rows * 80) != TF_OK)
-                    return set_error(TF_ERR_HIP, "fb_exact_sums: no room for the row sums' hand-off (%zu rows of %d strips)", rows, (int)strips);
-                TF_HIP(hipMemsetAsync(fb->row_sums.p, 0, fb->row_sums.bytes, stream()));
-            }
-        }
         if (++fb->chain_epoch == 0) { // 2^32 chained launches later: the flags start over
             TF_HIP(hipMemsetAsync(fb->chain_words.as<unsigned>() + 16, 0, fb->chain_words.bytes - 64, stream()));
-            if (fb->row_sums.p)
-                TF_HIP(hipMemsetAsync(fb->row_sums.p, 0, fb->row_sums.bytes, stream()));
             fb->chain_epoch = 1;
         }
         cc.mode = 1;
@@ -3699,7 +3634,6 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
         cc.ticket = fb->chain_words.as<unsigned>();
         cc.ticket_base = fb->ticket_base;
         cc.fault = fb->chain_fault;
-        cc.hsum = fb->row_sums.as<unsigned long long>();
         grid = dim3((unsigned)items);
     } else if (mc.segs > 1) {
         TF_TRY(fb_carry_room(fb, (size_t)mc.segs * n_pairs * 5 * w, 0));
@@ -3718,14 +3652,11 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     }
     int rc;
     const int kind = up ? 2 : (flow_in ? 1 : 0);
-    const char *name = lvl_name(exact ? "fb_flow_iter_exact" : "fb_flow_iter", k);
-#define TF_PC_LAUNCH(FLOWK, EX)                                                                                                \
-    launch(name, k_flow_iter_pc<M, FLOWK, EX>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs, \
+    const char *name = lvl_name("fb_flow_iter", k);
+#define TF_PC_LAUNCH(FLOWK)                                                                                                    \
+    launch(name, k_flow_iter_pc<M, FLOWK>, grid, dim3(TF_PC_THREADS), 0, R, flow_in, flow_out, w, h, scale, mc.seg, f, f.yofs,   \
            f.yfrac, cc)
-    if (exact)
-        rc = kind == 2 ? TF_PC_LAUNCH(2, true) : (kind == 1 ? TF_PC_LAUNCH(1, true) : TF_PC_LAUNCH(0, true));
-    else
-        rc = kind == 2 ? TF_PC_LAUNCH(2, false) : (kind == 1 ? TF_PC_LAUNCH(1, false) : TF_PC_LAUNCH(0, false));
+    rc = kind == 2 ? TF_PC_LAUNCH(2) : (kind == 1 ? TF_PC_LAUNCH(1) : TF_PC_LAUNCH(0));
 #undef TF_PC_LAUNCH
     if (rc == TF_OK && cc.mode == 1)
         fb->ticket_base += grid.x; // the tickets this launch's workgroups draw (only once it is really queued)
@@ -4326,10 +4257,10 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         const int out_buf = overlap ? 3 + set : -1; // where the full-resolution result of this call lives
         const long fuse_min_px = option(OPT_FB_FUSE_MIN_PX);
         // (the fused kernel multiplies the edge weights unconditionally: identical from 10 x 10 up, border_scale)
-        // fb_exact_sums: the one-kernel form hands the rows' sums from strip to strip, a serial wavefront across the level --
-        // worth it where many columns of workgroups stand side by side (4K x 32, level 0: 11.0 ms per launch against 16.3 as
-        // update-matrices + column walker + row walker; one 4K pair: 5.7 against ~3), the walkers otherwise
-        const bool exact_one_kernel = !option(OPT_FB_EXACT_SUMS) || fb->fused > 0 || (long)cdiv(L.W, 112) * n_pairs >= 400;
+        // fb_exact_sums: column sums straight from R (k_flow_carry_pc<.., STORE>, one march per column) where many columns
+        // stand side by side, through M in memory otherwise (4K: 7.0 against 9.3 ms per level-0 iteration with 32 pairs,
+        // 2.9 against 2.5 with 8, 1.8 against 0.5 with one)
+        const bool exact_one_kernel = !option(OPT_FB_EXACT_SUMS) || fb->fused > 0 || (long)cdiv(L.W, 112) * n_pairs >= 560;
         const bool fused_here = fusable && !fb->gaussian() && exact_one_kernel && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
