@@ -104,7 +104,7 @@ for case in range(n_cases):
                 print(f"FAIL case {case} {h}x{w} {kw} pair {i}: {name} is {db:.2f} tolerances from the one-kernel form")
 for k, v in DEFAULTS.items():
     _lib.set_option(k, v)
-print(f"{n_cases} cases, {pairs} pairs: exact mode (three forms) bit-identical to the oracle in {exact_identical}")
+print(f"{n_cases} cases, {pairs} pairs: exact mode ({len(EXACT_FORMS)} forms) bit-identical to the oracle in {exact_identical}")
 for name, _ in FORMS:
     t = st[name]
     print(f"  {name:52s}: bit-identical to the oracle in {t['identical']} pairs ({t['px_differ']} pixels differ in all), "

@@ -40,10 +40,13 @@ fi
 if [ "$part" = c ]; then
   python3 tools/fuzz_fused.py ${FUZZ_CASES:-600} 11 > $out/r04_fuzz.txt 2>&1 || true
   tail -10 $out/r04_fuzz.txt
-  (python3 tools/bench_host_path.py 1080p 48 bgr; python3 tools/bench_host_path.py 1080p 48 bgr prefetch; python3 tools/bench_host_path.py 4k 24 bgr; python3 tools/bench_host_path.py 4k 24 bgr prefetch; python3 tools/bench_host_path.py 4k 12 bgr exact) > $out/r04_host_path.txt 2>&1
+  (python3 tools/bench_host_path.py 1080p 48 bgr; python3 tools/bench_host_path.py 1080p 48 bgr prefetch; python3 tools/bench_host_path.py 4k 24 bgr; python3 tools/bench_host_path.py 4k 24 bgr prefetch; python3 tools/bench_host_path.py 4k 24 bgr exact; python3 tools/bench_host_path.py 4k 24 bgr exact prefetch; python3 tools/bench_host_path.py 1080p 48 bgr exact prefetch) > $out/r04_host_path.txt 2>&1
   cat $out/r04_host_path.txt
   (python3 tools/lanes_bench.py 4k 32 12; python3 tools/lanes_bench.py 4k 8 24; python3 tools/lanes_bench.py 1080p 64 24) > $out/r04_lanes.txt 2>&1
   cat $out/r04_lanes.txt
   python3 tools/kprof.py 4k 32 fb_exact_sums=1 reps=2 > $out/r04_kprof_4k_batch32_exact.txt 2>&1
   head -5 $out/r04_kprof_4k_batch32_exact.txt
+  python3 tools/kprof.py 4k 1 fb_exact_sums=1 > $out/r04_kprof_4k_one_pair_exact.txt 2>&1
+  python3 tools/kprof.py 4k 1 > $out/r04_kprof_4k_one_pair.txt 2>&1
+  head -3 $out/r04_kprof_4k_one_pair_exact.txt $out/r04_kprof_4k_one_pair.txt
 fi
