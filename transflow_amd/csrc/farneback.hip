@@ -3506,15 +3506,8 @@ static int fb_exact_hsolve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_ou
 {
     const int m = fb->prm.winsize / 2;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
-    // rows per wave (12 rows' differences in flight take all 512 registers of a lane: one wave per SIMD)
-    static const int rows_forced = (int)tune("TF_EXACT_ROWS", 0);
-    const int rows = rows_forced ? rows_forced : 3;
-    if (rows == 12)
-        return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve<12>, dim3(cdiv(h, 12), 1, n_pairs), dim3(64), 0,
-                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
-    if (rows == 6)
-        return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve<6>, dim3(cdiv(h, 6), 1, n_pairs), dim3(64), 0,
-                      (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
+    // three rows per wave (6: the same at 32 pairs of 4K, 202 against 165 us for one pair; 12: 3.7 x slower -- their
+    // differences in flight take every register a lane has)
     return launch(lvl_name("fb_exact_hsolve", k), k_exact_hsolve<3>, dim3(cdiv(h, 3), 1, n_pairs), dim3(64), 0,
                   (const double *)fb->exact_vsum.as<double>(), flow_out, w, h, m, scale);
 }
