@@ -856,7 +856,7 @@ def main():
             # above the copy kernel's rate the byte model would be wrong: flagged in the line, never a lost line
             out["roofline"]["exceeds_copy_ceiling"] = bool(max(achieved, out["roofline"]["alone"]["achieved"]) > ceiling * 1.02)
             if world == 1:
-                # the checking mode's rate on the same workload (option fb_exact_sums: the window summed in OpenCV's own
+                # the bit-identical mode's rate on the same workload (option fb_exact_sums: the window summed in OpenCV's own
                 # order along the rows too; its flow was compared bit for bit with the oracle's in the gate)
                 from transflow_amd import _lib as L
                 saved = L.get_option("fb_exact_sums")

@@ -56,8 +56,8 @@ int tf_device_count(int *count);
      "fb_exact_sums"  0   1 = the box window (flags without OPTFLOW_FARNEBACK_GAUSSIAN) is summed exactly as
                           FarnebackUpdateFlow_Blur sums it -- one set of running sums per image, float-differenced
                           down the columns from row 0, double-differenced along the rows from column 0 -- so the
-                          flow is bit-identical to the CPU path's instead of within 1e-4 of it; a checking mode,
-                          about five times slower (read per call)
+                          flow is bit-identical to the CPU path's instead of within 1e-4 of it; about twice the
+                          default's time, plus 40 bytes per pixel and pair of device memory (read per call)
      "fb_chain"       -1  the marching kernels keep FarnebackUpdateFlow_Blur's column sums (one running sum per column
                           from row 0).  A column cut into row segments needs the sum's value at each cut: 1 = every
                           segment waits for the one above it inside the launch (the sums are then the CPU path's bit

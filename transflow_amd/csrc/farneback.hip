@@ -4101,7 +4101,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
                    "tf_fb_calc_slots: pair %d uses a slot outside [0,%d)", i, fb->slots);
     TF_TRY(fb_check_fault(fb, "tf_fb_calc_slots (an earlier call)"));
     if (!option(OPT_FB_EXACT_SUMS) && fb->exact_vsum.p && fb->prm.winsize / 2 != 0)
-        fb->exact_vsum.release(); // the checking mode's column sums (40 bytes per pixel and pair): not kept once it is off
+        fb->exact_vsum.release(); // the exact mode's column sums (40 bytes per pixel and pair): not kept once it is off
     if (fb->pairs_pending) { // the previous call's copy out of the staging buffer (long done in practice)
         TF_HIP(hipEventSynchronize(fb->pairs_copied));
         fb->pairs_pending = false;
