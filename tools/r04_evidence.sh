@@ -40,7 +40,7 @@ fi
 if [ "$part" = c ]; then
   python3 tools/fuzz_fused.py ${FUZZ_CASES:-600} 11 > $out/r04_fuzz.txt 2>&1 || true
   tail -10 $out/r04_fuzz.txt
-  (python3 tools/bench_host_path.py 1080p 48 bgr; python3 tools/bench_host_path.py 1080p 48 bgr prefetch; python3 tools/bench_host_path.py 4k 24 bgr; python3 tools/bench_host_path.py 4k 24 bgr prefetch; python3 tools/bench_host_path.py 4k 24 bgr exact; python3 tools/bench_host_path.py 4k 24 bgr exact prefetch; python3 tools/bench_host_path.py 1080p 48 bgr exact prefetch) > $out/r04_host_path.txt 2>&1
+  (for a in "1080p 96 bgr" "1080p 96 bgr prefetch" "4k 72 bgr" "4k 72 bgr prefetch" "4k 72 bgr exact" "4k 72 bgr exact prefetch" "1080p 96 bgr exact prefetch"; do python3 tools/bench_host_path.py $a; done) > $out/r04_host_path.txt 2>&1
   cat $out/r04_host_path.txt
   (python3 tools/lanes_bench.py 4k 32 12; python3 tools/lanes_bench.py 4k 8 24; python3 tools/lanes_bench.py 1080p 64 24) > $out/r04_lanes.txt 2>&1
   cat $out/r04_lanes.txt
