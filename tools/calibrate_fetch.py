@@ -31,6 +31,17 @@ fb2.set_frame(0, a)
 fb2.set_frame(1, a)
 fb2.calc_slots([0], [1])
 set_option("fb_fused", -1)
+# the exact mode's kernels: column sums straight from the expansions + row walker, then through M in memory
+set_option("fb_exact_sums", 1)
+for fused in (1, 0):
+    set_option("fb_fused", fused)
+    fbx = Farneback(w, h, levels=0, frame_slots=2, max_pairs=1)
+    fbx.set_frame(0, a)
+    fbx.set_frame(1, a)
+    fbx.calc_slots([0], [1])
+    fbx.close()
+set_option("fb_fused", -1)
+set_option("fb_exact_sums", 0)
 for _ in range(5):
     fb.post_process(0, BACKWARD)          # k_pp_clip: N*8 read, N*8 written
 layer = RemapLayer(h, w)                   # k_remap_init: N*16 written

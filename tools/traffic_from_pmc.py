@@ -13,7 +13,10 @@ import sys
 PIXELS = 3840 * 2160
 KERNELS = {"fb_flow_iter": ("k_flow_iter_pc", 1), "fb_update_matrices": ("k_update_matrices", 1),
            "fb_blur_solve": ("k_blur_solve_wave", 1),
-           "fb_level_polyexp": ("k_level0_polyexp_t", 2), "pp_clip": ("k_pp_clip", 1)}
+           "fb_level_polyexp": ("k_level0_polyexp_t", 2), "pp_clip": ("k_pp_clip", 1),
+           # (a name may ask for several substrings: "a&b")
+           "fb_flow_carry": ("k_flow_carry_pc&false>(", 1), "fb_flow_vsum": ("k_flow_carry_pc&true>(", 1),
+           "fb_exact_vsum": ("k_exact_vsum", 1), "fb_exact_hsolve": ("k_exact_hsolve", 1)}
 
 
 def per_kernel(d, counter):
@@ -37,8 +40,8 @@ out = {"_note": "HBM-side bytes per level pixel and launch, from separate rocpro
                 "(check: pp_clip below reads 8 B/px and writes 8 B/px). tools/traffic_from_pmc.py.",
        "pixels": PIXELS}
 for label, (sub, images) in KERNELS.items():
-    fk = [v for k, vs in fetch.items() if sub in k for v in vs]
-    wk = [v for k, vs in write.items() if sub in k for v in vs]
+    fk = [v for k, vs in fetch.items() if all(p in k for p in sub.split("&")) for v in vs]
+    wk = [v for k, vs in write.items() if all(p in k for p in sub.split("&")) for v in vs]
     if not fk or not wk:
         continue
     f_kib, w_kib = sum(fk) / len(fk), sum(wk) / len(wk)
