@@ -142,6 +142,26 @@ __device__ __forceinline__ void xcd_tile(unsigned &bx, unsigned &by)
     by = t / gridDim.x;
 }
 
+// The same for the one-kernel iteration's grid of (strip, segment, pair): XCD x takes a contiguous run of the PAIRS (pairs
+// [x P / 8, (x + 1) P / 8)) and, of those, all strips and segments -- the strips of a pair share their halo columns in one
+// L2, and consecutive pairs the frame they both read (R0 of one is R1 of the next).  Bijective for any grid.
+__device__ __forceinline__ void xcd_pair_tile(unsigned &bx, unsigned &by, int &pair)
+{
+    const unsigned S = gridDim.x, G = gridDim.y, P = gridDim.z, nt = S * G * P;
+    const unsigned lin = (blockIdx.z * G + blockIdx.y) * S + blockIdx.x;
+    const unsigned xcd = lin & 7, qn = nt >> 3, rn = nt & 7;
+    const unsigned u = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3); // place in XCD-major order
+    const unsigned whole = u / (S * G); // whole pairs' worth of work in front of it
+    unsigned l = 0;
+    while (l < 7 && (l + 1) * P / 8 <= whole)
+        l++;
+    const unsigned p0 = l * P / 8, n = (l + 1) * P / 8 - p0, r = u - p0 * S * G; // within the run: (segment, strip, pair)
+    by = r / (S * n);
+    const unsigned rem = r - by * S * n;
+    bx = rem / n;
+    pair = (int)(p0 + (rem - bx * n));
+}
+
 // Barriers that order LDS traffic only.  __syncthreads() also carries a release fence on GLOBAL memory,
 // i.e. `s_waitcnt vmcnt(0)`: in a marching loop that drains every prefetched load at every row.
 // lds_barrier(): all waves of the workgroup; lds_wave_sync(): the lanes of one wave (single-wave exchange).
@@ -2055,8 +2075,7 @@ struct ColumnCarry {
     double *carry;
     unsigned *flags;      // mode 1: [((seg * pairs + pair) * strips + strip) * 2 + producer wave] == epoch once that wave's carries are stored
     unsigned epoch;       // never 0; a handle counts its chained launches
-    unsigned *ticket;     // mode 1: one counter per handle, never reset: this launch owns tickets ticket_base .. ticket_base + workgroups - 1
-    unsigned ticket_base;
+    unsigned *ticket;     // mode 1: eight counters (one list of work per XCD), zeroed before the launch
     unsigned *fault;      // host-visible word (pinned): set if a wait for a carry gave up
 };
 
@@ -2263,25 +2282,45 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     unsigned bx, by;
     int pair;
     if (cc.mode == 1) {
-        // Segment-major tickets: every segment of a column has a later ticket than the segment above it, and whoever
-        // holds a ticket is resident, so a wait for a predecessor always ends, whatever order the hardware dispatches in.
-        // (the ticket travels through a word of s_p, which the consumers first touch many barriers later: a word of its
-        // own would be the 43rd LDS granule of 1280 bytes and cost the CU its third workgroup)
+        // Tickets, one list per XCD.  The launch's pairs are dealt to the eight XCDs in contiguous runs, and the workgroups
+        // an XCD receives (the hardware deals workgroup i to XCD i mod 8) draw from their XCD's list first: the strips of a
+        // pair stand side by side in one L2 (their halo columns are read once), and so do consecutive pairs, which read
+        // the frame they share -- R0 of one, R1 of the next -- at the same rows at about the same time.  A list is
+        // segment-major (then strip, then pair): every segment of a column has a later ticket in the same list than the
+        // segment above it, and whoever holds a ticket is resident, so a wait for a predecessor always ends, whatever
+        // order the hardware dispatches in.  A workgroup whose own list is used up takes from the next one (lists
+        // differ in length when the pairs do not divide by eight): every workgroup finds exactly one ticket.
+        // (the ticket travels through a double of s_p, which the consumers first touch many barriers later: a word of
+        // its own would be the 43rd LDS granule of 1280 bytes and cost the CU its third workgroup)
         unsigned *s_ticket = reinterpret_cast<unsigned *>(&s_p[0][0][0]);
-        if (threadIdx.x == 0)
-            *s_ticket = __hip_atomic_fetch_add(cc.ticket, 1u, TF_RLX_AGENT) - cc.ticket_base;
+        if (threadIdx.x == 0) {
+            unsigned got = ~0u, list = 0;
+            for (unsigned k = 0; k < 8 && got == ~0u; k++) {
+                list = (blockIdx.x + k) & 7;
+                const unsigned n = (list + 1) * (unsigned)cc.pairs / 8 - list * (unsigned)cc.pairs / 8;
+                const unsigned len = n * (unsigned)(cc.segs * cc.strips);
+                if (len == 0 || __hip_atomic_load(cc.ticket + list, TF_RLX_AGENT) >= len)
+                    continue; // (a look first: a list that is used up is not counted up again by every passer-by)
+                const unsigned t = __hip_atomic_fetch_add(cc.ticket + list, 1u, TF_RLX_AGENT);
+                if (t < len)
+                    got = t;
+            }
+            s_ticket[0] = got;
+            s_ticket[1] = list;
+        }
         __syncthreads();
-        const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket), per_seg = (unsigned)(cc.pairs * cc.strips);
+        const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket[0]), list = __builtin_amdgcn_readfirstlane(s_ticket[1]);
         __syncthreads(); // every wave has read it
+        if (t == ~0u)
+            return; // (no ticket left: the grid and the lists have parted -- touch nothing)
+        const unsigned p0 = list * (unsigned)cc.pairs / 8, n = (list + 1) * (unsigned)cc.pairs / 8 - p0;
+        const unsigned per_seg = n * (unsigned)cc.strips;
         by = t / per_seg;
-        if (by >= (unsigned)cc.segs)
-            return; // (a ticket outside this launch: the counter and the host's count of it have parted -- touch nothing)
         const unsigned rem = t - by * per_seg;
-        pair = (int)(rem / (unsigned)cc.strips);
-        bx = rem - (unsigned)pair * (unsigned)cc.strips;
+        bx = rem / n;
+        pair = (int)(p0 + (rem - bx * n));
     } else {
-        xcd_tile(bx, by);
-        pair = blockIdx.z;
+        xcd_pair_tile(bx, by, pair);
     }
     const size_t Nk = (size_t)Wk * Hk;
     const int r0 = by * seg, r1 = min(r0 + seg, Hk);
@@ -3051,8 +3090,8 @@ struct tf_fb {
     DevBuf exact_vsum;           // option fb_exact_sums: OpenCV's column sums of the level being solved, [pair][5][y][x] doubles
     // OpenCV's column sums across row segments (ColumnCarry)
     DevBuf col_carry;            // the chain's value in front of every segment of the launch being issued
-    DevBuf chain_words;          // word 0: the ticket counter (never reset); from word 16 on: the hand-off flags
-    unsigned chain_epoch = 0, ticket_base = 0;
+    DevBuf chain_words;          // words 0-7: the ticket counters of a launch; from word 16 on: the hand-off flags
+    unsigned chain_epoch = 0;
     unsigned *chain_fault = nullptr; // pinned, device-visible: a wait for a carry gave up (k_flow_iter_pc)
     // tf_fb_async_io: uploads of frames and downloads of results on copy streams of their own, so that a streaming
     // caller's next frame goes up and its previous flow comes down while the current pair is being computed
@@ -3436,7 +3475,6 @@ static int fb_carry_room(tf_fb *fb, size_t carry_doubles, size_t flags)
     if (flags && fb->chain_words.bytes < words * 4) {
         TF_TRY(fb->chain_words.alloc(words * 4)); // (hipFree waits for whatever still uses the old one)
         TF_HIP(hipMemsetAsync(fb->chain_words.p, 0, words * 4, stream()));
-        fb->ticket_base = 0;
         fb->chain_epoch = 0;
     }
     if (!fb->chain_fault) {
@@ -3625,7 +3663,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
         cc.flags = fb->chain_words.as<unsigned>() + 16;
         cc.epoch = fb->chain_epoch;
         cc.ticket = fb->chain_words.as<unsigned>();
-        cc.ticket_base = fb->ticket_base;
+        TF_HIP(hipMemsetAsync(cc.ticket, 0, 8 * sizeof(unsigned), stream()));
         cc.fault = fb->chain_fault;
         grid = dim3((unsigned)items);
     } else if (mc.segs > 1) {
@@ -3651,8 +3689,6 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
            f.yfrac, cc)
     rc = kind == 2 ? TF_PC_LAUNCH(2) : (kind == 1 ? TF_PC_LAUNCH(1) : TF_PC_LAUNCH(0));
 #undef TF_PC_LAUNCH
-    if (rc == TF_OK && cc.mode == 1)
-        fb->ticket_base += grid.x; // the tickets this launch's workgroups draw (only once it is really queued)
     return rc;
 }
 

@@ -209,5 +209,11 @@ def profile_traffic(name, width, height, levels, pairs, launches_per_step, itera
     if name == "fb_flow_iter":
         n = [v for v in n if level_is_fused(v, pairs, fused)]
     images = 2 if name in ("fb_polyexp", "fb_level_image") else 1
-    total = table[name]["bytes_per_px"] * sum(n) * pairs * images * per_level_launches
+    entry = table[name]
+    # a batch of consecutive pairs reads the frame two pairs share once per XCD (the iteration kernel's work order):
+    # measured at the bench's own batch where the table has it
+    batched = table.get(name + "_batched")
+    if batched and pairs >= batched.get("pairs", 1 << 30) // 2:
+        entry = batched
+    total = entry["bytes_per_px"] * sum(n) * pairs * images * per_level_launches
     return total / max(1.0, launches_per_step)
