@@ -28,6 +28,9 @@ if [ "$part" = b ]; then
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/r04_fetch -- python3 $root/tools/calibrate_fetch.py > $out/r04_fetch.log 2>&1)
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/r04_write -- python3 $root/tools/calibrate_fetch.py > $out/r04_write.log 2>&1)
   python3 tools/traffic_from_pmc.py gpurun_out/r04_fetch gpurun_out/r04_write gpurun_out/r04_traffic.json
+  tools/pmc_pass.sh r04_bf 4k 32 FETCH_SIZE
+  tools/pmc_pass.sh r04_bw 4k 32 WRITE_SIZE
+  python3 tools/traffic_batched.py gpurun_out/pmc_r04_bf gpurun_out/pmc_r04_bw gpurun_out/r04_traffic.json
   A="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"
   B="SQ_WAVES SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
   tools/pmc_pass.sh r04_a 4k 32 $A
