@@ -14,11 +14,15 @@
 //          k_level_rowpass + k_level_colpass (long blur kernels) or k_level_image, then k_polyexp_t
 //   A3+A4(+A5)  k_flow_iter_pc: one whole iteration, the 2x2 systems never leave the CU (large levels);
 //          k_update_matrices + k_blur_solve_wave on the small ones
+//   option fb_exact_sums: k_flow_carry_pc<.., STORE> or k_update_matrices + k_exact_vsum, then k_exact_hsolve
 //
 // Arithmetic discipline: every float/double operation is written in the order of
 // the CPU path and the file is compiled with -ffp-contract=off, so A1-A3 are
-// bit-identical to the scalar CPU statement; A4 sums the window directly in
-// double instead of OpenCV's running sums (differences ~1e-16 relative).
+// bit-identical to the scalar CPU statement.  A4 keeps OpenCV's running column sums (one
+// float-differenced chain per column from row 0, carried across row segments) and adds them across
+// the window's columns directly in double where OpenCV slides a second running sum along the row
+// (differences ~1e-16 relative); with option fb_exact_sums that sum is OpenCV's too and the flow
+// is bit-identical.
 //
 // HBM layout (per handle, sized for `max_pairs` frame pairs):
 //   frames   u8  [slot][H][W]
@@ -26,6 +30,7 @@
 //   rowf     f32 [level][image][H][2*Wk]   row-pass planes of the long-kernel levels
 //   R        f32 [image][5][Hk*Wk]         polynomial coefficients, planar (SoA); image = a frame of the batch
 //   M        f32 [pair][5][Hk*Wk]          2x2 systems, planar (two-kernel iterations only)
+//   exact_vsum f64 [pair][5][Hk*Wk]        option fb_exact_sums: the column sums of every row of the level being solved
 //   lflow[5] f32 [pair][Hk*Wk][2]          per-level flow: three rotate, two hold the result of even / odd calls
 // Stencils, gathers and 2x2 solves (<= ~60 flop/B, no dense contraction): MFMA is not applicable.
 #include <type_traits>
