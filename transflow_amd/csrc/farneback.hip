@@ -2333,6 +2333,10 @@ k_flow_iter_pc(const float *__restrict__ R, const float2 *__restrict__ flow_in, 
     // e - M; a consumer turns the sums of step s - 1 into the flow of row r0 + (s - 1) - WIN
     const int e0 = r0 - M - 1, n_rows = (r1 - r0) + WIN, nsteps = n_rows + 1;
     if (wave < 2) {
+        // the producers set a step's pace: where a SIMD holds a producer and consumers (or another kernel's waves) the
+        // producer issues first (4K x 32, one batch in flight: level 0 2859 -> 2806 us, level 1 894 -> 851, 1750 -> 1784
+        // frames/s; with two batches in flight nothing changes)
+        __builtin_amdgcn_s_setprio(1);
         const int col = wave * 64 + lane;
         const int x = clampi((int)bx * OUTC - HALO + col, 0, Wk - 1); // replicated border columns
         RowProducer<FLOW> P;
