@@ -804,6 +804,8 @@ def main():
         "parity_gate": gate if gate is not None else "skipped (--no-gate)",
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / rf.HBM_PEAK_GBS,
+                     # (with two lanes `frac` is on launch durations that include shared time; the kernel by itself:)
+                     "frac_alone": built / max(1, dom_cnt) * alone_cnt / (alone_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
                      "bytes_model": "bytes the kernel as built must move per launch (DESIGN.md §5): for the one-kernel "
                                     "iteration R0 20 + R1 20 + flow in 8 + flow out 8 B/px (M never leaves the CU)",
                      "traffic": traffic, "traffic_source": "profile constant: B/px from the rocprofv3 FETCH_SIZE/WRITE_SIZE "
