@@ -61,6 +61,8 @@ pairs = exact_identical = 0
 st = {name: dict(identical=0, worst=0.0, outlier_pairs=0, px_differ=0) for name, _ in FORMS}
 worst_between = 0.0
 for case in range(n_cases):
+    if case and case % 250 == 0:
+        print(f"... {case} cases, {pairs} pairs, {bad} failures so far", file=sys.stderr, flush=True)   # (a long run stays audible)
     h, w = int(rng.integers(10, 300)), int(rng.integers(10, 460))
     kw = dict(levels=int(rng.integers(0, 4)), winsize=int(rng.choice([7, 11, 15])), iterations=int(rng.integers(1, 4)),
               poly_n=int(rng.choice([5, 7])))
