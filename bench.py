@@ -599,6 +599,10 @@ def main():
     ap.add_argument("--size", default=None, help="WxH: run the chosen workload's configuration at another frame size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed side measurements")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip the three synchronised steps behind the timed region that time the dominant kernel with nothing "
+                         "beside it (roofline.alone): under rocprofv3 every launch of the process is then a gate, warm-up or "
+                         "timed-region launch, and its per-kernel average is comparable with roofline.avg_launch_ms")
     ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (the JSON line says so)")
     ap.add_argument("--equal-batches", action="store_true",
                     help="trim every rank's pass to the shortest one (T=256 over 8 ranks: 31 pairs everywhere instead of 32 x 7 + 31)")
@@ -746,13 +750,15 @@ def main():
     job.prof_reset()
     _L.set_option("prof_levels", 1)          # labels carry the pyramid level: "fb_flow_iter.k0"
     job.prof(True, dominant)
-    for _ in range(3):
+    for _ in range(0 if args.no_alone else 3):
         job.step()
         job.sync()
     job.prof(False)
     _L.set_option("prof_levels", 0)
     by_level = {k: v for k, v in job.prof_report().items() if k.startswith(dominant + ".k")}
     alone_cnt, alone_ms = sum(v[0] for v in by_level.values()), sum(v[1] for v in by_level.values())
+    if args.no_alone:
+        alone_cnt, alone_ms = 0, float("inf")   # (frac_alone and alone.frac then read 0.0)
     rank_fps = host.gather(args.steps * job.batch / t_rank)
     oob = host.gather(bool(job.layer.out_of_frame()))
 

@@ -16,10 +16,10 @@ mkdir -p $out
 if [ "$part" = a ]; then
   python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/r04_bench_4k_default.json 2> $out/r04_bench_4k_default.err
   tail -c 300 $out/r04_bench_4k_default.err
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/r04_stats -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --no-extra > $out/r04_bench_4k_under_rocprof.json 2> $out/r04_bench_under_rocprof.err)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/r04_stats -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --no-extra --no-alone > $out/r04_bench_4k_under_rocprof.json 2> $out/r04_bench_under_rocprof.err)
   cp $(find $out/r04_stats -name "*kernel_stats.csv" | head -1) $out/r04_bench_4k_kernel_stats.csv
   python3 bench.py --gpus 1 --steps 20 --warmup 5 --lanes 1 --no-extra > $out/r04_bench_4k_one_lane.json 2> $out/r04_bench_4k_one_lane.err
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/r04_stats1 -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --lanes 1 --no-extra > $out/r04_bench_4k_one_lane_under_rocprof.json 2> $out/r04_bench_one_lane_under_rocprof.err)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/r04_stats1 -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --lanes 1 --no-extra --no-alone > $out/r04_bench_4k_one_lane_under_rocprof.json 2> $out/r04_bench_one_lane_under_rocprof.err)
   cp $(find $out/r04_stats1 -name "*kernel_stats.csv" | head -1) $out/r04_bench_4k_one_lane_kernel_stats.csv
   python3 tools/kprof.py 4k 32 > $out/r04_kprof_4k_batch32.txt 2>&1
   head -6 $out/r04_bench_4k_kernel_stats.csv $out/r04_bench_4k_one_lane_kernel_stats.csv
