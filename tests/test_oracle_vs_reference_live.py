@@ -154,3 +154,39 @@ def test_flow_ops_oracle_equals_live_reference_on_random_inputs(ref):
         scale, binary = float(rng.choice([0.25, 0.5, 1.0, 2.0])), bool(rng.integers(2))
         np.testing.assert_array_equal(F.render1d(arr, scale=scale, binary=binary), render1d(arr, scale=scale, binary=binary))
         np.testing.assert_array_equal(F.render2d(flows[0], scale=scale), render2d(flows[0], scale=scale))
+
+
+def test_mask_rules_against_the_reference_live():
+    """transflow_amd/masks.py is a rule table with builders of its own (row x column outer products,
+    a distance test), not a restatement of utils.py:51-140: walk the argument grammar at random --
+    every rule name, 0-5 arguments from pixels / percentages / blanks / junk, dimensions larger than the
+    frame (where the reference's results are what numpy slicing makes of negative bounds), ':inv' --
+    and require the same array and dtype wherever the reference produces one, an exception wherever it
+    raises one."""
+    import random
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from transflow import utils as U
+    from transflow_amd import masks as M
+    rnd = random.Random(5)
+    names = ["border", "border-top", "border-right", "border-bottom", "border-left", "hline", "vline", "circle",
+             "rect", "grid", "zeros", "ones", "Border", "CIRCLE", "Rect"]
+    tokens = ["", "0", "1", "2", "3", "4", "7", "15", "200", "5%", "50%", "120%", "x"]
+    produced = 0
+    for _ in range(1500):
+        spec = ":".join([rnd.choice(names)] + [rnd.choice(tokens) for _ in range(rnd.choice([0, 1, 1, 2, 2, 3, 4, 5]))])
+        spec += rnd.choice(["", ":inv"])
+        shape = rnd.choice([(37, 53), (60, 80), (8, 8), (5, 9), (1, 1)])
+        try:
+            want = U.load_float_mask(spec, shape, 1)
+        except Exception:
+            with pytest.raises(Exception):
+                M.load_float_mask(spec, shape, 1)
+            continue
+        got = M.load_float_mask(spec, shape, 1)
+        assert got.dtype == want.dtype, spec
+        np.testing.assert_array_equal(got, want, err_msg=f"{spec} {shape}")
+        np.testing.assert_array_equal(M.load_bool_mask(spec, shape, True), U.load_bool_mask(spec, shape, True))
+        produced += 1
+    assert produced > 400

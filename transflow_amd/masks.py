@@ -12,128 +12,174 @@ import re
 import numpy as np
 
 
-def _dim(arg: str, parent: int) -> int:
-    """'12' -> 12, '40%' -> int(0.4*parent), '' -> 0   (utils.py:13-18)"""
-    arg = arg.strip()
-    if arg == "":
+_LENGTH = re.compile(r"\d+%?\Z")
+
+
+def _length(token: str, extent: int) -> int:
+    """A mask dimension: pixels ('12'), a share of the axis it is measured along ('40%',
+    truncated), or nothing ('' = 0).  Argument grammar of utils.py:13-18."""
+    token = token.strip()
+    if not token:
         return 0
-    if arg.endswith("%"):
-        return int(float(arg[:-1]) / 100 * parent)
-    return int(arg)
+    if token[-1] == "%":
+        return int(float(token[:-1]) / 100 * extent)
+    return int(token)
 
 
-def _border(spec: str, h: int, w: int):
-    name, args = spec.lower().split(":", 1)
-    top = right = bottom = left = 0
-    if name == "border":
-        vals = [_dim(a, h if i % 2 == 0 else w) for i, a in enumerate(args.split(":"))]
-        if len(vals) == 1:
-            top = right = bottom = left = vals[0]
-        elif len(vals) == 2:
-            top = bottom = vals[0]
-            right = left = vals[1]
-        elif len(vals) == 4:
-            top, right, bottom, left = vals
-        else:
-            raise ValueError(f"Invalid number of argument {len(vals)} for border mask")
-    elif name == "border-top":
-        top = _dim(args, h)
-    elif name == "border-right":
-        right = _dim(args, w)
-    elif name == "border-bottom":
-        bottom = _dim(args, h)
-    elif name == "border-left":
-        left = _dim(args, w)
-    else:
-        raise ValueError(f"Invalid border rule name {name}")
-    return top, right, bottom, left
+def _picked(n: int, start, stop) -> np.ndarray:
+    """Which of n rows (columns) the Python slice start:stop picks, as a bool vector: negative
+    and overshooting bounds mean what they mean to numpy indexing, which is what the reference's
+    results are made of when a dimension exceeds the frame."""
+    v = np.zeros(n, bool)
+    v[slice(start, stop)] = True
+    return v
 
 
-_RE_BORDER = re.compile(r"^border(\-(top|right|bottom|left))?:(\d+%?:|:|\d+%?$){1,4}$", re.I)
-_RE_LINE = re.compile(r"^[hv]line:\d+%?$", re.I)
-_RE_CIRCLE = re.compile(r"circle:\d+%?", re.I)
-_RE_RECT = re.compile(r"rect:\d+%?(:\d+%?)?", re.I)
-_RE_GRID = re.compile(r"grid:\d+:\d+:\d+?", re.I)
+def _edges(n: int, head: int, tail: int) -> np.ndarray:
+    """The first `head` and the last `tail` of n positions."""
+    k = np.arange(n)
+    return (k < head) | (k >= n - tail)
+
+
+# ---- shape builders: (args, h, w) -> mask.  Stripes, frames and boxes are outer products of
+# one row vector and one column vector; discs are a distance test. ----------------------------
+def _frame(sides):
+    """border / border-<side>: `sides` maps the argument list to (top, right, bottom, left)."""
+    def build(args, h, w):
+        top, right, bottom, left = sides(args, h, w)
+        return (_edges(h, top, bottom)[:, None] | _edges(w, left, right)[None, :]).astype(np.float32)
+    return build
+
+
+def _all_sides(args, h, w):
+    if len(args) not in (1, 2, 4):
+        raise ValueError(f"Invalid number of argument {len(args)} for border mask")
+    # vertical extents (top, bottom) are measured along the height, horizontal ones along the width
+    v = [_length(a, (h, w)[i % 2]) for i, a in enumerate(args)]
+    return {1: lambda: (v[0],) * 4, 2: lambda: (v[0], v[1], v[0], v[1]), 4: lambda: tuple(v)}[len(v)]()
+
+
+def _one_side(index):
+    def sides(args, h, w):
+        out = [0, 0, 0, 0]
+        out[index] = _length(":".join(args), (h, w)[index % 2])
+        return out
+    return sides
+
+
+def _stripe(axis):
+    """hline / vline: a centred band of the given thickness across the frame."""
+    def build(args, h, w):
+        n = (h, w)[axis]
+        t = _length(args[0], n)
+        first = (n - t) // 2
+        band = _picked(n, first, first + t)
+        rows, cols = (band, np.ones(w, bool)) if axis == 0 else (np.ones(h, bool), band)
+        return (rows[:, None] & cols[None, :]).astype(np.float32)
+    return build
+
+
+def _disc(args, h, w):
+    """circle: the open disc around (h // 2, w // 2).  A BOOL array, as utils.py:92 leaves it
+    (so ':inv' of it is float64) -- tests/golden/masks.npz pins the dtypes."""
+    r = _length(args[0], min(h, w))
+    dy = np.arange(h)[:, None] - h // 2
+    dx = np.arange(w)[None, :] - w // 2
+    return dx * dx + dy * dy < r * r
+
+
+def _box(args, h, w):
+    """rect: centred box, width[:height]; one argument serves both axes (each against its own)."""
+    if len(args) > 2:
+        raise ValueError(f"Invalid number of argument {len(args)} for rect mask")
+    bw, bh = _length(args[0], w), _length(args[-1], h)
+    rows = ~(_picked(h, None, h // 2 - bh // 2) | _picked(h, h // 2 + bh // 2, None))
+    cols = ~(_picked(w, None, w // 2 - bw // 2) | _picked(w, w // 2 + bw // 2, None))
+    return (rows[:, None] & cols[None, :]).astype(np.float32)
+
+
+def _dots(args, h, w):
+    """grid: rows:cols:radius -- one disc stamped at the centre of every cell, cells in raster
+    order (a stamp is a whole 2r x 2r block, so where blocks overlap the later one stands)."""
+    nrows, ncols, r = (int(a) for a in args)
+    k = np.arange(2 * r) - r
+    stamp = k[None, :] ** 2 + k[:, None] ** 2 < r * r
+    out = np.zeros((h, w), np.float32)
+    ch, cw = h // nrows, w // ncols
+    for cell in range(nrows * ncols):
+        i0 = ch * (cell // ncols) + ch // 2 - r
+        j0 = cw * (cell % ncols) + cw // 2 - r
+        out[i0:i0 + 2 * r, j0:j0 + 2 * r] = stamp
+    return out
+
+
+# ---- the rule table: name -> (do these arguments make it a rule?, builder).  A name whose
+# arguments do not fit is not a rule and the string is a file name -- the reference's patterns
+# (utils.py:64-112) send the same strings to PIL.  circle / rect / grid are recognised by their
+# leading arguments alone there; what follows is ignored (circle) or counted (rect, grid). -------
+_DIGITS = re.compile(r"\d")
+
+
+def _lengths(args, blank_ok=False):
+    return all(_LENGTH.match(a) or (blank_ok and a == "") for a in args)
+
+
+def _is_frame(args):
+    return 1 <= len(args) <= 4 and any(args) and _lengths(args, blank_ok=True)
+
+
+def _leading(n):
+    return lambda args: len(args) >= n and all(_DIGITS.match(a) for a in args[:n])
+
+
+def _bare(args):
+    return not args
+
+
+_SHAPES = {
+    "zeros": (_bare, lambda a, h, w: np.zeros((h, w), np.float32)),
+    "ones": (_bare, lambda a, h, w: np.ones((h, w), np.float32)),
+    "random": (_bare, lambda a, h, w: np.random.rand(h, w).astype(np.float32)),
+    "border": (_is_frame, _frame(_all_sides)),
+    "border-top": (_is_frame, _frame(_one_side(0))),
+    "border-right": (_is_frame, _frame(_one_side(1))),
+    "border-bottom": (_is_frame, _frame(_one_side(2))),
+    "border-left": (_is_frame, _frame(_one_side(3))),
+    "hline": (lambda args: len(args) == 1 and _lengths(args), _stripe(0)),
+    "vline": (lambda args: len(args) == 1 and _lengths(args), _stripe(1)),
+    "circle": (_leading(1), _disc),
+    "rect": (_leading(1), _box),
+    "grid": (_leading(3), _dots),
+}
+
+
+def _shape_rule(spec: str):
+    name, *args = spec.split(":")
+    fits, build = _SHAPES.get(name.lower(), (None, None))
+    if fits is None or not fits(args):
+        return None
+    return lambda h, w: build(args, h, w)
+
+
+def _from_image(path: str) -> np.ndarray:
+    import PIL.Image
+    with PIL.Image.open(path) as image:
+        px = np.asarray(image).astype(np.float32)
+    if px.ndim == 2:
+        return px / 255
+    if px.ndim == 3:
+        return px[:, :, :3].mean(axis=2) / 255          # an alpha channel is ignored
+    raise ValueError(f"Image has wrong number of dimensions {px.ndim}, expected 2 or 3")
 
 
 def load_float_mask(mask_path: str | None, shape=(0, 0), default: float = 0) -> np.ndarray:
-    h, w = shape
     if mask_path is None:
         return np.full(shape, default, dtype=np.float32)
     inverse = mask_path.endswith(":inv")
-    if inverse:
-        mask_path = mask_path[:-4]
-    low = mask_path.lower()
-    if low == "zeros":
-        arr = np.zeros(shape, np.float32)
-    elif low == "ones":
-        arr = np.ones(shape, np.float32)
-    elif low == "random":
-        arr = np.random.rand(*shape).astype(np.float32)
-    elif _RE_BORDER.match(mask_path):
-        top, right, bottom, left = _border(mask_path, h, w)
-        arr = np.zeros(shape, np.float32)
-        if top:
-            arr[:top, :] = 1
-        if right:
-            arr[:, -right:] = 1
-        if bottom:
-            arr[-bottom:, :] = 1
-        if left:
-            arr[:, :left] = 1
-    elif _RE_LINE.match(mask_path):
-        name, a = low.split(":")
-        arr = np.zeros(shape, np.float32)
-        if name == "hline":
-            t = _dim(a, h)
-            i = (h - t) // 2
-            arr[i:i + t, :] = 1
-        else:
-            t = _dim(a, w)
-            j = (w - t) // 2
-            arr[:, j:j + t] = 1
-    elif _RE_CIRCLE.match(mask_path):
-        radius = _dim(low.split(":")[1], min(shape))
-        ii = np.arange(h)[:, None] - h // 2
-        jj = np.arange(w)[None, :] - w // 2
-        arr = jj ** 2 + ii ** 2 < radius ** 2          # bool, like the reference (utils.py:92)
-    elif _RE_RECT.match(mask_path):
-        args = mask_path[mask_path.index(":") + 1:].split(":")
-        if len(args) == 1:
-            rw, rh = _dim(args[0], w), _dim(args[0], h)
-        elif len(args) == 2:
-            rw, rh = _dim(args[0], w), _dim(args[1], h)
-        else:
-            raise ValueError(f"Invalid number of argument {len(args)} for rect mask")
-        arr = np.ones(shape, np.float32)
-        arr[:h // 2 - rh // 2, :] = 0
-        arr[h // 2 + rh // 2:, :] = 0
-        arr[:, :w // 2 - rw // 2] = 0
-        arr[:, w // 2 + rw // 2:] = 0
-    elif _RE_GRID.match(mask_path):
-        nrows, ncols, radius = (int(a) for a in mask_path[mask_path.index(":") + 1:].split(":"))
-        dia = 2 * radius
-        k = np.arange(dia) - radius
-        disc = k[None, :] ** 2 + k[:, None] ** 2 < radius ** 2
-        arr = np.zeros(shape, np.float32)
-        ch, cw = h // nrows, w // ncols
-        for i in range(nrows):
-            for j in range(ncols):
-                i0, j0 = ch * i + ch // 2 - radius, cw * j + cw // 2 - radius
-                arr[i0:i0 + dia, j0:j0 + dia] = disc
-    else:
-        import PIL.Image
-        with PIL.Image.open(mask_path) as image:
-            arr = np.array(image).astype(np.float32)
-        if arr.ndim == 2:
-            arr /= 255
-        elif arr.ndim == 3:
-            arr = np.mean(arr[:, :, :3], axis=2) / 255
-        else:
-            raise ValueError(f"Image has wrong number of dimensions {arr.ndim}, expected 2 or 3")
-    if inverse:
-        arr = 1.0 - arr
-    return arr
+    spec = mask_path.removesuffix(":inv")
+    rule = _shape_rule(spec)
+    mask = rule(*shape) if rule else _from_image(spec)
+    return 1.0 - mask if inverse else mask
 
 
 def load_bool_mask(mask_path: str | None, shape=(0, 0), default: bool = False) -> np.ndarray:
