@@ -215,10 +215,20 @@ class Job:
         return out
 
 
+def gate_pairs(batch, n_check=2):
+    """Which pairs of a batch the gate compares with the oracle: the first and the LAST (n_check = 2).  In the
+    one-kernel iteration the pairs of a launch are dealt to the eight XCDs' ticket lists in contiguous runs: pairs 0
+    and 1 -- what rounds 1-4 checked -- both sit in list 0, the first and the last pair in lists 0 and 7."""
+    n_check = min(n_check, batch)
+    if n_check <= 1:
+        return [0][:n_check]
+    return sorted({round(j * (batch - 1) / (n_check - 1)) for j in range(n_check)})
+
+
 def parity_gate(job, n_check=2):
     """The calls the timed loop makes (one batched Farnebäck pass over the first batch, shared expansions;
-    then the fused remap step per pair with the uniform drawn on the GPU) against the CPU oracle on the
-    first `n_check` pairs.
+    then the fused remap step per pair with the uniform drawn on the GPU) against the CPU oracle on
+    `n_check` pairs of the batch, the first and the last (gate_pairs).
 
     Flow, default mode (what is timed): EVERY pixel within TOL_REL * max(1, max|ref|) of the oracle.  (Rounds 2 and 3
     excused a few border pixels -- FarnebackUpdateMatrices' in-frame test is discontinuous in the flow and the kernels'
@@ -233,12 +243,12 @@ def parity_gate(job, n_check=2):
     baseline sample."""
     from oracle import farneback as OF
     from oracle import remap_ref as OR
-    from transflow_amd import _lib
     from transflow_amd.device import DevBuffer
     from transflow_amd.remap import CompImage
     wl = job.wl
     w, h = wl["w"], wl["h"]
-    n_check = min(n_check, job.batch)
+    idx = gate_pairs(job.batch, n_check)
+    n_check = len(idx)
     OF.lib()
     job.calc_pass(0)
     job.sync()
@@ -250,17 +260,18 @@ def parity_gate(job, n_check=2):
     ora = OR.MoveRefLayer(h, w, prm, reset_mask=job.reset_mask, introduction_masks=[np.ones((h, w), bool)])
     white = np.full((h, w, 3), 255, np.uint8)
     ubuf = DevBuffer(h * w * 8)
-    rep = {"pairs_checked": n_check, "flow_max_abs_err": 0.0, "flow_tol": 0.0, "flow_pixels": n_check * h * w,
+    rep = {"pairs_checked": n_check, "pairs": idx, "flow_max_abs_err": 0.0, "flow_tol": 0.0, "flow_pixels": n_check * h * w,
            "outliers_default": 0, "flow_pixels_differing": 0, "lanes_bit_identical": True,
            "outliers_exact": 0, "exact_max_abs_err": 0.0, "exact_bit_identical": True,
            "flow_ok": True, "remap_bit_exact": True,
-           "what": "first pairs of the first batch through the timed loop's own calls vs the CPU oracle.  flow_ok = NO pixel "
+           "what": "the first and the last pair of the first batch (`pairs`: ticket lists 0 and 7 of the one-kernel iteration's "
+                   "launches) through the timed loop's own calls vs the CPU oracle.  flow_ok = NO pixel "
                    f"beyond {TOL_REL:g} * max(1, max|ref|) (outliers_default == 0; no allowance), the other lane's flow of "
-                   "the same pairs bit-identical to the first lane's, AND the same pairs with option fb_exact_sums (the "
-                   "window summed in OpenCV's own order) bit-identical to the oracle"}
+                   "the same pairs bit-identical to the first lane's, AND the same pairs in the handle's exact mode "
+                   "(tf_fb_set_exact: the window summed in OpenCV's own order) bit-identical to the oracle"}
     t_fb = t_rm = 0.0
     refs, firsts = [], []
-    for i in range(n_check):
+    for i in idx:
         a, b = job.synth.frame(f0 + prev[i]), job.synth.frame(f0 + nxt[i])
         t0 = time.perf_counter()
         ref = OF.calc(a, b, levels=wl["levels"])
@@ -293,13 +304,13 @@ def parity_gate(job, n_check=2):
     # the same batch through the other lane (with one lane: the same handle again, a replay)
     job.calc_pass(0)
     job.sync()
-    for i in range(n_check):
-        rep["lanes_bit_identical"] = rep["lanes_bit_identical"] and bool(np.array_equal(job.fb.get_flow(i), firsts[i]))
-    # the same pairs with the window summed in OpenCV's own order
-    saved = _lib.get_option("fb_exact_sums")
-    _lib.set_option("fb_exact_sums", 1)
+    for j, i in enumerate(idx):
+        rep["lanes_bit_identical"] = rep["lanes_bit_identical"] and bool(np.array_equal(job.fb.get_flow(i), firsts[j]))
+    job.gate_flows = dict(zip(idx, firsts))      # pass 0, synchronised: what the timed region's re-check compares with
+    # the same pairs with the window summed in OpenCV's own order (the handle's mode, tf_fb_set_exact)
+    job.fb.set_exact(True)
     try:
-        job.fb.calc_slots(prev[:n_check], nxt[:n_check])
+        job.fb.calc_slots([prev[i] for i in idx], [nxt[i] for i in idx])
         job.sync()
         for i in range(n_check):
             got = job.fb.get_flow(i)
@@ -309,7 +320,7 @@ def parity_gate(job, n_check=2):
             rep["exact_max_abs_err"] = max(rep["exact_max_abs_err"], float(d.max()))
             rep["exact_bit_identical"] = rep["exact_bit_identical"] and bool(np.array_equal(got, refs[i]))
     finally:
-        _lib.set_option("fb_exact_sums", saved)
+        job.fb.set_exact(None)
     rep["flow_pixels_over_tol"] = rep["outliers_default"]
     rep["flow_ok"] = bool(rep["flow_ok"] and rep["exact_bit_identical"] and rep["lanes_bit_identical"])
     rep["out_of_frame"] = bool(layer.out_of_frame())
@@ -318,6 +329,32 @@ def parity_gate(job, n_check=2):
     layer.close()
     comp.close()
     return rep, {"pairs": n_check, "farneback_s": t_fb, "remap_s": t_rm}
+
+
+def timed_region_recheck(job, lanes):
+    """Are the flows of the overlapped timed region the flows the synchronised gate vouched for?  The flows of the LAST
+    timed step (first and last pair of its batch) are still in its lane's result buffer when the region ends: they are
+    brought down, the same pass is computed again with nothing beside it -- once per lane, a synchronisation after each,
+    exactly how the gate ran pass 0 -- and all must agree bit for bit; where the last step happened to be pass 0 again,
+    also with the flows the gate compared with the oracle.  No oracle work: a few milliseconds."""
+    last = job.n_steps - 1
+    which = last % len(job.passes)
+    idx = gate_pairs(job.batch)
+    timed = [job.fb.get_flow(i) for i in idx]
+    same = True
+    for _ in range(max(1, lanes)):
+        job.calc_pass(which)
+        job.sync()
+        for i, t in zip(idx, timed):
+            same = same and bool(np.array_equal(job.fb.get_flow(i), t))
+    out = {"step": last, "pass": which, "pairs": idx, "lanes_recomputed": max(1, lanes),
+           "equals_synchronised_recomputation": bool(same),
+           "what": "flows of the last step of the overlapped timed region vs the same pass computed alone on each lane"}
+    gate = getattr(job, "gate_flows", None)
+    if which == 0 and gate is not None:
+        out["equals_gate_flows"] = bool(all(np.array_equal(gate[i], t) for i, t in zip(idx, timed)))
+    out["ok"] = bool(same and out.get("equals_gate_flows", True))
+    return out
 
 
 def host_description():
@@ -633,7 +670,7 @@ def main():
         if rank == 0:
             line = line_skeleton(args, wl, world, plans)     # the keys of a measured line, nulls where a GPU would speak
             line.update({"rccl_ranks": None, "rccl_version": None, "per_rank_frames_per_s": None,
-                         "parity_gate": "skipped (--dry-run)", "roofline": None, "cpu_baseline": None,
+                         "parity_gate": "skipped (--dry-run)", "timed_region_recheck": None, "roofline": None, "cpu_baseline": None,
                          "kernels_ms_per_step": None, "remap_out_of_frame": None, "gather": None,
                          "dry_run": True, "clip_frames": args.clip_frames, "plans": plans})
             print(json.dumps(line))
@@ -743,6 +780,7 @@ def main():
     elapsed = host.max_over_ranks(time.perf_counter() - t0)
     job.prof(False)
     dom_cnt, dom_ms = job.prof_report()[dominant]
+    recheck = host.gather(timed_region_recheck(job, args.lanes))
     # the same kernel with nothing beside it: a few steps with a synchronisation after each, so neither the other lane's
     # batch nor the previous batch's remap shares the chip with it (in the timed region they do: that is what two lanes
     # are for, and a launch's duration there includes the time it shares)
@@ -755,10 +793,13 @@ def main():
         job.sync()
     job.prof(False)
     _L.set_option("prof_levels", 0)
-    by_level = {k: v for k, v in job.prof_report().items() if k.startswith(dominant + ".k")}
-    alone_cnt, alone_ms = sum(v[0] for v in by_level.values()), sum(v[1] for v in by_level.values())
-    if args.no_alone:
-        alone_cnt, alone_ms = 0, float("inf")   # (frac_alone and alone.frac then read 0.0)
+    alone_report = job.prof_report()
+    by_level = {k: v for k, v in alone_report.items() if k.startswith(dominant + ".k")}
+    # (a kernel launched without a level label -- fb_w1_vsum, fb_blur_solve_generic -- is reported under its own name)
+    alone_src = by_level or {k: v for k, v in alone_report.items() if k == dominant}
+    alone_cnt, alone_ms = sum(v[0] for v in alone_src.values()), sum(v[1] for v in alone_src.values())
+    if args.no_alone or alone_cnt == 0 or alone_ms <= 0:
+        alone_cnt, alone_ms = 0, None           # not measured: the line carries nulls, never Infinity
     rank_fps = host.gather(args.steps * job.batch / t_rank)
     oob = host.gather(bool(job.layer.out_of_frame()))
 
@@ -804,40 +845,60 @@ def main():
     per_gpu_s = args.steps / elapsed
     out = line_skeleton(args, wl, world, plans)
     out.update({"value": fps, "ms_per_step": elapsed / args.steps * 1e3})
+    per_launch = built / max(1, dom_cnt)
+    timed = {"launches": dom_cnt, "avg_launch_ms": avg_ms, "achieved": achieved, "frac": achieved / rf.HBM_PEAK_GBS}
+    alone = None
+    if alone_cnt:
+        alone_gbs = per_launch * alone_cnt / (alone_ms * 1e-3) / 1e9
+        alone = {"what": "the same launches in steps that are synchronised one by one (no other lane, no remap beside "
+                         "them), measured right after the timed region",
+                 "launches": alone_cnt, "avg_launch_ms": alone_ms / alone_cnt,
+                 "by_level": level_fracs(rf, dominant, by_level, wl, P),
+                 "achieved": alone_gbs, "frac": alone_gbs / rf.HBM_PEAK_GBS}
+    # The kernel's own figure: with one lane the timed region's launches have the chip to themselves and ARE it; with two
+    # lanes a launch of the timed region shares the chip with the other lane's batch (its duration includes the time it
+    # shares: `overlapped`), and the kernel's own figure is the `alone` measurement.
+    own = timed if args.lanes == 1 else alone
+    step_frac = step_built * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS
     out.update({
         "rccl_ranks": world if rccl_version is not None else 0, "rccl_version": rccl_version,
         "per_rank_frames_per_s": rank_fps,
         "parity_gate": gate if gate is not None else "skipped (--no-gate)",
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / rf.HBM_PEAK_GBS,
-                     # (with two lanes `frac` is on launch durations that include shared time; the kernel by itself:)
-                     "frac_alone": built / max(1, dom_cnt) * alone_cnt / (alone_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
+        "timed_region_recheck": {"ok": all(r["ok"] for r in recheck), "per_rank": recheck},
+        "roofline": {"bound": "hbm", "kernel": dominant,
+                     "achieved": own["achieved"] if own else None, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": own["frac"] if own else None,
+                     "frac_source": ("timed region (one lane: nothing runs beside a launch)" if args.lanes == 1 else
+                                     "`alone`: the timed workload's launches with nothing beside them, right after the "
+                                     "timed region" if alone else "not measured (--no-alone with two lanes): see `overlapped`"),
+                     "avg_launch_ms": own["avg_launch_ms"] if own else None,
+                     "step_frac": step_frac,     # = whole_step.frac: everything a step launches, built bytes / wall time
+                     "frac_overlapped": timed["frac"] if args.lanes > 1 else None,
+                     "overlapped": dict(timed, what="the timed region's own launches: with two lanes each shares the chip "
+                                                    "with the other lane's batch and its duration includes that -- how long "
+                                                    "a launch took, not how well the kernel uses the memory system")
+                                   if args.lanes > 1 else None,
                      "bytes_model": "bytes the kernel as built must move per launch (DESIGN.md §5): for the one-kernel "
-                                    "iteration R0 20 + R1 20 + flow in 8 + flow out 8 B/px (M never leaves the CU)",
+                                    "iteration R0 20 + R1 20 + flow in 8 + flow out 8 = 56 B/px (M never leaves the CU).  "
+                                    "SURVEY §8(d)'s stage-once model charges the reference's stages 96 B/px (M stored and "
+                                    "read back): on those bytes the same launches read > 1 of peak by construction "
+                                    "(`model_work_rate`: a work rate, not utilisation)",
                      "traffic": traffic, "traffic_source": "profile constant: B/px from the rocprofv3 FETCH_SIZE/WRITE_SIZE "
                                                            "passes under profiles/ scaled to this workload's launches, "
                                                            "not a measurement of this run",
-                     "counter_GBs": traffic / (avg_ms * 1e-3) / 1e9 if traffic else None,
-                     "counter_frac": traffic / (avg_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if traffic else None,
-                     "launches": dom_cnt, "avg_launch_ms": avg_ms,
-                     "algorithmic_bytes_per_launch": built / max(1, dom_cnt),
-                     "timed_region_note": ("two lanes: a launch of the timed region shares the chip with the other lane's batch, "
-                                           "its duration includes that; `alone` is the same kernel with nothing beside it"
-                                           if args.lanes > 1 else "one lane"),
-                     "alone": {"what": "the same launches in steps that are synchronised one by one (no other lane, no remap "
-                                       "beside them), measured right after the timed region",
-                               "launches": alone_cnt, "avg_launch_ms": alone_ms / max(1, alone_cnt),
-                               "by_level": level_fracs(rf, dominant, by_level, wl, P),
-                               "achieved": built / max(1, dom_cnt) * alone_cnt / (alone_ms * 1e-3) / 1e9,
-                               "frac": built / max(1, dom_cnt) * alone_cnt / (alone_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS},
+                     "counter_GBs": traffic / (own["avg_launch_ms"] * 1e-3) / 1e9 if traffic and own else None,
+                     "counter_frac": traffic / (own["avg_launch_ms"] * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if traffic and own else None,
+                     "launches": dom_cnt,
+                     "algorithmic_bytes_per_launch": per_launch,
+                     "alone": alone,
                      "model_work_rate": {"what": "SURVEY Appendix C stage-once bytes of the reference's stages (96 B/px per "
                                                  "iteration, M stored and re-read) per second: the reference's work rate, "
                                                  "not HBM utilisation",
                                          "bytes_per_launch": model / max(1, dom_cnt),
-                                         "achieved": model / (dom_ms * 1e-3) / 1e9,
-                                         "frac": model / (dom_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS},
+                                         "achieved": (model / max(1, dom_cnt)) / (own["avg_launch_ms"] * 1e-3) / 1e9 if own else None,
+                                         "frac": (model / max(1, dom_cnt)) / (own["avg_launch_ms"] * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if own else None},
                      "whole_step": {"built_bytes": step_built, "achieved": step_built * per_gpu_s / 1e9,
-                                    "frac": step_built * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS,
+                                    "frac": step_frac,
                                     "model_bytes": step_model, "model_work_rate": step_model * per_gpu_s / 1e9,
                                     "model_frac": step_model * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS}},
         "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
@@ -862,13 +923,11 @@ def main():
             ceiling = copy_ceiling(job.lib, job.check)
             out["roofline"]["measured_copy_ceiling_GBs"] = ceiling
             # above the copy kernel's rate the byte model would be wrong: flagged in the line, never a lost line
-            out["roofline"]["exceeds_copy_ceiling"] = bool(max(achieved, out["roofline"]["alone"]["achieved"]) > ceiling * 1.02)
+            out["roofline"]["exceeds_copy_ceiling"] = bool(max(achieved, (alone or {}).get("achieved", 0.0)) > ceiling * 1.02)
             if world == 1:
                 # the bit-identical mode's rate on the same workload (option fb_exact_sums: the window summed in OpenCV's own
                 # order along the rows too; its flow was compared bit for bit with the oracle's in the gate)
-                from transflow_amd import _lib as L
-                saved = L.get_option("fb_exact_sums")
-                L.set_option("fb_exact_sums", 1)
+                job.fb.set_exact(True)
                 try:
                     for _ in range(2):                   # both lanes once: each sizes its buffer of column sums at its first call
                         job.step()
@@ -879,10 +938,10 @@ def main():
                     job.sync()
                     out["exact_mode"] = {"frames_per_s": 4 * job.batch / (time.perf_counter() - t0),
                                          "bit_identical": None if gate is None else bool(gate["exact_bit_identical"]),
-                                         "what": "the timed workload with option fb_exact_sums, untimed region; the default mode "
+                                         "what": "the timed workload in the handles' exact mode (tf_fb_set_exact), untimed region; the default mode "
                                                  "differs from the same oracle in parity_gate.flow_pixels_differing pixels"}
                 finally:
-                    L.set_option("fb_exact_sums", saved)
+                    job.fb.set_exact(None)
             extra = {}
             for name in (("1080p", "1080p-1level") if world == 1 else ()):
                 if name == args.workload:
@@ -922,7 +981,7 @@ def main():
             leg_errors["extras"] = f"{type(err).__name__}: {err}"
     if leg_errors:
         out["side_leg_errors"] = leg_errors
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out, allow_nan=False), flush=True)
     if not STUCK_THREADS:
         host.close()
     if out["roofline"].get("exceeds_copy_ceiling"):

@@ -138,10 +138,17 @@ int tf_fb_create(tf_fb **out, int width, int height, const tf_fb_params *params,
    cv.py:479-490): a handle of the same size and parameters that READS FIRST'S FRAME SLOTS and queues its calls on the
    library's other call stream.  Batches sent alternately to the two handles are in flight together, so the launches of
    one that leave the chip part-empty (coarse pyramid levels, the tail of every launch) run beside those of the other.
-   Everything else is per handle: results are read from the handle that ran the call.  Destroy the lane before `first`.
-   Not with tf_fb_keep_expansions. */
+   Everything else is per handle: results are read from the handle that ran the call.  `first` destroyed while lanes
+   still read its slots is released with the last of them (it must not be used after its own tf_fb_destroy).
+   Not with tf_fb_keep_expansions.  A lane starts with first's tf_fb_set_exact mode. */
 int tf_fb_create_lane(tf_fb **out, tf_fb *first);
 void tf_fb_destroy(tf_fb *fb);
+/* Which summation this HANDLE's calls use for the box window (cv.py:479-490: one call, one result; nothing outside
+   the handle decides it): 1 = OpenCV's own order along the rows too (flow bit-identical to the CPU path's, ~2x the
+   time), 0 = the default (window added across columns directly, every pixel within 1e-4 relative), -1 = whatever the
+   process-wide option "fb_exact_sums" says when a call is issued (the state a new handle is in).  Takes effect with the
+   next call; two handles of one process may differ, whichever threads drive them. */
+int tf_fb_set_exact(tf_fb *fb, int mode);
 
 /* One pair, host in / host out: flow_out is float32 [height][width][2] (x=dx, y=dy),
    exactly the array cv.py:479-490 produces.  Strides in bytes.  With TF_OPTFLOW_USE_INITIAL_FLOW the

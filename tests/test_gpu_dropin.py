@@ -295,6 +295,60 @@ def test_prefetching_flow_source_yields_the_same_flows_from_pinned_arrays():
         np.testing.assert_array_equal(a, b)
 
 
+def test_views_of_pooled_arrays_survive_more_frames_than_the_pool_holds():
+    """What a caller really keeps is `flow[..., 0]` or `frame[:, :, ::-1]`, not the array: numpy points such a view at the
+    hidden owner of the page-locked memory, which the pool watches as well (advisor, round 4) -- over more frames than the
+    pools hold (4 + prefetch flows, 4 frames) every held view still shows its own frame's values."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import FlowConfig, LayerConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 96, 128
+    frames = _bgr_frames(h, w, 13)
+    pix = np.random.default_rng(4).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+    class Src:
+        introduction_mask = np.ones((h, w), bool)
+
+        def next(self, timeout=1):
+            return pix
+
+    for cfg in (None, FlowConfig(hip_prefetch=2)):
+        comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
+        comp.set_sources({0: [Src()]})
+        views, copies = [], []
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
+            for flow in source:
+                comp.update(flow)
+                frame = comp.render()
+                views.append((flow[..., 0], frame[:, :, ::-1]))        # views only: the arrays themselves are let go
+                copies.append((flow[..., 0].copy(), frame[:, :, ::-1].copy()))
+                del flow, frame
+        assert len(views) == 12
+        for (fv, iv), (fc, ic) in zip(views, copies):
+            np.testing.assert_array_equal(fv, fc)
+            np.testing.assert_array_equal(iv, ic)
+
+
+@pytest.mark.parametrize("shape,no_overlap", [((48, 48), 0), ((120, 160), 1)])
+def test_prefetching_flow_source_with_one_result_set(shape, no_overlap, lib_option):
+    """A handle with a single result set in rotation -- a frame under 64 pixels (one scale, K == 0) or option fb_no_overlap
+    -- under the prefetching worker, which issues flow t + 1 (its download included) before it ends flow t's: round 4 failed
+    on the second flow with 'the previous download of this result set has not been ended' (advisor)."""
+    from transflow_amd.config import FlowConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    lib_option("fb_no_overlap", no_overlap)
+    h, w = shape
+    frames = _bgr_frames(h, w, 7)
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward") as source:
+        plain = [f.copy() for f in source]
+    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward",
+                                 cv_config=FlowConfig(hip_prefetch=2)) as source:
+        ahead = [f.copy() for f in source]
+    assert len(plain) == len(ahead) == 6
+    for a, b in zip(plain, ahead):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_prefetching_flow_source_passes_errors_on_and_stops_cleanly():
     """An exception in the worker thread (a provider that fails) surfaces in the consumer's thread at the flow it belongs
     to; closing a source whose worker is blocked on a full queue returns."""
@@ -336,24 +390,59 @@ def test_flow_source_host_path_ingests_on_the_device_too(lib_option):
 
 
 def test_flow_config_can_ask_for_opencv_identical_flows(lib_option):
-    """`"hip_exact_sums": true` in the cv_config JSON: the drop-in source's flows equal the CPU path's bit for bit."""
+    """`"hip_exact_sums": true` in the cv_config JSON: the drop-in source's flows equal the CPU path's bit for bit.
+    Exactness is the HANDLE's (tf_fb_set_exact): the source never touches the process-wide option, whatever it says."""
     from transflow_amd import _lib
     from transflow_amd.config import FlowConfig
     from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
-    lib_option("fb_exact_sums", 0)                     # restored afterwards whatever the source sets
     h, w = 120, 160
     frames = _frames(h, w, 3)
     cfg = FlowConfig(hip_exact_sums=True, fb_levels=2)
     assert cfg.to_dict()["hip_exact_sums"] is True and FlowConfig(**cfg.to_dict()).hip_exact_sums
-    with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
-        flows = [f.copy() for f in source]
-        assert _lib.get_option("fb_exact_sums") == 1   # the source's, while it is open ...
-    assert _lib.get_option("fb_exact_sums") == 0       # ... and what it found, once it is closed
-    lib_option("fb_exact_sums", 1)
+    expected = [R.post_process(OF.calc(frames[t + 1], frames[t], levels=2), R.BACKWARD) for t in range(2)]
+    for process_wide in (0, 1):
+        lib_option("fb_exact_sums", process_wide)
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
+            flows = [f.copy() for f in source]
+            assert _lib.get_option("fb_exact_sums") == process_wide    # untouched while the source is open ...
+        assert _lib.get_option("fb_exact_sums") == process_wide        # ... and after
+        for flow, exp in zip(flows, expected):
+            np.testing.assert_array_equal(flow, exp)
+
+
+def test_two_sources_of_one_process_disagree_about_exactness(lib_option):
+    """One exact source and one default source open TOGETHER, their calls interleaved, the default one prefetching in a
+    worker thread on a library stream of its own: each returns its own mode's flows -- bit-identical to the CPU path's, or
+    the default mode's (equal to a default source run alone, within tolerance of the oracle).  The two modes' flows are
+    often equal to the last bit, so the kernels say which ran: the exact mode's row walker is launched once per level and
+    iteration of the exact source's six flows and not once more (the profiler's records are shared by the two threads).
+    With the process-wide option saying the opposite of each."""
+    from transflow_amd.config import FlowConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 270, 480
+    frames = _frames(h, w, 7, seed=11)
+    oracle = [R.post_process(OF.calc(frames[t + 1], frames[t]), R.BACKWARD) for t in range(6)]
     with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward") as source:
-        next(source)
-        assert _lib.get_option("fb_exact_sums") == 0   # a source whose configuration does not ask for it turns it off
-    assert _lib.get_option("fb_exact_sums") == 1
-    for t, flow in enumerate(flows):
-        exp = R.post_process(OF.calc(frames[t + 1], frames[t], levels=2), R.BACKWARD)
-        np.testing.assert_array_equal(flow, exp)
+        alone = [f.copy() for f in source]
+    from transflow_amd import _lib
+    for process_wide in (1, 0):
+        lib_option("fb_exact_sums", process_wide)
+        _lib.profile(True)
+        exact_src = HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward",
+                                            cv_config=FlowConfig(hip_exact_sums=True))
+        default_src = HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward",
+                                              cv_config=FlowConfig(hip_prefetch=2))
+        with exact_src as es, default_src as ds:
+            for t in range(6):
+                if t % 2:
+                    d, e = next(ds).copy(), next(es).copy()
+                else:
+                    e, d = next(es).copy(), next(ds).copy()
+                np.testing.assert_array_equal(e, oracle[t], err_msg=f"exact source, flow {t}")
+                np.testing.assert_array_equal(d, alone[t], err_msg=f"default source, flow {t}")
+                assert np.abs(d - oracle[t]).max() <= 1e-4 * max(1.0, float(np.abs(oracle[t]).max()))
+        _lib.profile(False, reset=False)
+        rep = _lib.profile_report()
+        walkers = sum(n for name, (n, _) in rep.items() if name.startswith("fb_exact_hsolve"))
+        assert walkers == 6 * 4 * 3, rep                    # levels=3: four scales, three iterations, six flows
+        assert any(name.startswith(("fb_flow_iter", "fb_blur_solve")) for name in rep), rep   # the default source's

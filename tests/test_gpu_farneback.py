@@ -440,6 +440,28 @@ def test_fused_iteration_on_random_shapes_and_batches(FB, lib_option):
         fb.close()
 
 
+def test_plan_forms_fuzz(lib_option, capsys):
+    """tools/fuzz_fused.py inside the suite (rounds 3-4 kept its runs under profiles/ only): 150 random configurations,
+    fixed seed, every pair through the six forms of the marching kernels' plan -- one-kernel iteration whole / 3 segments
+    handed down / 3 segments from the pre-pass, two-kernel iteration whole / 3 segments, the planner's own choice -- and
+    the exact mode two ways, against the oracle.  Exact mode: bit-identical in every pair.  Every other form: no pixel
+    beyond 1e-4 * max(1, max|ref|), and no two forms further apart than that."""
+    for name in ("fb_fused", "fb_segs", "fb_chain", "fb_exact_sums"):
+        lib_option(name, _lib_get(name))             # the tool sets them per form: restored whatever happens
+    from tools.fuzz_fused import EXACT_FORMS, FORMS, fuzz
+    res = fuzz(150, 20261004)
+    report = capsys.readouterr().out
+    assert res["failures"] == 0, report
+    assert res["pairs"] >= 150 and res["exact_identical"] == res["pairs"], report
+    assert all(res["forms"][name]["outlier_pairs"] == 0 for name, _ in FORMS), report
+    assert res["worst_between"] <= 1.0 and len(EXACT_FORMS) == 2
+
+
+def _lib_get(name):
+    from transflow_amd import _lib
+    return _lib.get_option(name)
+
+
 def test_unusual_parameter_values_close(FB):
     """Values cv2 accepts but nobody picks: even window sizes (the window is 2*(winsize/2)+1 wide, the
     scale 1/winsize^2: optflowgf.cpp as written), windows of 1-3 pixels, every polynomial radius from 1 to

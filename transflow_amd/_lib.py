@@ -82,6 +82,7 @@ PROTOTYPES = {
     "tf_host_free": (_I, [_P]),
     "tf_thread_stream": (_I, [_I]),
     "tf_fb_create_lane": (_I, [_PP, _P]),
+    "tf_fb_set_exact": (_I, [_P, _I]),
     "tf_fb_async_io": (_I, [_P, _I]),
     "tf_fb_get_flow_begin": (_I, [_P, _I, _P, _PI]),
     "tf_fb_get_flow_end": (_I, [_P, _I]),
@@ -187,6 +188,26 @@ def get_option(name: str) -> int:
     v = C.c_long()
     check(load().tf_get_option(name.encode(), C.byref(v)))
     return v.value
+
+
+def profile(on: bool, name_filter: str | None = None, reset: bool = True) -> None:
+    """tf_prof_*: HIP events around every launch whose label contains `name_filter` (all if None)."""
+    lib = load()
+    check(lib.tf_prof_set_filter(name_filter.encode() if name_filter else None))
+    if reset:
+        check(lib.tf_prof_reset())
+    check(lib.tf_prof_enable(1 if on else 0))
+
+
+def profile_report() -> dict:
+    """label -> (launches, milliseconds) since the last reset."""
+    buf = C.create_string_buffer(1 << 16)
+    check(load().tf_prof_report(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
 
 
 class TfError(RuntimeError):

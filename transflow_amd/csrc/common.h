@@ -68,11 +68,14 @@ struct StreamScope {
             return tf::set_error(TF_ERR_ARG, __VA_ARGS__); \
     } while (0)
 
-// Per-kernel profiler: brackets a launch with events when enabled.
+// Per-kernel profiler: brackets a launch with events when enabled.  Any thread may launch (a flow source prefetching
+// in a worker thread beside the compositor's thread): a scope owns its two events until it ends and the shared record
+// lists are only touched under the profiler's lock.
 struct ProfScope {
     explicit ProfScope(const char *name);
     ~ProfScope();
-    int slot;
+    const char *name;
+    hipEvent_t a, b;
 };
 bool prof_enabled();
 

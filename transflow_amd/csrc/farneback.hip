@@ -40,6 +40,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 
 #include "common.h"
@@ -3112,8 +3113,10 @@ struct tf_fb {
     bool download_pending[2] = {false, false};
     std::vector<long> slot_read_call;                  // the last call that read each slot's frame bytes (expanded it)
     long n_calls = 0;
+    int exact = -1;              // tf_fb_set_exact: 1 / 0 = this handle sums the box window in OpenCV's own order or not; -1 = as option "fb_exact_sums" says at each call
     tf_fb *lane_of = nullptr;    // tf_fb_create_lane: the handle whose frame slots these are
     int lanes = 0;               // ... and how many lanes read this handle's
+    bool destroy_with_lanes = false; // tf_fb_destroy came while lanes were alive: the last lane's destroy releases it
     bool use_initial() const { return (prm.flags & 4) != 0; }
     bool gaussian() const { return (prm.flags & 256) != 0; }
     // A3+A4 of one iteration as ONE kernel (k_flow_iter_pc: M never stored) on levels big enough to fill
@@ -3153,6 +3156,10 @@ struct tf_fb {
     }
 };
 
+// The exact mode is a property of the HANDLE (tf_fb_set_exact); a handle that was never told follows the process-wide
+// option, read at each call.
+static bool fb_exact(const tf_fb *fb) { return fb->exact >= 0 ? fb->exact != 0 : option(OPT_FB_EXACT_SUMS) != 0; }
+
 // read when a handle is created: option "fb_no_overlap" = 1 keeps everything on the library stream
 static bool fb_overlap_enabled() { return option(OPT_FB_NO_OVERLAP) == 0; }
 
@@ -3163,7 +3170,9 @@ static const char *lvl_name(const char *base, int k)
     const bool per_level = option(OPT_PROF_LEVELS) != 0;
     if (!per_level || k < 0)
         return base;
-    static std::map<std::string, std::string> names;
+    static std::map<std::string, std::string> names; // (entries are never erased: the strings stay where they are)
+    static std::mutex names_mu;                       // handles of several threads label their launches
+    std::lock_guard<std::mutex> lk(names_mu);
     std::string key = std::string(base) + ".k" + std::to_string(k);
     auto it = names.find(key);
     if (it == names.end())
@@ -3563,7 +3572,7 @@ static int fb_blur_solve(tf_fb *fb, int w, int h, int n_pairs, float2 *flow_out,
 {
     const int m = fb->prm.winsize / 2;
     const double scale = 1. / ((double)fb->prm.winsize * fb->prm.winsize);
-    if (option(OPT_FB_EXACT_SUMS)) { // OpenCV's own running sums, in its order (k_exact_vsum's note)
+    if (fb_exact(fb)) { // OpenCV's own running sums, in its order (k_exact_vsum's note)
         const size_t need = (size_t)n_pairs * 5 * w * h * sizeof(double);
         if (fb->exact_vsum.bytes < need && fb->exact_vsum.alloc(need) != TF_OK)
             return set_error(TF_ERR_HIP, "fb_exact_sums: no room for the column sums of %d pairs of %d x %d pixels (%zu bytes of doubles; "
@@ -3628,7 +3637,7 @@ static int launch_flow_iter(tf_fb *fb, int w, int h, int n_pairs, const float2 *
     if (up)
         f = *up;
     f.rmap = fb->rmap_dev;
-    if (option(OPT_FB_EXACT_SUMS)) {
+    if (fb_exact(fb)) {
         // fb_exact_sums on a large launch: the column sums of EVERY row straight from R0, R1 and the flow (the pre-pass
         // kernel with one segment, storing as it goes: M is never in memory), then the row walker.  4K x 32, level 0: 4.3 +
         // 2.7 ms against 3.3 + 3.1 + 2.8 through update-matrices (and 9.0 for an exact form of k_flow_iter_pc whose
@@ -3985,6 +3994,7 @@ static int fb_create(tf_fb **out, int width, int height, const tf_fb_params *par
         return fail(set_error(TF_ERR_HIP, "creating the handle's events and staging buffer failed"));
     if (share) {
         fb->lane_of = share;
+        fb->exact = share->exact;
         share->lanes++;
     }
     *out = fb;
@@ -4008,11 +4018,29 @@ TF_API int tf_fb_create_lane(tf_fb **out, tf_fb *first)
     return fb_create(out, first->W, first->H, &first->prm, first->slots, first->max_pairs, first);
 }
 
+// A handle whose frame slots lanes still read outlives its own tf_fb_destroy: it is released with the last of them
+// (the lanes' `frames` is first's memory, and their lane_of points at it).
 TF_API void tf_fb_destroy(tf_fb *fb)
 {
-    if (fb && fb->lane_of)
-        fb->lane_of->lanes--;
+    if (!fb)
+        return;
+    if (fb->lanes > 0) {
+        fb->destroy_with_lanes = true;
+        return;
+    }
+    tf_fb *first = fb->lane_of;
     delete fb;
+    if (first && --first->lanes == 0 && first->destroy_with_lanes)
+        delete first;
+}
+
+// Per-handle exactness (cv.py:479-490: one call, one result -- no state outside the handle decides what a call returns).
+TF_API int tf_fb_set_exact(tf_fb *fb, int mode)
+{
+    TF_REQUIRE(fb, "tf_fb_set_exact: null handle");
+    TF_REQUIRE(mode >= -1 && mode <= 1, "tf_fb_set_exact: mode %d (1: exact, 0: default, -1: as option fb_exact_sums says)", mode);
+    fb->exact = mode;
+    return TF_OK;
 }
 
 TF_API int tf_fb_level_count(tf_fb *fb, int *n_scales)
@@ -4145,7 +4173,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         TF_REQUIRE(prev_slots[i] >= 0 && prev_slots[i] < fb->slots && next_slots[i] >= 0 && next_slots[i] < fb->slots,
                    "tf_fb_calc_slots: pair %d uses a slot outside [0,%d)", i, fb->slots);
     TF_TRY(fb_check_fault(fb, "tf_fb_calc_slots (an earlier call)"));
-    if (!option(OPT_FB_EXACT_SUMS) && fb->exact_vsum.p && fb->prm.winsize / 2 != 0)
+    if (!fb_exact(fb) && fb->exact_vsum.p && fb->prm.winsize / 2 != 0)
         fb->exact_vsum.release(); // the exact mode's column sums (40 bytes per pixel and pair): not kept once it is off
     if (fb->pairs_pending) { // the previous call's copy out of the staging buffer (long done in practice)
         TF_HIP(hipEventSynchronize(fb->pairs_copied));
@@ -4298,7 +4326,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         // fb_exact_sums: column sums straight from R (k_flow_carry_pc<.., STORE>, one march per column) where many columns
         // stand side by side, through M in memory otherwise (4K: 7.0 against 9.3 ms per level-0 iteration with 32 pairs,
         // 2.9 against 2.5 with 8, 1.8 against 0.5 with one)
-        const bool exact_one_kernel = !option(OPT_FB_EXACT_SUMS) || fb->fused > 0 || (long)cdiv(L.W, 112) * n_pairs >= 560;
+        const bool exact_one_kernel = !fb_exact(fb) || fb->fused > 0 || (long)cdiv(L.W, 112) * n_pairs >= 560;
         const bool fused_here = fusable && !fb->gaussian() && exact_one_kernel && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
@@ -4395,7 +4423,14 @@ TF_API int tf_fb_get_flow_begin(tf_fb *fb, int pair, float *flow_out, int *token
     TF_REQUIRE(pair >= 0 && pair < fb->last_pairs, "tf_fb_get_flow_begin: pair %d was not computed by the last call", pair);
     TF_TRY(ensure_init());
     const int set = (fb->cur + fb->nsets - 1) % fb->nsets; // the last call's result set
-    TF_REQUIRE(!fb->download_pending[set], "tf_fb_get_flow_begin: the previous download of this result set has not been ended");
+    if (fb->download_pending[set]) {
+        // A handle with ONE result set in rotation (a single scale, or option fb_no_overlap): the download a streaming
+        // caller still holds is of this very set.  The call in between already waited for it on the device before it
+        // wrote the set again (tf_fb_calc_slots), so it is over or about to be: end it here; its tf_fb_get_flow_end then
+        // finds nothing left to wait for but this download.
+        TF_HIP(hipEventSynchronize(fb->download_done[set]));
+        fb->download_pending[set] = false;
+    }
     void *src;
     TF_TRY(tf_fb_flow_ptr(fb, pair, &src));
     TF_HIP(hipEventRecord(fb->result_ready[set], stream()));

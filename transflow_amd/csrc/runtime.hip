@@ -63,6 +63,7 @@ int side_stream(int which, hipStream_t *out)
 {
     TF_REQUIRE(which >= 0 && which <= 4, "side_stream: bad index");
     TF_TRY(ensure_init());
+    std::lock_guard<std::mutex> lk(g_mu); // handles are created from any thread
     if (!g_side[which]) {
         int least = 0, greatest = 0;
         TF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -147,6 +148,7 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 static bool g_prof = false;
+static std::mutex g_prof_mu; // g_prof_filter, g_recs, g_free_events, g_acc
 static std::string g_prof_filter;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free_events;
@@ -154,7 +156,7 @@ static std::map<std::string, std::pair<long, double>> g_acc;
 
 bool prof_enabled() { return g_prof; }
 
-static hipEvent_t get_event()
+static hipEvent_t get_event_locked()
 {
     if (!g_free_events.empty()) {
         hipEvent_t e = g_free_events.back();
@@ -166,7 +168,7 @@ static hipEvent_t get_event()
     return e;
 }
 
-static void prof_drain()
+static void prof_drain_locked()
 {
     if (g_recs.empty())
         return;
@@ -183,24 +185,29 @@ static void prof_drain()
     g_recs.clear();
 }
 
-ProfScope::ProfScope(const char *name) : slot(-1)
+ProfScope::ProfScope(const char *name_) : name(name_), a(nullptr), b(nullptr)
 {
     if (!g_prof)
         return;
-    if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str()))
-        return;
-    if (g_recs.size() >= 4096)
-        prof_drain();
-    ProfRec r{name, get_event(), get_event()};
-    (void)hipEventRecord(r.a, stream());
-    slot = (int)g_recs.size();
-    g_recs.push_back(r);
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str()))
+            return;
+        if (g_recs.size() >= 4096)
+            prof_drain_locked();
+        a = get_event_locked();
+        b = get_event_locked();
+    }
+    (void)hipEventRecord(a, stream());
 }
 
 ProfScope::~ProfScope()
 {
-    if (slot >= 0)
-        (void)hipEventRecord(g_recs[slot].b, stream());
+    if (!a)
+        return;
+    (void)hipEventRecord(b, stream());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_recs.push_back(ProfRec{name, a, b});
 }
 
 } // namespace tf
@@ -304,21 +311,24 @@ TF_API void tf_event_destroy(tf_event *ev)
 TF_API int tf_prof_enable(int on)
 {
     TF_TRY(ensure_init());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!on)
-        prof_drain();
+        prof_drain_locked();
     g_prof = on != 0;
     return TF_OK;
 }
 
 TF_API int tf_prof_set_filter(const char *substring)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_filter = substring ? substring : "";
     return TF_OK;
 }
 
 TF_API int tf_prof_reset(void)
 {
-    prof_drain();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain_locked();
     g_acc.clear();
     return TF_OK;
 }
@@ -326,7 +336,8 @@ TF_API int tf_prof_reset(void)
 TF_API int tf_prof_report(char *buf, size_t buf_size)
 {
     TF_REQUIRE(buf && buf_size > 0, "tf_prof_report: null buffer");
-    prof_drain();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain_locked();
     size_t off = 0;
     buf[0] = 0;
     for (auto &kv : g_acc) {

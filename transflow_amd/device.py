@@ -95,12 +95,18 @@ class ArrayPool:
 
     def take(self) -> np.ndarray:
         import sys
-        for a in self._arrays:
-            if sys.getrefcount(a) == 3:      # the list, the loop variable, getrefcount's argument
+        for a, root in self._arrays:
+            # nobody but the pool holds `a` or any view of its memory.  References counted: the pool's tuple, the loop
+            # variable, getrefcount's argument -- and for the owner of a page-locked array's memory also `a.base`.
+            if sys.getrefcount(a) == 3 and (root is None or sys.getrefcount(root) == 4):
                 return a
         a = pinned_empty(self.shape, self.dtype) if self.pinned else np.empty(self.shape, self.dtype)
+        # A page-locked array is itself a view (frombuffer -> reshape), and numpy points every view of a view at the
+        # array that owns the memory: a caller's `flow[..., 0]` references that hidden 1-D array, not `a`.  The pool
+        # watches both.
+        root = a.base if isinstance(a.base, np.ndarray) else None
         if len(self._arrays) < self.limit:
-            self._arrays.append(a)
+            self._arrays.append((a, root))
         return a
 
 

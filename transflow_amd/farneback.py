@@ -27,11 +27,15 @@ def _ptr(a: np.ndarray) -> C.c_void_p:
 class Farneback:
     def __init__(self, width: int, height: int, pyr_scale: float = 0.5, levels: int = 3, winsize: int = 15,
                  iterations: int = 3, poly_n: int = 5, poly_sigma: float = 1.2, flags: int = 0,
-                 frame_slots: int = 2, max_pairs: int = 1, device: int | None = None, lanes: int = 1):
+                 frame_slots: int = 2, max_pairs: int = 1, device: int | None = None, lanes: int = 1,
+                 exact: bool | None = None):
         """lanes = 2: calc_slots calls go alternately to two handles that share the frame slots and queue on the
         library's two call streams (tf_fb_create_lane), so consecutive batches are in flight together; results
         (get_flow, flow_ptr, post_process ...) are those of the latest call.  For callers that issue batch after
-        batch without reading each back first (the resident path); not with keep_expansions."""
+        batch without reading each back first (the resident path); not with keep_expansions.
+        exact: True / False = this handle's calls sum the box window in OpenCV's own order (flows bit-identical to the
+        CPU path's) or the default way, whatever other handles of the process do (tf_fb_set_exact); None = as the
+        process-wide option fb_exact_sums says at each call."""
         if lanes not in (1, 2):
             raise ValueError("lanes must be 1 or 2")
         self._lib = _lib.load()
@@ -52,6 +56,13 @@ class Farneback:
             self._handles.append(self._h2)
         self._calls = 0
         self._last = self._h   # the handle whose results the reading methods return
+        if exact is not None:
+            self.set_exact(exact)
+
+    def set_exact(self, exact: bool | None) -> None:
+        """tf_fb_set_exact on every lane: takes effect with the next call."""
+        for h in self._handles:
+            check(self._lib.tf_fb_set_exact(h, -1 if exact is None else int(bool(exact))))
 
     @property
     def _next(self):

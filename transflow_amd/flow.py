@@ -592,13 +592,10 @@ class HipFlowSource(FlowSource):
     def _handle(self):
         if self._fb is None:
             from .farneback import Farneback
-            # The library option is process-wide and read per call: this source states what its configuration says (on
-            # OR off) and close() puts back what it found.  (The reference forks the flow source into a process of its
-            # own, pipeline.py:56-64; in-process, two sources that disagree about exactness cannot be open together.)
-            from . import _lib
-            self._exact_before = _lib.get_option("fb_exact_sums")
-            _lib.set_option("fb_exact_sums", 1 if getattr(self.config, "hip_exact_sums", False) else 0)
-            self._fb = Farneback(self.width, self.height, device=self.device, **self.config.fb_kwargs())
+            # Exactness belongs to the handle (tf_fb_set_exact): this source states what its configuration says, on OR off,
+            # and touches nothing process-wide -- sources that disagree may be open together, in any threads.
+            self._fb = Farneback(self.width, self.height, device=self.device,
+                                 exact=bool(getattr(self.config, "hip_exact_sums", False)), **self.config.fb_kwargs())
             self._fb.keep_expansions(True)  # the frame that was "next" stays expanded for its turn as "prev"
             if getattr(self.config, "hip_prefetch", 0):
                 self._fb.async_io(True)     # the next frame up and the previous flow down beside this pair's kernels
@@ -749,10 +746,6 @@ class HipFlowSource(FlowSource):
             self._fb.close()
             self._fb = None
             self._pp = None
-            if getattr(self, "_exact_before", None) is not None:
-                from . import _lib
-                _lib.set_option("fb_exact_sums", self._exact_before)
-                self._exact_before = None
         else:
             FlowSource.close(self)
         self.provider.release()
