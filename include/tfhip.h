@@ -80,6 +80,22 @@ int tf_event_create(tf_event **ev);
 int tf_event_record(tf_event *ev);
 int tf_event_elapsed_ms(tf_event *start, tf_event *stop, float *ms); /* synchronises on stop */
 void tf_event_destroy(tf_event *ev);
+/* A flow that stays on the device between the flow source and the compositor (the seam transflow/pipeline.py:85-86,
+   326, 562-567 crosses with a pickled host array): the producer records an event behind the flow's last kernel on ITS
+   stream (tf_event_record), the consumer's stream waits for it on the device before its kernels read the flow
+   (tf_stream_wait_event: no host synchronisation), or the host waits for it before the memory is handed to another
+   process (tf_event_synchronize). */
+int tf_stream_wait_event(tf_event *ev);
+int tf_event_synchronize(tf_event *ev);
+/* The same seam across the reference's process boundary (pipeline.py:56-64: the flow source is a child process, its
+   items travel through a multiprocessing queue): a device allocation of this process (tf_dev_alloc) exported as 64
+   opaque bytes (hipIpcGetMemHandle), opened in the consumer's process (hipIpcOpenMemHandle; one mapping per allocation,
+   kept until tf_ipc_close) -- what crosses the queue is the 64 bytes instead of 66 MB per 4K flow.  The exporter
+   keeps the allocation alive and untouched until the consumer has read it. */
+#define TF_IPC_HANDLE_BYTES 64
+int tf_ipc_export(void *dev, void *handle_out);
+int tf_ipc_open(const void *handle, void **dev);
+int tf_ipc_close(void *dev);
 
 /* Per-kernel timing: when enabled every launch is bracketed by HIP events on the
    library stream.  tf_prof_report writes lines "name count total_ms" into buf. */

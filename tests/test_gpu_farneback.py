@@ -733,7 +733,7 @@ def assert_within_tolerance(got, ref, what):
     the oracle.  Rounds 2 and 3 excused a few pixels near the frame edges: FarnebackUpdateMatrices' in-frame test is
     discontinuous in the flow, and the ~1e-7 by which per-segment window sums differed from OpenCV's image-long running
     sums decided it where a sample point sat within float resolution of the frame's last row / column.  The marching
-    kernels now keep OpenCV's column sums (ColumnCarry in farneback.hip) and compute M without FMA contraction; what is
+    kernels now keep OpenCV's column sums (ColumnCarry in fb_iterate.hip) and compute M without FMA contraction; what is
     left between them and the oracle is the association of double additions.  Returns the number of pixels that differ
     from the oracle at all."""
     d = np.abs(got - ref).max(axis=2)

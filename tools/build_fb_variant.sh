@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage: tools/build_fb_variant.sh <name> [-DMACRO ...]: only farneback.hip is recompiled, the other objects
-# come from build_abl/base (made on first use)  ->  build_abl/libtfhip_<name>.so
+# usage: tools/build_fb_variant.sh <name> [-DMACRO ...]: the units of the Farneback path (farneback.hip, fb_*.hip) are
+# recompiled with the macros (in parallel), the other objects come from build_abl/_common (made on first use)
+#   ->  build_abl/libtfhip_<name>.so   (TFHIP_LIBRARY=build_abl/libtfhip_<name>.so picks it: transflow_amd/_lib.py)
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../transflow_amd/csrc"
@@ -8,8 +9,11 @@ out=../../build_abl
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result -DTF_EXPERIMENT"
 mkdir -p $out/_common $out/$name
 for f in runtime remap flowops batch; do
-  if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ]; then $CC -c $f.hip -o $out/_common/$f.o; fi
+  if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ]; then $CC -c $f.hip -o $out/_common/$f.o & fi
 done
-$CC "$@" -c farneback.hip -o $out/$name/farneback.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libtfhip_$name.so $out/_common/runtime.o $out/_common/remap.o $out/_common/flowops.o $out/_common/batch.o $out/$name/farneback.o -ldl
+FB="farneback fb_pyramid fb_matrices fb_iterate fb_exact fb_postprocess fb_stages"
+for f in $FB; do $CC "$@" -c $f.hip -o $out/$name/$f.o & done
+wait
+objs=""; for f in $FB; do objs="$objs $out/$name/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libtfhip_$name.so $out/_common/runtime.o $out/_common/remap.o $out/_common/flowops.o $out/_common/batch.o $objs -ldl
 echo built $out/libtfhip_$name.so

@@ -67,6 +67,11 @@ PROTOTYPES = {
     "tf_event_record": (_I, [_P]),
     "tf_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
     "tf_event_destroy": (None, [_P]),
+    "tf_stream_wait_event": (_I, [_P]),
+    "tf_event_synchronize": (_I, [_P]),
+    "tf_ipc_export": (_I, [_P, _P]),
+    "tf_ipc_open": (_I, [_P, _PP]),
+    "tf_ipc_close": (_I, [_P]),
     "tf_prof_enable": (_I, [_I]),
     "tf_prof_set_filter": (_I, [C.c_char_p]),
     "tf_prof_reset": (_I, []),

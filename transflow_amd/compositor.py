@@ -275,7 +275,18 @@ class HipCompositor:
         if self._frame_pool is None:
             from .device import ArrayPool
             self._frame_pool = ArrayPool((self.height, self.width, 3), np.uint8, pinned=True)
-        return comp.download(self._frame_pool.take())
+        frame = comp.download(self._frame_pool.take())
+        for layer in self.layers:
+            # updates from flows that stayed on the device (DeviceFlow) could not raise when they were queued: the
+            # reference's IndexError for a flow vector that leaves the frame (movement.py:33, 39) comes here, at the
+            # first synchronisation behind them
+            dev = getattr(layer, "_dev", None)
+            if dev is not None and getattr(dev, "device_updates", 0):
+                dev.device_updates = 0
+                if dev.out_of_frame():
+                    raise IndexError("a rounded flow vector left the frame in an update since the last render "
+                                     "(run post_process first)")
+        return frame
 
     @classmethod
     def from_args(cls, height: int, width: int, layer_configs, background_color: str = "#ffffff", rng: str = "numpy"):

@@ -100,6 +100,12 @@ class FlowConfig:
         # library stream of its own (what the reference gets from running the source in a child process behind a
         # queue, pipeline.py:56-64, for a source used in-process).  Its position attributes then run ahead by as much.
         self.hip_prefetch = int(kwargs.pop("hip_prefetch", 0) or 0)
+        # "hip_device_flows": true -- the source yields DeviceFlow objects (transflow_amd/deviceflow.py): flows that stay in
+        # HBM until something reads them on the host, and that HipCompositor.update takes by device address (no 66 MB per
+        # 4K frame down the link and up again across pipeline.py:562-567).  "ipc": the same, and through a multiprocessing
+        # queue (pipeline.py:85-86) such a flow travels as a 64-byte HIP IPC handle instead of the pickled array.
+        v = kwargs.pop("hip_device_flows", None)
+        self.hip_device_flows = "ipc" if isinstance(v, str) and v.lower() == "ipc" else parse_bool_arg(v, False)
         self.extra = dict(kwargs)  # hs_*, lk_*, show_window ...: not used by this backend
 
     def fb_kwargs(self) -> dict:
@@ -115,6 +121,8 @@ class FlowConfig:
             d["hip_exact_sums"] = True
         if self.hip_prefetch:
             d["hip_prefetch"] = self.hip_prefetch
+        if self.hip_device_flows:
+            d["hip_device_flows"] = self.hip_device_flows
         return d
 
     def to_file(self, path: str):

@@ -1,0 +1,1273 @@
+// A1 + A2 of the Farneback path: the level images (pre-blur + resize) and the polynomial expansion, with the fused forms
+// for the full-resolution and the half-size level (optflowgf.cpp FarnebackPrepareGaussian /
+// FarnebackPolyExp and imgproc's GaussianBlur + resize as calcOpticalFlowFarneback calls them, cv.py:479-490).
+#include "fb_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// A1: level image = resize(GaussianBlur(float(frame)), level size), one kernel per level.
+// A block produces a tile of TWo x THo level pixels.  It stages the uint8 source region
+// those pixels depend on (with the blur's halo, REFLECT_101 applied while loading) in
+// LDS, runs the row pass only at the two source columns each output column interpolates
+// between, then the column pass at the two source rows of each output row, then the two
+// lerps.  Tap order and float rounding are those of the CPU filters (row pass: paired
+// taps for ksz <= 5, left-to-right otherwise; column pass: centre, then pairs outwards).
+// In the row pass lanes walk source ROWS, so the byte reads of one instruction hit
+// different LDS banks (pitch/4 is odd).
+// ---------------------------------------------------------------------------------
+// resize.cpp's INTER_LINEAR source coordinate for destination index d (the statement order
+// of the host's make_lerp: double product and difference, one rounding each, then float).
+__device__ __forceinline__ int lerp_coord(int d, double scale, int src, bool zero_at_edges, float &frac)
+{
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (zero_at_edges) {
+        if (s < 0) {
+            f = 0.f;
+            s = 0;
+        }
+        if (s >= src - 1) {
+            f = 0.f;
+            s = src - 1;
+        }
+    }
+    frac = f;
+    return s;
+}
+
+__global__ void __launch_bounds__(256)
+k_level_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W,
+              int H, int Wk, int Hk, const float *__restrict__ kern, int ksz, ImgTile tl)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    uint8_t *sS = s_raw;                                                     // [LH][pitch] source bytes
+    float *sR = reinterpret_cast<float *>(s_raw + (size_t)tl.LH * tl.pitch); // [LH][2*TWo] row-pass values
+    float *sK = sR + (size_t)tl.LH * tl.rstride;                             // [ksz] blur taps
+    __shared__ int sX[128], sY[32];     // source column / row of each output column / row of the tile
+    __shared__ float sFx[128], sFy[32]; // and the lerp fractions
+    const int r = ksz >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < ksz; i += blockDim.x)
+        sK[i] = kern[i];
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const int dx0 = blockIdx.x * tl.TWo, dy0 = blockIdx.y * tl.THo;
+    const int ndx = min(tl.TWo, Wk - dx0), ndy = min(tl.THo, Hk - dy0);
+    float ftmp;
+    int sx_first, sx_last, sy_first, sy_last;
+    if (tl.same_size) { // resize of equal sizes is a copy: source == destination coordinates
+        sx_first = dx0;
+        sx_last = dx0 + ndx - 1;
+        sy_first = dy0;
+        sy_last = dy0 + ndy - 1;
+    } else {
+        sx_first = lerp_coord(dx0, tl.scale_x, W, true, ftmp);
+        sx_last = lerp_coord(dx0 + ndx - 1, tl.scale_x, W, true, ftmp);
+        sy_first = lerp_coord(dy0, tl.scale_y, H, false, ftmp);
+        sy_last = lerp_coord(dy0 + ndy - 1, tl.scale_y, H, false, ftmp);
+        if (threadIdx.x < ndx) {
+            float f;
+            sX[threadIdx.x] = lerp_coord(dx0 + threadIdx.x, tl.scale_x, W, true, f);
+            sFx[threadIdx.x] = f;
+        } else if (threadIdx.x >= 128 && threadIdx.x - 128 < ndy) {
+            float f;
+            sY[threadIdx.x - 128] = lerp_coord(dy0 + threadIdx.x - 128, tl.scale_y, H, false, f);
+            sFy[threadIdx.x - 128] = f;
+        }
+    }
+    // staged columns start at a multiple of 4 so interior tiles can be copied as dwords
+    const int x_lo = (sx_first - r) & ~3, x_hi = min(sx_last + 1, W - 1) + r;
+    const int y_lo = clampi(sy_first, 0, H - 1) - r, y_hi = clampi(sy_last + 1, 0, H - 1) + r;
+    const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
+    // ---- phase 1: stage the source region.  Each wave owns rows wave, wave+4, ...; loads are
+    // issued eight rows at a time so their latencies overlap.
+    constexpr int U = 8;
+    const bool small_halo = r < H && r < W; // one reflection is enough
+    const bool dwords = (W & 3) == 0 && x_lo >= 0 && x_lo + ((ncols + 3) & ~3) <= W;
+    if (dwords) {
+        const int nq = (ncols + 3) >> 2;
+        for (int c = lane; c < nq; c += 64) {
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = *reinterpret_cast<const uint32_t *>(
+                            src + (size_t)(small_halo ? reflect101_once(y_lo + ry, H) : reflect101(y_lo + ry, H)) * W + x_lo + 4 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        *reinterpret_cast<uint32_t *>(sS + ry * tl.pitch + 4 * c) = v[u];
+                }
+            }
+        }
+    } else {
+        for (int c = lane; c < ncols; c += 64) {
+            const int x = reflect101(x_lo + c, W);
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint8_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = src[(size_t)reflect101(y_lo + ry, H) * W + x];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        sS[ry * tl.pitch + c] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: row pass at the needed columns.  With many staged rows the lanes walk rows
+    // (conflict-free byte reads); with few (small kernels) they walk output columns.
+    // A copy-sized level only needs column sx of each output (even slots).
+    const int ostep = tl.same_size ? 2 : 1;
+    const int no = 2 * ndx / ostep;
+    const bool lanes_on_rows = nrows >= 48;
+    const int n_a = lanes_on_rows ? nrows : no, n_b = lanes_on_rows ? no : nrows;
+    const float k0 = sK[0], kc = sK[r], kc1 = ksz >= 3 ? sK[r + 1] : 0.f, kc2 = ksz >= 5 ? sK[r + 2] : 0.f;
+    if (lanes_on_rows && ksz > 5) {
+        // long kernels: a lane owns one staged row and four output columns at a time, so four
+        // independent left-to-right sums are in flight and each tap is fetched once for the four
+        // work item = (chunk of 64 staged rows, group of 4 output columns), dealt round-robin to
+        // the four waves so none idles when a tile has few column groups
+        const int ngroups = (no + 3) >> 2, nchunks = (nrows + 63) >> 6;
+        for (int item = wave; item < ngroups * nchunks; item += 4) {
+            const int b_ = item % ngroups, ry = (item / ngroups) * 64 + lane;
+            // the four columns are two interpolation pairs (sx, sx+1): base columns A and B
+            const int sxA = __builtin_amdgcn_readfirstlane(sX[min(4 * b_, no - 1) >> 1]);
+            const int sxB = __builtin_amdgcn_readfirstlane(sX[min(4 * b_ + 2, no - 1) >> 1]);
+            if (sxA + 1 < W && sxB + 1 < W) {
+                // Column sx+1 reads the byte stream of column sx one tap later, so each pair shares one
+                // stream: aligned dword reads (conflict-free: pitch/4 is odd) re-aligned to the
+                // stream's first byte, each byte converted once, and the two streams carried as the
+                // halves of float pairs so that a tap costs two packed multiplies and two packed adds
+                // for four sums.  Every sum still adds its taps left to right.
+                const int a0 = sxA - x_lo - r, b0 = sxB - x_lo - r;
+                const int da = a0 >> 2, db = b0 >> 2;
+                const unsigned sa = a0 & 3, sb = b0 & 3;
+                if (ry < nrows) {
+                    const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + ry * tl.pitch);
+                    uint32_t loA = q32[da], loB = q32[db], hiA = q32[da + 1], hiB = q32[db + 1];
+                    uint32_t wA = __builtin_amdgcn_alignbyte(hiA, loA, sa), wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+                    f32x2 p0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+                    f32x2 p1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+                    f32x2 p2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+                    f32x2 p3 = {(float)(wA >> 24), (float)(wB >> 24)};
+                    f32x2 acc0, acc1; // {A, B} and {A+1, B+1}
+                    int i = 0, t = 2;
+                    for (; i + 4 <= ksz; i += 4, t++) {
+                        loA = hiA;
+                        loB = hiB;
+                        hiA = q32[da + t];
+                        hiB = q32[db + t];
+                        wA = __builtin_amdgcn_alignbyte(hiA, loA, sa);
+                        wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+                        const f32x2 c0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+                        const f32x2 c1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+                        const f32x2 c2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+                        const f32x2 c3 = {(float)(wA >> 24), (float)(wB >> 24)};
+                        const float t0 = sK[i], t1 = sK[i + 1], t2 = sK[i + 2], t3 = sK[i + 3];
+                        if (i == 0) {
+                            acc0 = t0 * p0;
+                            acc1 = t0 * p1;
+                        } else {
+                            acc0 += t0 * p0;
+                            acc1 += t0 * p1;
+                        }
+                        acc0 += t1 * p1;
+                        acc1 += t1 * p2;
+                        acc0 += t2 * p2;
+                        acc1 += t2 * p3;
+                        acc0 += t3 * p3;
+                        acc1 += t3 * c0;
+                        p0 = c0;
+                        p1 = c1;
+                        p2 = c2;
+                        p3 = c3;
+                    }
+                    if (i < ksz) { // up to three taps left; they need p0..p3 only
+                        float tt = sK[i];
+                        acc0 += tt * p0;
+                        acc1 += tt * p1;
+                        if (i + 1 < ksz) {
+                            tt = sK[i + 1];
+                            acc0 += tt * p1;
+                            acc1 += tt * p2;
+                        }
+                        if (i + 2 < ksz) {
+                            tt = sK[i + 2];
+                            acc0 += tt * p2;
+                            acc1 += tt * p3;
+                        }
+                    }
+                    float *out = sR + ry * tl.rstride + 4 * b_;
+                    out[0] = acc0.x;
+                    out[1] = acc1.x;
+                    if (4 * b_ + 2 < no) {
+                        out[2] = acc0.y;
+                        out[3] = acc1.y;
+                    }
+                }
+                continue;
+            }
+            // a pair at the right image border (sx + 1 clamps to sx): plain per-column streams
+            int cofs[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int o = min(4 * b_ + j, no - 1);
+                int sx = sX[o >> 1];
+                cofs[j] = ((o & 1) ? min(sx + 1, W - 1) : sx) - x_lo - r;
+            }
+            if (ry < nrows) {
+                const uint8_t *q = sS + ry * tl.pitch;
+                float acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[j] = k0 * (float)q[cofs[j]];
+#pragma unroll 4
+                for (int i = 1; i < ksz; i++) {
+                    const float t = sK[i];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[j] += t * (float)q[cofs[j] + i];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * b_ + j < no)
+                        sR[ry * tl.rstride + 4 * b_ + j] = acc[j];
+            }
+        }
+    } else {
+    for (int b_ = wave; b_ < n_b; b_ += 4) {
+        for (int a_ = lane; a_ < n_a; a_ += 64) {
+            const int ry = lanes_on_rows ? a_ : b_, o = (lanes_on_rows ? b_ : a_) * ostep;
+            int sx = tl.same_size ? dx0 + (o >> 1) : sX[o >> 1];
+            int col = (o & 1) ? min(sx + 1, W - 1) : sx;
+            const uint8_t *p = sS + ry * tl.pitch + (col - x_lo); // tap i sits at p[i - r]
+            float acc;
+            if (ksz == 3) {
+                acc = (float)p[0] * kc + ((float)p[-1] + (float)p[1]) * kc1;
+            } else if (ksz == 5) {
+                acc = (float)p[0] * kc + ((float)p[-1] + (float)p[1]) * kc1 + ((float)p[-2] + (float)p[2]) * kc2;
+            } else {
+                const uint8_t *q = p - r;
+                acc = k0 * (float)q[0];
+                int i = 1;
+                for (; i + 3 < ksz; i += 4) { // same left-to-right order, four taps per trip
+                    float t0 = sK[i] * (float)q[i], t1 = sK[i + 1] * (float)q[i + 1];
+                    float t2 = sK[i + 2] * (float)q[i + 2], t3 = sK[i + 3] * (float)q[i + 3];
+                    acc += t0;
+                    acc += t1;
+                    acc += t2;
+                    acc += t3;
+                }
+                for (; i < ksz; i++)
+                    acc += sK[i] * (float)q[i];
+            }
+            sR[ry * tl.rstride + (tl.same_size ? (o >> 1) : o)] = acc;
+        }
+    }
+    }
+    __syncthreads();
+    // ---- phase 3: column pass at the needed rows, then the lerps
+    float *dst = img + (size_t)pi * Wk * Hk;
+    const int st = tl.rstride;
+    const int cs = tl.same_size ? 1 : 2; // row-pass slots per output column
+    for (int idx = threadIdx.x; idx < (ndy << tl.tw_shift); idx += blockDim.x) {
+        const int ty = idx >> tl.tw_shift, tx = idx & (tl.TWo - 1);
+        if (tx >= ndx)
+            continue;
+        int dx = dx0 + tx, dy = dy0 + ty;
+        const int sy = tl.same_size ? dy : sY[ty];
+        int row0 = clampi(sy, 0, H - 1) - y_lo, row1 = clampi(sy + 1, 0, H - 1) - y_lo;
+        const float *c0 = sR + row0 * st + cs * tx;
+        const float *c1 = sR + row1 * st + cs * tx;
+        float v00 = kc * c0[0];
+        for (int i = 1; i <= r; i++)
+            v00 += sK[r + i] * (c0[i * st] + c0[-i * st]);
+        float out;
+        if (tl.same_size) {
+            out = v00;
+        } else {
+            float v01 = kc * c0[1];
+            for (int i = 1; i <= r; i++)
+                v01 += sK[r + i] * (c0[i * st + 1] + c0[-i * st + 1]);
+            float v10 = v00, v11 = v01;
+            if (row1 != row0) {
+                v10 = kc * c1[0];
+                v11 = kc * c1[1];
+                for (int i = 1; i <= r; i++) {
+                    v10 += sK[r + i] * (c1[i * st] + c1[-i * st]);
+                    v11 += sK[r + i] * (c1[i * st + 1] + c1[-i * st + 1]);
+                }
+            }
+            const float fx = sFx[tx], fy = sFy[ty];
+            float h0, h1;
+            if (sX[tx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+                h0 = v00;
+                h1 = v10;
+            } else {
+                h0 = v00 * (1.f - fx) + v01 * fx;
+                h1 = v10 * (1.f - fx) + v11 * fx;
+            }
+            out = h0 * (1.f - fy) + h1 * fy;
+        }
+        dst[(size_t)dy * Wk + dx] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// A1 for the levels with long blur kernels (ksz >= 15: scale 1/8 and coarser), as two kernels.
+// One tile of such a level depends on a frame region of (tile * scale + ksz)^2 bytes, so
+// k_level_image's tiles shrink to a few dozen outputs and its fixed costs per workgroup dominate.
+// Here the row pass runs over whole frame rows (k_level_rowpass: every lane busy, the frame read
+// once) into a [H][2*Wk] float plane per image, and the column pass + both lerps read that plane
+// through an LDS tile (k_level_colpass).  Same statements in the same order as k_level_image:
+// row pass left to right, column pass centre then pairs outwards, horizontal then vertical lerp.
+// ---------------------------------------------------------------------------------
+// lanes = R rows x (64/R) groups of two interpolation pairs; with the row pitch = 1 (mod R) dwords and
+// the groups s/2 dwords apart the 64 aligned-dword reads of one instruction fall in 64 banks.  One launch
+// serves every split level: the frame rows are staged once (margin of the longest kernel) and each level
+// runs its own taps over them into its own plane.
+struct RowPassLevel {
+    float *rowf;        // [image][H][NC]
+    const int *colsrc;  // [NC]
+    const float *kern;  // [ksz]
+    int NC, ksz, rshift;
+};
+struct RowPassArgs {
+    int n;
+    RowPassLevel lv[RP_MAX_LEVELS];
+};
+
+__global__ void __launch_bounds__(256)
+k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, int W, int H, RowPassArgs args, int RB,
+                int pitch, int r4, int rmax)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rp[];
+    uint8_t *sS = s_rp;                                                   // [RB][pitch]: column c at byte r4 + c
+    float *sKall = reinterpret_cast<float *>(s_rp + (size_t)RB * pitch);  // the levels' taps, one after the other
+    const int pi = blockIdx.y;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const int y0 = blockIdx.x * RB, nrows = min(RB, H - y0);
+    {
+        int base = 0;
+        for (int l = 0; l < args.n; l++) {
+            for (int i = threadIdx.x; i < args.lv[l].ksz; i += 256)
+                sKall[base + i] = args.lv[l].kern[i];
+            base += args.lv[l].ksz;
+        }
+    }
+    // stage nrows frame rows: the interior as dwords (W % 4 == 0 is required by the host), rmax reflected bytes each side
+    const int nq = W >> 2;
+    for (int idx = threadIdx.x; idx < nrows * nq; idx += 256) {
+        const int i = idx / nq, c = idx - i * nq;
+        *reinterpret_cast<uint32_t *>(sS + i * pitch + r4 + 4 * c) =
+            *reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + i) * W + 4 * c);
+    }
+    for (int idx = threadIdx.x; idx < nrows * 2 * rmax; idx += 256) {
+        const int i = idx / (2 * rmax), j = idx - i * 2 * rmax;
+        const int c = j < rmax ? j - rmax : W + (j - rmax); // -rmax..-1, W..W+rmax-1
+        sS[i * pitch + r4 + c] = src[(size_t)(y0 + i) * W + reflect101(c, W)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int kbase = 0;
+    for (int l = 0; l < args.n; l++) {
+        const RowPassLevel &L = args.lv[l];
+        const float *sK = sKall + kbase;
+        kbase += L.ksz;
+        const int ksz = L.ksz, r = ksz >> 1, NC = L.NC, rshift = L.rshift;
+        const int R = 1 << rshift, G = 64 >> rshift;
+        const int li = lane & (R - 1), lg = lane >> rshift;
+        const int ngroups = (NC + 3) >> 2;
+        const int n_rb = (nrows + R - 1) >> rshift, n_gb = (ngroups + G - 1) / G;
+        for (int item = wave; item < n_rb * n_gb; item += 4) {
+            const int gb = item % n_gb, rb = item / n_gb;
+            const int row = rb * R + li, grp = gb * G + lg;
+            if (row >= nrows || grp >= ngroups)
+                continue;
+            const int oA = 4 * grp, oB = min(4 * grp + 2, NC - 2);
+            const int cA = L.colsrc[oA], cB = L.colsrc[oB];
+            const bool dupA = L.colsrc[oA + 1] == cA, dupB = L.colsrc[oB + 1] == cB; // pair at the right frame border: sx+1 clamps to sx
+            const int a0 = r4 + cA - r, b0 = r4 + cB - r;
+            const int da = a0 >> 2, db = b0 >> 2;
+            const unsigned sa = a0 & 3, sb = b0 & 3;
+            const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + row * pitch);
+            uint32_t loA = q32[da], loB = q32[db], hiA = q32[da + 1], hiB = q32[db + 1];
+            uint32_t wA = __builtin_amdgcn_alignbyte(hiA, loA, sa), wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+            f32x2 p0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+            f32x2 p1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+            f32x2 p2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+            f32x2 p3 = {(float)(wA >> 24), (float)(wB >> 24)};
+            f32x2 acc0, acc1; // {A, B} and {A+1, B+1}
+            int i = 0, t = 2;
+            for (; i + 4 <= ksz; i += 4, t++) {
+                loA = hiA;
+                loB = hiB;
+                hiA = q32[da + t];
+                hiB = q32[db + t];
+                wA = __builtin_amdgcn_alignbyte(hiA, loA, sa);
+                wB = __builtin_amdgcn_alignbyte(hiB, loB, sb);
+                const f32x2 c0 = {(float)(wA & 0xff), (float)(wB & 0xff)};
+                const f32x2 c1 = {(float)((wA >> 8) & 0xff), (float)((wB >> 8) & 0xff)};
+                const f32x2 c2 = {(float)((wA >> 16) & 0xff), (float)((wB >> 16) & 0xff)};
+                const f32x2 c3 = {(float)(wA >> 24), (float)(wB >> 24)};
+                const float t0 = sK[i], t1 = sK[i + 1], t2 = sK[i + 2], t3 = sK[i + 3];
+                if (i == 0) {
+                    acc0 = t0 * p0;
+                    acc1 = t0 * p1;
+                } else {
+                    acc0 += t0 * p0;
+                    acc1 += t0 * p1;
+                }
+                acc0 += t1 * p1;
+                acc1 += t1 * p2;
+                acc0 += t2 * p2;
+                acc1 += t2 * p3;
+                acc0 += t3 * p3;
+                acc1 += t3 * c0;
+                p0 = c0;
+                p1 = c1;
+                p2 = c2;
+                p3 = c3;
+            }
+            if (i < ksz) { // up to three taps left; they need p0..p3 only
+                float tt = sK[i];
+                acc0 += tt * p0;
+                acc1 += tt * p1;
+                if (i + 1 < ksz) {
+                    tt = sK[i + 1];
+                    acc0 += tt * p1;
+                    acc1 += tt * p2;
+                }
+                if (i + 2 < ksz) {
+                    tt = sK[i + 2];
+                    acc0 += tt * p2;
+                    acc1 += tt * p3;
+                }
+            }
+            // a clamped pair reads the same column twice: the same sum
+            if (dupA)
+                acc1.x = acc0.x;
+            if (dupB)
+                acc1.y = acc0.y;
+            float *out = L.rowf + ((size_t)pi * H + y0 + row) * NC + 4 * grp;
+            out[0] = acc0.x;
+            out[1] = acc1.x;
+            if (4 * grp + 2 < NC) {
+                out[2] = acc0.y;
+                out[3] = acc1.y;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_level_colpass(const float *__restrict__ rowf, float *__restrict__ img, int W, int H, int Wk, int Hk, int NC,
+                const float *__restrict__ kern, int ksz, const int *__restrict__ xofs, const float *__restrict__ xfrac,
+                const int *__restrict__ yofs, const float *__restrict__ yfrac)
+{
+    // One thread per level pixel, straight from the row-pass plane (round 2; the LDS-tiled form spent its time on
+    // LDS reads, one per multiply-add): a pixel's two source columns sit side by side in the plane (one 8-byte
+    // load per row, consecutive lanes consecutive pairs) and its two source rows sy, sy + 1 are one row apart, so
+    // the taps of the second are the first's shifted by one: tap i of row sy needs rows sy + i and sy - i, tap i
+    // of row sy + 1 needs sy + i + 1 and sy - i + 1 -- the upper one is loaded for the next tap of row sy anyway,
+    // the lower one was the previous tap's.  Two loads and six packed operations per tap; the statements and
+    // their order are k_level_image's (centre first, then pairs outwards; both lerps).
+    extern __shared__ float s_taps[]; // [ksz]
+    const int r = ksz >> 1;
+    for (int i = threadIdx.x; i < ksz; i += 256)
+        s_taps[i] = kern[i];
+    __syncthreads();
+    const int pi = blockIdx.z;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= Wk || dy >= Hk)
+        return;
+    const float *plane = rowf + (size_t)pi * H * NC + 2 * dx;
+    // rows at most r + 1 outside the frame: one reflection does where the frame is taller than that (no loop around
+    // the loads then: the whole column is written twice, under one uniform branch); the taps go four at a time, their
+    // eight rows loaded before the first is used
+    const int sy = yofs[dy];
+    const int row0 = clampi(sy, 0, H - 1), row1 = clampi(sy + 1, 0, H - 1);
+    float2u v0, v1;
+    auto column = [&](auto reflect) {
+        auto row = [&](int y) { return *reinterpret_cast<const float2u *>(plane + (size_t)reflect(y) * NC); };
+        const float kc = s_taps[r];
+        const float2u c0 = row(row0);
+        float2u up = row(row0 + 1);   // U[1]
+        float2u down_prev = c0;       // D[0]
+        v0 = kc * c0;
+        v1 = kc * up; // row1 == row0 + 1 wherever v1 is used: its centre is U[1]
+        int i = 1;
+        for (; i + 3 <= r; i += 4) {
+            float2u dn[4], un[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dn[q] = row(row0 - (i + q));     // D[i + q]
+                un[q] = row(row0 + (i + q) + 1); // U[i + q + 1]
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float k = s_taps[r + i + q];
+                v0 += k * (up + dn[q]);
+                v1 += k * (un[q] + down_prev);
+                up = un[q];
+                down_prev = dn[q];
+            }
+        }
+        for (; i <= r; i++) {
+            const float k = s_taps[r + i];
+            const float2u down = row(row0 - i);     // D[i]
+            const float2u up_next = row(row0 + i + 1); // U[i + 1]
+            v0 += k * (up + down);
+            v1 += k * (up_next + down_prev);
+            up = up_next;
+            down_prev = down;
+        }
+    };
+    if (H > r + 2)
+        column([&](int y) { return reflect101_once(y, H); });
+    else
+        column([&](int y) { return reflect101(y, H); });
+    if (row1 == row0) // both source rows clamp to the same frame row (above the first / below the last)
+        v1 = v0;
+    const float fx = xfrac[dx], fy = yfrac[dy];
+    float h0, h1;
+    if (xofs[dx] >= W - 1) { // resize.cpp: dx >= xmax copies S[sx]
+        h0 = v0.x;
+        h1 = v1.x;
+    } else {
+        h0 = v0.x * (1.f - fx) + v0.y * fx;
+        h1 = v1.x * (1.f - fx) + v1.y * fx;
+    }
+    img[(size_t)pi * Wk * Hk + (size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
+}
+
+// ---------------------------------------------------------------------------------
+// A2: FarnebackPolyExp.  Tile 64x16 outputs; LDS holds the image tile with an
+// n-pixel halo, then the three vertical-pass planes; the horizontal pass runs in
+// double.  Clamped loads reproduce OpenCV's row clamping (vertical) and its
+// replication of the edge triple (horizontal).
+// ---------------------------------------------------------------------------------
+constexpr int PX_TW = 64, PX_TH = 16;
+
+__global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
+{
+    extern __shared__ float s_mem[];
+    const int n = pc.n;
+    const int LW = PX_TW + 2 * n;     // columns incl. halo
+    const int LH = PX_TH + 2 * n;     // rows incl. halo
+    float *sI = s_mem;                // [LH][LW]
+    float *sT = s_mem + LH * LW;      // [3][PX_TH][LW]
+    const int pi = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *src = img + (size_t)pi * Nk;
+    const int x0 = blockIdx.x * PX_TW, y0 = blockIdx.y * PX_TH;
+    for (int idx = threadIdx.x; idx < LH * LW; idx += blockDim.x) {
+        int ry = idx / LW, cx = idx % LW;
+        int y = clampi(y0 - n + ry, 0, Hk - 1), x = clampi(x0 - n + cx, 0, Wk - 1);
+        sI[idx] = src[(size_t)y * Wk + x];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < PX_TH * LW; idx += blockDim.x) {
+        int ty = idx / LW, cx = idx % LW;
+        int y = y0 + ty;
+        // rows y-k / y+k are clamped to the image: compute their LDS row from the clamped index
+        const float c = sI[(ty + n) * LW + cx];
+        float t0 = c * pc.g[0], t1 = 0.f, t2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            int ya = max(y - k, 0), yb = min(y + k, Hk - 1);
+            // LDS row of image row yy is (yy - (y0 - n)); clamped loads make out-of-image halo
+            // rows equal to the edge row, so indexing by ty works when y itself is in range
+            float a = sI[(ya - y0 + n) * LW + cx];
+            float b = sI[(yb - y0 + n) * LW + cx];
+            float p = a + b;
+            t0 = t0 + pc.g[k] * p;
+            t1 = t1 + pc.xg[k] * (b - a);
+            t2 = t2 + pc.xxg[k] * p;
+        }
+        if (y >= Hk) {
+            t0 = t1 = t2 = 0.f;
+        }
+        sT[(0 * PX_TH + ty) * LW + cx] = t0;
+        sT[(1 * PX_TH + ty) * LW + cx] = t1;
+        sT[(2 * PX_TH + ty) * LW + cx] = t2;
+    }
+    __syncthreads();
+    float *dst = R + (size_t)pi * 5 * Nk;
+    for (int idx = threadIdx.x; idx < PX_TH * PX_TW; idx += blockDim.x) {
+        int ty = idx / PX_TW, cx = idx % PX_TW;
+        int x = x0 + cx, y = y0 + ty;
+        if (x >= Wk || y >= Hk)
+            continue;
+        const float *T0 = sT + (0 * PX_TH + ty) * LW + cx + n;
+        const float *T1 = sT + (1 * PX_TH + ty) * LW + cx + n;
+        const float *T2 = sT + (2 * PX_TH + ty) * LW + cx + n;
+        float g0 = pc.g[0];
+        double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            double tg = T0[k] + T0[-k];
+            g0 = pc.g[k];
+            b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+            b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
+            b2 += (T0[k] - T0[-k]) * pc.xg[k];
+            b3 += (T1[k] + T1[-k]) * g0;
+            b6 += (T1[k] - T1[-k]) * pc.xg[k];
+            b5 += (T2[k] + T2[-k]) * g0;
+        }
+        size_t o = (size_t)y * Wk + x;
+        const float v[5] = {(float)(b3 * pc.ig11), (float)(b2 * pc.ig11), (float)(b1 * pc.ig03 + b5 * pc.ig33),
+                            (float)(b1 * pc.ig03 + b4 * pc.ig33), (float)(b6 * pc.ig55)};
+        r_store_px(dst, Nk, o, v);
+    }
+}
+
+// A2, register-blocked form for a compile-time poly_n.  Same arithmetic, statement for
+// statement; what changes is how often LDS is read: the vertical pass slides a window of
+// 4+2N rows down a column in registers (4 outputs per item), the horizontal pass computes two
+// adjacent outputs from one window of 2+2N triples.  ~25 DS operations per pixel instead of ~62.
+typedef float float2w __attribute__((ext_vector_type(2), aligned(4)));
+
+// FarnebackPolyExp's vertical pass for four consecutive rows of two adjacent columns: v[j] holds
+// rows y0-N+j of the column pair; results go to the three planes at rows 0..3 (row stride LW).
+template <int N>
+__device__ __forceinline__ void polyexp_vertical4(const f32x2 (&v)[4 + 2 * N], const PolyConst &pc, float *T0, float *T1,
+                                                  float *T2, int LW)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x2 c = v[q + N];
+        f32x2 t0 = c * pc.g[0], t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 1; k <= N; k++) {
+            const f32x2 a = v[q + N - k], b = v[q + N + k]; // rows y-k and y+k (clamped when staged)
+            const f32x2 p = a + b;
+            t0 = t0 + pc.g[k] * p;
+            t1 = t1 + pc.xg[k] * (b - a);
+            t2 = t2 + pc.xxg[k] * p;
+        }
+        *reinterpret_cast<f32x2 *>(T0 + q * LW) = t0;
+        *reinterpret_cast<f32x2 *>(T1 + q * LW) = t1;
+        *reinterpret_cast<f32x2 *>(T2 + q * LW) = t2;
+    }
+}
+
+template <int N>
+__global__ void __launch_bounds__(256)
+k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 2 * N, LH = TH + 2 * N;
+    __shared__ float sI[LH * LW];
+    __shared__ float sT[3][TH][LW];
+    const int pi = blockIdx.z;
+    const size_t Nk = (size_t)Wk * Hk;
+    const float *src = img + (size_t)pi * Nk;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int idx = threadIdx.x; idx < LH * LW; idx += 256) {
+        int ry = idx / LW, cx = idx - ry * LW; // LW is a compile-time constant
+        int y = clampi(y0 - N + ry, 0, Hk - 1), x = clampi(x0 - N + cx, 0, Wk - 1);
+        sI[idx] = src[(size_t)y * Wk + x];
+    }
+    __syncthreads();
+    // vertical pass (float): item = (pair of columns, group of 4 rows); the two columns ride in
+    // the halves of packed fp32 operations
+    static_assert(LW % 2 == 0, "column pairs");
+    for (int idx = threadIdx.x; idx < (TH / 4) * (LW / 2); idx += 256) {
+        const int g = idx / (LW / 2), cx = 2 * (idx - g * (LW / 2));
+        f32x2 v[4 + 2 * N];
+#pragma unroll
+        for (int j = 0; j < 4 + 2 * N; j++)
+            v[j] = *reinterpret_cast<const f32x2 *>(&sI[(4 * g + j) * LW + cx]);
+        polyexp_vertical4<N>(v, pc, &sT[0][4 * g][cx], &sT[1][4 * g][cx], &sT[2][4 * g][cx], LW);
+    }
+    __syncthreads();
+    // horizontal pass (double): item = (row, pair of columns)
+    float *dst = R + (size_t)pi * 5 * Nk;
+    for (int idx = threadIdx.x; idx < TH * (TW / 2); idx += 256) {
+        const int ty = idx / (TW / 2), cp = idx - ty * (TW / 2);
+        const int x = x0 + 2 * cp, y = y0 + ty;
+        if (x >= Wk || y >= Hk)
+            continue;
+        float w0[2 + 2 * N], w1[2 + 2 * N], w2[2 + 2 * N]; // triples at columns x-N .. x+1+N
+#pragma unroll
+        for (int j = 0; j < 2 + 2 * N; j++) {
+            w0[j] = sT[0][ty][2 * cp + j];
+            w1[j] = sT[1][ty][2 * cp + j];
+            w2[j] = sT[2][ty][2 * cp + j];
+        }
+        float out[2][5];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float *T0 = w0 + q + N, *T1 = w1 + q + N, *T2 = w2 + q + N;
+            float g0 = pc.g[0];
+            double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                double tg = T0[k] + T0[-k];
+                g0 = pc.g[k];
+                b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+                b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
+                b2 += (T0[k] - T0[-k]) * pc.xg[k];
+                b3 += (T1[k] + T1[-k]) * g0;
+                b6 += (T1[k] - T1[-k]) * pc.xg[k];
+                b5 += (T2[k] + T2[-k]) * g0;
+            }
+            out[q][0] = (float)(b3 * pc.ig11);
+            out[q][1] = (float)(b2 * pc.ig11);
+            out[q][2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            out[q][3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            out[q][4] = (float)(b6 * pc.ig55);
+        }
+        const size_t o = (size_t)y * Wk + x;
+        if (x + 1 < Wk)
+            r_store_px2(dst, Nk, o, out[0], out[1]);
+        else
+            r_store_px(dst, Nk, o, out[0]);
+    }
+}
+
+// The two passes of FarnebackPolyExp over a blurred level tile held in LDS (sI, indexed by real level
+// coordinates relative to (xr0, yr0); virtual coordinates outside the level clamp, as OpenCV
+// replicates edge rows/columns of the level image): shared by the fused level-0 and level-1 kernels.
+// W, H: the LEVEL's size.  Call with sI complete and the workgroup synchronised.
+template <int N, int TW, int TH>
+__device__ __forceinline__ void tile_expansion(const float *sI, float (*sT)[TH][TW + 2 * N], int x0, int y0, int xr0,
+                                               int yr0, int W, int H, const PolyConst &pc, float *dst, size_t Nk)
+{
+    constexpr int LW = TW + 2 * N;
+    // polynomial expansion, vertical pass: virtual row y0-N+j reads real row clamp(...) - yr0
+    // (an interior tile reads rows/columns 4g+j / cx directly; a border tile clamps them)
+    const bool interior = x0 - N >= 0 && x0 + TW - 1 + N <= W - 1 && y0 - N >= 0 && y0 + TH - 1 + N <= H - 1;
+    for (int idx = threadIdx.x; idx < (TH / 4) * (LW / 2); idx += 256) {
+        const int g = idx / (LW / 2), cx = 2 * (idx - g * (LW / 2));
+        f32x2 v[4 + 2 * N];
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * N; j++)
+                v[j] = *reinterpret_cast<const f32x2 *>(&sI[(4 * g + j) * LW + cx]);
+        } else {
+            const int xa = clampi(x0 - N + cx, 0, W - 1) - xr0, xb = clampi(x0 - N + cx + 1, 0, W - 1) - xr0;
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * N; j++) {
+                const float *row = sI + (clampi(y0 - N + 4 * g + j, 0, H - 1) - yr0) * LW;
+                v[j] = f32x2{row[xa], row[xb]};
+            }
+        }
+        polyexp_vertical4<N>(v, pc, &sT[0][4 * g][cx], &sT[1][4 * g][cx], &sT[2][4 * g][cx], LW);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TH * (TW / 2); idx += 256) {
+        const int ty = idx / (TW / 2), cp = idx - ty * (TW / 2);
+        const int x = x0 + 2 * cp, y = y0 + ty;
+        if (x >= W || y >= H)
+            continue;
+        float w0[2 + 2 * N], w1[2 + 2 * N], w2[2 + 2 * N];
+#pragma unroll
+        for (int j = 0; j < 2 + 2 * N; j++) {
+            w0[j] = sT[0][ty][2 * cp + j];
+            w1[j] = sT[1][ty][2 * cp + j];
+            w2[j] = sT[2][ty][2 * cp + j];
+        }
+        float out[2][5];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float *T0 = w0 + q + N, *T1 = w1 + q + N, *T2 = w2 + q + N;
+            float g0 = pc.g[0];
+            double b1 = T0[0] * g0, b2 = 0, b3 = T1[0] * g0, b4 = 0, b5 = T2[0] * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                double tg = T0[k] + T0[-k];
+                g0 = pc.g[k];
+                b1 = __builtin_fma(tg, (double)g0, b1); // exact products of float values: fused == separate
+                b4 = __builtin_fma(tg, (double)pc.xxg[k], b4);
+                b2 += (T0[k] - T0[-k]) * pc.xg[k];
+                b3 += (T1[k] + T1[-k]) * g0;
+                b6 += (T1[k] - T1[-k]) * pc.xg[k];
+                b5 += (T2[k] + T2[-k]) * g0;
+            }
+            out[q][0] = (float)(b3 * pc.ig11);
+            out[q][1] = (float)(b2 * pc.ig11);
+            out[q][2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            out[q][3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            out[q][4] = (float)(b6 * pc.ig55);
+        }
+        const size_t o = (size_t)y * W + x;
+        if (x + 1 < W)
+            r_store_px2(dst, Nk, o, out[0], out[1]);
+        else
+            r_store_px(dst, Nk, o, out[0]);
+    }
+}
+
+// rows of a tile of the fused expansion kernels (4K x 33 frames: level 0 with 12 / 16 / 20 rows 2.43 / 2.10 / 2.18 ms,
+// level 1 with 16 / 20 / 24 / 32 rows 1.31 (before its 2 x 2 blocks) / 0.87 / 0.95 / 1.05 ms)
+#ifndef TF_EXP_TH0
+#define TF_EXP_TH0 16
+#endif
+#ifndef TF_EXP_TH1
+#define TF_EXP_TH1 20
+#endif
+// A1+A2 fused for the full-resolution level (resize is a copy, the blur has 3 taps): the level
+// image never leaves the CU.  Stages the u8 region by REAL image coordinates (REFLECT_101 ring of
+// one pixel), blurs it into LDS exactly as k_level_image does (row pass, then column pass), then
+// runs k_polyexp_t's two passes, reading the blurred tile with CLAMPED coordinates (OpenCV's
+// polynomial expansion replicates edge rows/columns of the already blurred image).
+template <int N>
+__global__ void __launch_bounds__(256)
+k_level0_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ R, int W,
+                   int H, float kc, float k1, PolyConst pc)
+{
+    constexpr int TW = 64, TH = TF_EXP_TH0, LW = TW + 2 * N, LH = TH + 2 * N; // blurred tile (virtual extent)
+    constexpr int SW = ((LW + 2 + 3 + 3) + 3) & ~3, SH = LH + 2; // staged bytes: one more pixel all round, dword slack
+    // LDS: the staged bytes and the row-pass values are dead once the blurred tile exists, so the
+    // three planes of the expansion's vertical pass reuse their space
+    constexpr int RS = (LW + 3) & ~3; // row stride of the row-pass values: whole groups of four columns
+    static_assert(SW >= RS + 4 + 4 && (SH * SW) % 16 == 0, "a group's three dwords stay inside its staged row; sRow 16-byte aligned");
+    constexpr int BYTES_A = SH * SW + SH * RS * 4, BYTES_T = 3 * TH * LW * 4;
+    constexpr int BYTES_U = ((BYTES_A > BYTES_T ? BYTES_A : BYTES_T) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) uint8_t s_u[BYTES_U];
+    __shared__ float sI[LH * LW]; // blurred level image, indexed by real coordinate offsets
+    uint8_t *sS = s_u;                                          // [SH][SW] staged bytes
+    float *sRow = reinterpret_cast<float *>(s_u + SH * SW);     // [SH][RS] row-pass values, rows yr0-1 .. yr1+1
+    float(*sT)[TH][LW] = reinterpret_cast<float(*)[TH][LW]>(s_u); // [3][TH][LW], after the blur
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const size_t Nk = (size_t)W * H;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // real image region the tile's (clamped) reads touch
+    const int xr0 = max(x0 - N, 0), xr1 = min(x0 + TW - 1 + N, W - 1);
+    const int yr0 = max(y0 - N, 0), yr1 = min(y0 + TH - 1 + N, H - 1);
+    const int ny = yr1 - yr0 + 1; // (columns past xr1 are computed from whatever was staged and never read)
+    // stage bytes for columns xr0-1 .. xr1+1, rows yr0-1 .. yr1+1 (reflected outside the image);
+    // the staged columns start at a multiple of 4 so interior tiles copy dwords
+    const int xs = (xr0 - 1) & ~3, off = xr0 - 1 - xs; // column xr0-1 sits at byte `off` of a staged row
+    const int ncols = xr1 + 1 - xs + 1;
+    const bool dwords = (W & 3) == 0 && xs >= 0 && xs + ((ncols + 3) & ~3) <= W;
+    constexpr int U = 8;
+    if (dwords) {
+        const int nq = (ncols + 3) >> 2;
+        for (int c = lane; c < nq; c += 64) {
+            for (int j0 = wave; j0 < ny + 2; j0 += 4 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101_near(yr0 - 1 + ry, H) * W + xs + 4 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        *reinterpret_cast<uint32_t *>(sS + ry * SW + 4 * c) = v[u];
+                }
+            }
+        }
+    } else {
+        for (int c = lane; c < ncols; c += 64) {
+            const int x = reflect101_near(xs + c, W);
+            for (int j0 = wave; j0 < ny + 2; j0 += 4 * U) {
+                uint8_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        v[u] = src[(size_t)reflect101_near(yr0 - 1 + ry, H) * W + x];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < ny + 2)
+                        sS[ry * SW + c] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // row pass (tap order of k_level_image, ksz == 3), four adjacent pixels per item: their six bytes come out of
+    // three aligned dwords (the staged row starts on a dword; `off` is the same for the whole tile)
+    for (int idx = threadIdx.x; idx < (ny + 2) * (RS / 4); idx += 256) {
+        const int ry = idx / (RS / 4), cx = 4 * (idx - ry * (RS / 4));
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(sS + ry * SW + cx); // bytes off + cx .. are pixels cx-1 ..
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, off), hi = __builtin_amdgcn_alignbyte(d2, d1, off);
+        const float b0 = (float)(lo & 0xff), b1 = (float)((lo >> 8) & 0xff), b2 = (float)((lo >> 16) & 0xff),
+                    b3 = (float)(lo >> 24), b4 = (float)(hi & 0xff), b5 = (float)((hi >> 8) & 0xff);
+        float *o = sRow + ry * RS + cx;
+        *reinterpret_cast<f32x2 *>(o) = f32x2{b1 * kc + (b0 + b2) * k1, b2 * kc + (b1 + b3) * k1};
+        *reinterpret_cast<f32x2 *>(o + 2) = f32x2{b3 * kc + (b2 + b4) * k1, b4 * kc + (b3 + b5) * k1};
+    }
+    __syncthreads();
+    // column pass -> blurred image at real coordinates (xr0 + cx, yr0 + ry), four columns per item
+    for (int idx = threadIdx.x; idx < ny * (RS / 4); idx += 256) {
+        const int ry = idx / (RS / 4), cx = 4 * (idx - ry * (RS / 4));
+        const float *c = sRow + (ry + 1) * RS + cx;
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(c), dn = *reinterpret_cast<const f32x4 *>(c + RS),
+                    up = *reinterpret_cast<const f32x4 *>(c - RS);
+        f32x4 v = kc * m;
+        v += k1 * (dn + up);
+        float *o = sI + ry * LW + cx;
+        *reinterpret_cast<f32x2 *>(o) = f32x2{v.x, v.y};
+        if (cx + 2 < LW)
+            *reinterpret_cast<f32x2 *>(o + 2) = f32x2{v.z, v.w};
+    }
+    __syncthreads();
+    tile_expansion<N, TW, TH>(sI, sT, x0, y0, xr0, yr0, W, H, pc, R + (size_t)pi * 5 * Nk, Nk);
+}
+
+// A1+A2 fused for a level that is exactly half the frame in both directions with the 3-tap blur
+// (level 1 of a pyr_scale = 0.5 pyramid over even frame sizes).  resize.cpp's coordinates are then
+// (2X, 2Y) with both fractions exactly 0.5, so a level pixel is the lerp of the blurred frame at a 2x2
+// block, each of those a 3x3 separable blur: computed per level pixel from its 4x4 bytes with
+// k_level_image's statements (row pass, column pass centre-then-pair, horizontal lerp, vertical
+// lerp); the level image never leaves the CU.  Then the expansion passes shared with level 0.
+template <int N>
+__global__ void __launch_bounds__(256)
+k_level1_polyexp_t(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ R, int W,
+                   int H, float kc, float k1, PolyConst pc)
+{
+    constexpr int TW = 64, TH = TF_EXP_TH1, LW = TW + 2 * N, LH = TH + 2 * N;
+    constexpr int SW = ((2 * LW + 2 + 3 + 3) + 3) & ~3, SH = 2 * LH + 2; // staged bytes: 2 per level pixel + 1 all round
+    constexpr int BYTES_A = SH * SW, BYTES_T = 3 * TH * LW * 4;
+    constexpr int BYTES_U = ((BYTES_A > BYTES_T ? BYTES_A : BYTES_T) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) uint8_t s_u[BYTES_U];
+    __shared__ float sI[LH * LW];
+    uint8_t *sS = s_u;
+    float(*sT)[TH][LW] = reinterpret_cast<float(*)[TH][LW]>(s_u);
+    const int Wk = W >> 1, Hk = H >> 1;
+    const int pi = blockIdx.z;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const size_t Nk = (size_t)Wk * Hk;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xr0 = max(x0 - N, 0), xr1 = min(x0 + TW - 1 + N, Wk - 1);
+    const int yr0 = max(y0 - N, 0), yr1 = min(y0 + TH - 1 + N, Hk - 1);
+    const int ny = yr1 - yr0 + 1;
+    // frame bytes: columns 2*xr0-1 .. 2*xr1+2, rows 2*yr0-1 .. 2*yr1+2 (REFLECT_101 outside the frame)
+    const int cfirst = 2 * xr0 - 1, rfirst = 2 * yr0 - 1, nrows = 2 * ny + 2;
+    const int xs = cfirst >= 0 ? (cfirst & ~3) : cfirst, off = cfirst - xs;
+    const int ncols = 2 * xr1 + 2 - xs + 1;
+    const bool dwords = (W & 3) == 0 && xs >= 0 && (xs & 3) == 0 && xs + ((ncols + 3) & ~3) <= W;
+    constexpr int U = 8;
+    if (dwords) {
+        const int nq = (ncols + 3) >> 2;
+        for (int c = lane; c < nq; c += 64) {
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)reflect101_near(rfirst + ry, H) * W + xs + 4 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        *reinterpret_cast<uint32_t *>(sS + ry * SW + 4 * c) = v[u];
+                }
+            }
+        }
+    } else {
+        for (int c = lane; c < ncols; c += 64) {
+            const int x = reflect101_near(xs + c, W);
+            for (int j0 = wave; j0 < nrows; j0 += 4 * U) {
+                uint8_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        v[u] = src[(size_t)reflect101_near(rfirst + ry, H) * W + x];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int ry = j0 + 4 * u;
+                    if (ry < nrows)
+                        sS[ry * SW + c] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // Level pixel (xr0 + cx, yr0 + ry): frame rows 2Y-1 .. 2Y+2 are staged rows 2*ry .. 2*ry+3, frame columns
+    // 2X-1 .. 2X+2 staged bytes off + 2*cx .. +3.  An item is a 2 x 2 block of level pixels: six staged rows, six
+    // bytes of each out of three aligned dwords (`off` is the tile's), 24 row-pass values instead of 32.  Rows and
+    // columns past the tile's real region are computed from whatever was staged and never read.
+    static_assert(LW % 2 == 0 && SW >= 2 * LW + 8, "2 x 2 blocks; a block's three dwords stay inside its staged row");
+    for (int idx = threadIdx.x; idx < ((ny + 1) >> 1) * (LW / 2); idx += 256) {
+        const int by2 = idx / (LW / 2), ry = 2 * by2, cx = 2 * (idx - by2 * (LW / 2));
+        float rp[6][4];
+#pragma unroll
+        for (int dy = 0; dy < 6; dy++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(sS + (2 * ry + dy) * SW + 2 * cx);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, off), hi = __builtin_amdgcn_alignbyte(d2, d1, off);
+            const float b0 = (float)(lo & 0xff), b1 = (float)((lo >> 8) & 0xff), b2 = (float)((lo >> 16) & 0xff),
+                        b3 = (float)(lo >> 24), b4 = (float)(hi & 0xff), b5 = (float)((hi >> 8) & 0xff);
+            rp[dy][0] = b1 * kc + (b0 + b2) * k1; // row pass at frame columns 2X, 2X+1 (this pixel), 2X+2, 2X+3 (the next)
+            rp[dy][1] = b2 * kc + (b1 + b3) * k1;
+            rp[dy][2] = b3 * kc + (b2 + b4) * k1;
+            rp[dy][3] = b4 * kc + (b3 + b5) * k1;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            float out[2];
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                float v00 = kc * rp[2 * a + 1][2 * b], v01 = kc * rp[2 * a + 1][2 * b + 1];
+                float v10 = kc * rp[2 * a + 2][2 * b], v11 = kc * rp[2 * a + 2][2 * b + 1];
+                v00 += k1 * (rp[2 * a + 2][2 * b] + rp[2 * a][2 * b]); // column pass at frame row 2Y: centre, then (row+1 + row-1)
+                v01 += k1 * (rp[2 * a + 2][2 * b + 1] + rp[2 * a][2 * b + 1]);
+                v10 += k1 * (rp[2 * a + 3][2 * b] + rp[2 * a + 1][2 * b]); //                          2Y+1
+                v11 += k1 * (rp[2 * a + 3][2 * b + 1] + rp[2 * a + 1][2 * b + 1]);
+                const float h0 = v00 * (1.f - 0.5f) + v01 * 0.5f, h1 = v10 * (1.f - 0.5f) + v11 * 0.5f;
+                out[b] = h0 * (1.f - 0.5f) + h1 * 0.5f;
+            }
+            if (ry + a < ny)
+                *reinterpret_cast<f32x2 *>(sI + (ry + a) * LW + cx) = f32x2{out[0], out[1]};
+        }
+    }
+    __syncthreads();
+    tile_expansion<N, TW, TH>(sI, sT, x0, y0, xr0, yr0, Wk, Hk, pc, R + (size_t)pi * 5 * Nk, Nk);
+}
+
+} // namespace
+
+namespace tf {
+namespace fb {
+
+// `standalone`: a single level is wanted (stage entry points): run the shared row pass regardless of the order
+int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone)
+{
+    Level &L = *fb->lv[k];
+    if (L.split) {
+        if (k == fb->rp_first || standalone) { // the coarsest split level comes first in the preparation: row pass of all of them now
+            RowPassArgs a;
+            memset(&a, 0, sizeof(a));
+            size_t taps = 0;
+            for (int j = fb->K; j >= 1; j--) {
+                Level &S = *fb->lv[j];
+                if (!S.split)
+                    continue;
+                RowPassLevel &rl = a.lv[a.n++];
+                rl.rowf = fb->rowf.as<float>() + S.rowf_off;
+                rl.colsrc = S.colsrc.as<int>();
+                rl.kern = S.kern.as<float>();
+                rl.NC = S.NC;
+                rl.ksz = S.ksz;
+                rl.rshift = S.rp_rshift;
+                taps += (size_t)S.ksz;
+            }
+            const size_t smem_rp = (size_t)fb->rp_RB * fb->rp_pitch + taps * sizeof(float);
+            TF_TRY(launch(lvl_name("fb_level_rowpass", -1), k_level_rowpass, dim3(cdiv(fb->H, fb->rp_RB), n_images),
+                          dim3(256), smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(),
+                          fb->image_list(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
+                          fb->rp_rmax));
+        }
+        return launch(lvl_name("fb_level_colpass", k), k_level_colpass, dim3(cdiv(L.W, 64), cdiv(L.H, 4), n_images), dim3(256),
+                      (size_t)L.ksz * sizeof(float), (const float *)(fb->rowf.as<float>() + L.rowf_off), fb->imgk(k), fb->W, fb->H,
+                      L.W, L.H, L.NC, (const float *)L.kern.as<float>(), L.ksz, (const int *)L.img_lerp.xofs.as<int>(),
+                      (const float *)L.img_lerp.xfrac.as<float>(), (const int *)L.img_lerp.yofs.as<int>(),
+                      (const float *)L.img_lerp.yfrac.as<float>());
+    }
+    const ImgTile &t = L.tile;
+    dim3 grid(cdiv(L.W, t.TWo), cdiv(L.H, t.THo), n_images);
+    size_t smem = (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)L.ksz * sizeof(float);
+    return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->imgk(k),
+                  fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
+}
+
+// Plans the two-kernel form of A1 for a level with a long blur kernel (returns false where it does not
+// apply: short kernels, frame widths that are not a multiple of 4, frames too wide to stage 8 rows).
+bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc)
+{
+    static const bool off = tune("TF_IMG_NO_SPLIT", 0) != 0;
+    static const int min_ksz = (int)tune("TF_IMG_SPLIT_MIN_KSZ", 9);
+    if (off || L.ksz < min_ksz || L.ksz <= 5 || (W & 3) != 0 || (L.W == W && L.H == H))
+        return false;
+    std::vector<int> xo, yo;
+    std::vector<float> fr;
+    make_lerp(W, L.W, true, xo, fr);
+    make_lerp(H, L.H, false, yo, fr);
+    L.NC = 2 * L.W;
+    colsrc.resize((size_t)L.NC);
+    for (int x = 0; x < L.W; x++) {
+        colsrc[2 * x] = xo[x];
+        colsrc[2 * x + 1] = std::min(xo[x] + 1, W - 1);
+    }
+    // lanes = R rows x 64/R groups; one group = two level columns = s/2 dwords of a frame row
+    const int s_ = std::max(1, W / std::max(1, L.W));
+    int rshift = 1;
+    while ((1 << rshift) < std::min(8, std::max(2, s_ / 2)))
+        rshift++;
+    L.rp_rshift = rshift;
+    return true;
+}
+
+// Output tile of a level: as large as fits ~60 KB of LDS, given the source extent a tile needs.
+ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz, int level)
+{
+    std::vector<int> xo, yo;
+    std::vector<float> fr;
+    make_lerp(W, Wk, true, xo, fr);
+    make_lerp(H, Hk, false, yo, fr);
+    const int r = ksz / 2;
+    auto extent = [&](const std::vector<int> &ofs, int n, int len, int tile, bool align4) {
+        int worst = 0;
+        for (int d0 = 0; d0 < n; d0 += tile) {
+            int d1 = std::min(n, d0 + tile) - 1;
+            int lo = std::max(0, std::min(ofs[d0], len - 1)) - r, hi = std::max(0, std::min(ofs[d1] + 1, len - 1)) + r;
+            if (align4)
+                lo &= ~3;
+            worst = std::max(worst, hi - lo + 1);
+        }
+        return worst;
+    };
+    int s = std::max(1, (W + Wk - 1) / Wk);
+    static const size_t lds_cap = (size_t)tune("TF_IMG_LDS_KB", 60) * 1024;
+    ImgTile t;
+    t.same_size = (W == Wk && H == Hk);
+    t.scale_x = 1. / ((double)Wk / W);
+    t.scale_y = 1. / ((double)Hk / H);
+    auto fill = [&](int two, int tho) {
+        t.TWo = two;
+        t.THo = tho;
+        t.LW = extent(xo, Wk, W, two, true) + 3; // dword copies may run up to 3 bytes past the last column
+        t.LH = extent(yo, Hk, H, tho, false);
+        t.pitch = (t.LW + 3) & ~3;
+        if (((t.pitch / 4) & 1) == 0)
+            t.pitch += 4;
+        t.rstride = t.same_size ? two : 2 * two;
+        t.tw_shift = 0;
+        while ((1 << t.tw_shift) < two)
+            t.tw_shift++;
+        return (size_t)t.LH * t.pitch + (size_t)t.LH * t.rstride * sizeof(float) + (size_t)ksz * sizeof(float);
+    };
+    if (const char *ov = tune_str("TF_IMG_TILES")) { // "level:TWo:THo,..." experiment override
+        for (const char *p = ov; p && *p;) {
+            int l = 0, a = 0, b = 0;
+            if (sscanf(p, "%d:%d:%d", &l, &a, &b) == 3 && l == level && fill(a, b) <= 64 * 1024)
+                return t;
+            p = strchr(p, ',');
+            if (p)
+                p++;
+        }
+    }
+    if (ksz > 5) {
+        // long kernels (measured on MI355X, tools/tile_sweep.sh): tiles spanning ~128 source columns,
+        // as many output rows as fill whole rounds of 64 staged rows (the row pass costs
+        // ceil(LH/64) lane-rounds per column group) within ~40 KB of LDS so several blocks share a CU
+        const size_t cap = std::min<size_t>(lds_cap, 40 * 1024);
+        int btw = 4;
+        while (btw * 2 <= std::max(4, 128 / s))
+            btw *= 2;
+        int bth = 1;
+        double best = 1e30;
+        for (int tho = 1; tho <= 32; tho++) {
+            size_t smem = fill(btw, tho);
+            if (smem > cap && tho > 1)
+                break;
+            double rounds = (double)((t.LH + 63) / 64) * 64 / tho; // lane-rows per output row
+            if (rounds <= best) {
+                best = rounds;
+                bth = tho;
+            }
+        }
+        fill(btw, bth);
+        return t;
+    }
+    int two = 8;
+    while (two * 2 <= std::min(128, 256 / s))
+        two *= 2;
+    int tho = std::max(2, std::min(32, 128 / s));
+    for (;;) {
+        size_t smem = fill(two, tho);
+        if (smem <= std::min<size_t>(lds_cap, 32 * 1024) || (two <= 2 && tho <= 1))
+            break;
+        if (tho > 1 && (tho >= two / 4 || two <= 2))
+            tho = std::max(1, tho / 2);
+        else
+            two = std::max(2, two / 2);
+    }
+    return t;
+}
+
+int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k)
+{
+    const int n = fb->pc.n;
+    dim3 grid(cdiv(w, PX_TW), cdiv(h, PX_TH), n_images);
+    if (n == 5)
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<5>, grid, dim3(256), 0, (const float *)fb->imgk(k),
+                      fb->Rk_out(k), w, h, fb->pc);
+    if (n == 7)
+        return launch(lvl_name("fb_polyexp", k), k_polyexp_t<7>, grid, dim3(256), 0, (const float *)fb->imgk(k),
+                      fb->Rk_out(k), w, h, fb->pc);
+    size_t smem = ((size_t)(PX_TH + 2 * n) * (PX_TW + 2 * n) + 3 * (size_t)PX_TH * (PX_TW + 2 * n)) * sizeof(float);
+    return launch(lvl_name("fb_polyexp_generic", k), k_polyexp, grid, dim3(256), smem,
+                  (const float *)fb->imgk(k), fb->Rk_out(k), w, h, fb->pc);
+}
+
+// A1+A2 fusion applies to a level that is a copy-sized resize of the frame with the 3-tap blur
+// (level 0 of every pyramid) and a poly_n the blocked expansion is instantiated for.
+bool fb_can_fuse_level(tf_fb *fb, int k)
+{
+    static const bool off = tune("TF_FB_NO_A1A2", 0) != 0;
+    const Level &L = *fb->lv[k];
+    return !off && L.W == fb->W && L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
+}
+
+// ... and to a level that is exactly half the frame (k_level1_polyexp_t)
+bool fb_can_fuse_half_level(tf_fb *fb, int k)
+{
+    static const bool off = tune("TF_FB_NO_A1A2", 0) != 0;
+    const Level &L = *fb->lv[k];
+    return !off && 2 * L.W == fb->W && 2 * L.H == fb->H && L.ksz == 3 && (fb->pc.n == 5 || fb->pc.n == 7);
+}
+
+int fb_level1_polyexp(tf_fb *fb, int k, int n_images)
+{
+    Level &L = *fb->lv[k];
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, TF_EXP_TH1), n_images);
+    const float kc = L.kern_host[1], k1 = L.kern_host[2];
+    if (fb->pc.n == 5)
+        return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<5>, grid, dim3(256), 0,
+                      (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k), fb->W,
+                      fb->H, kc, k1, fb->pc);
+    return launch(lvl_name("fb_level_polyexp", k), k_level1_polyexp_t<7>, grid, dim3(256), 0,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k), fb->W, fb->H,
+                  kc, k1, fb->pc);
+}
+
+int fb_level0_polyexp(tf_fb *fb, int k, int n_images)
+{
+    Level &L = *fb->lv[k];
+    dim3 grid(cdiv(L.W, 64), cdiv(L.H, TF_EXP_TH0), n_images);
+    const float kc = L.kern_host[1], k1 = L.kern_host[2];
+    if (fb->pc.n == 5)
+        return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<5>, grid, dim3(256), 0,
+                      (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k),
+                      L.W, L.H, kc, k1, fb->pc);
+    return launch(lvl_name("fb_level_polyexp", k), k_level0_polyexp_t<7>, grid, dim3(256), 0,
+                  (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->Rk_out(k), L.W,
+                  L.H, kc, k1, fb->pc);
+}
+
+} // namespace fb
+} // namespace tf

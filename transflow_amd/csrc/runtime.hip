@@ -300,6 +300,50 @@ TF_API int tf_event_elapsed_ms(tf_event *start, tf_event *stop, float *ms)
     return TF_OK;
 }
 
+TF_API int tf_stream_wait_event(tf_event *ev)
+{
+    TF_REQUIRE(ev, "tf_stream_wait_event: null event");
+    TF_TRY(ensure_init());
+    TF_HIP(hipStreamWaitEvent(stream(), ev->ev, 0));
+    return TF_OK;
+}
+
+TF_API int tf_event_synchronize(tf_event *ev)
+{
+    TF_REQUIRE(ev, "tf_event_synchronize: null event");
+    TF_HIP(hipEventSynchronize(ev->ev));
+    return TF_OK;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) == TF_IPC_HANDLE_BYTES, "tfhip.h states the size of an IPC handle");
+
+TF_API int tf_ipc_export(void *dev, void *handle_out)
+{
+    TF_REQUIRE(dev && handle_out, "tf_ipc_export: null pointer");
+    TF_TRY(ensure_init());
+    hipIpcMemHandle_t h;
+    TF_HIP(hipIpcGetMemHandle(&h, dev));
+    memcpy(handle_out, &h, sizeof(h));
+    return TF_OK;
+}
+
+TF_API int tf_ipc_open(const void *handle, void **dev)
+{
+    TF_REQUIRE(handle && dev, "tf_ipc_open: null pointer");
+    TF_TRY(ensure_init());
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    TF_HIP(hipIpcOpenMemHandle(dev, h, hipIpcMemLazyEnablePeerAccess));
+    return TF_OK;
+}
+
+TF_API int tf_ipc_close(void *dev)
+{
+    if (dev)
+        TF_HIP(hipIpcCloseMemHandle(dev));
+    return TF_OK;
+}
+
 TF_API void tf_event_destroy(tf_event *ev)
 {
     if (!ev)

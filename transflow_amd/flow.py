@@ -580,6 +580,7 @@ class HipFlowSource(FlowSource):
         self._pending = None     # array handed out by read_next_flow whose flow is still on the device
         self._mask_dev = None
         self._flow_pool = None
+        self._flow_ring = None   # FlowConfig.hip_device_flows: the device buffers the yielded DeviceFlows live in
         self._prefetch = None
         self._download_token = None
         FlowSource.__init__(self, *args, **kwargs)
@@ -687,6 +688,15 @@ class HipFlowSource(FlowSource):
             self.rewind()
         self._advance()
         self.input_frame_index += 1
+        if getattr(self.config, "hip_device_flows", False):
+            # the flow stays in HBM: a DeviceFlow over a buffer of the source's ring, filled by post_process
+            from .deviceflow import DeviceFlow, FlowRing
+            if self._flow_ring is None:
+                self._flow_ring = FlowRing((self.height, self.width, 2), slots=4 + self.config.hip_prefetch)
+            slot = self._flow_ring.take()
+            self._pending = DeviceFlow((self.height, self.width, 2), slot.buf.ptr, slot.ready, ring=self._flow_ring, slot=slot,
+                                       cross_process="ipc" if self.config.hip_device_flows == "ipc" else None)
+            return self._pending
         if self._flow_pool is None:
             from .device import ArrayPool
             self._flow_pool = ArrayPool((self.height, self.width, 2), np.float32, limit=4 + self.config.hip_prefetch, pinned=True)
@@ -707,6 +717,14 @@ class HipFlowSource(FlowSource):
                     np.ascontiguousarray(self.mask, dtype=np.float32).reshape(self.height, self.width))
             mask_dev = self._mask_dev.ptr
         fb.post_process_ex(0, self.direction.value, ops, mask_dev)
+        if not isinstance(raw, np.ndarray):
+            # a DeviceFlow: out of the handle's result buffer (the next call but one writes it again) into the flow's own,
+            # device to device on this thread's stream; the event behind the copy is what consumers wait for
+            from . import _lib
+            import ctypes as C
+            _lib.check(_lib.load().tf_dev_copy(C.c_void_p(raw.dev_ptr), C.c_void_p(fb.flow_ptr(0)), raw.nbytes))
+            raw._ready.record()
+            return raw
         if self._prefetch is not None:
             # the worker thread: the flow starts its way down and the worker goes on to the next frame; it hands this
             # array to the consumer only once the transfer has ended (_Prefetch._run)
@@ -742,6 +760,8 @@ class HipFlowSource(FlowSource):
         if self._mask_dev is not None:
             self._mask_dev.close()
             self._mask_dev = None
+        self._pending = None
+        self._flow_ring = None      # (buffers live as long as a DeviceFlow the caller still holds)
         if self._fb is not None:
             self._fb.close()
             self._fb = None

@@ -109,6 +109,27 @@ class RemapLayer:
         check(self._lib.tf_remap_set_sources(self._h, len(masks), arr))
 
     def update(self, flow: np.ndarray, uniform: np.ndarray | None = None, seed: int = 0) -> None:
+        if getattr(flow, "dev_ptr", None) is not None and not flow.on_host:
+            # a DeviceFlow nobody brought down (transflow_amd/deviceflow.py): the kernels read it where it is.  A flow
+            # vector that leaves the frame cannot raise here (nothing waits for the kernel): `device_updates` tells the
+            # compositor to look at the layer's flag when it next synchronises (HipCompositor.render).
+            if tuple(flow.shape) != (self.height, self.width, 2):
+                raise ValueError(f"flow shape {tuple(flow.shape)} != {(self.height, self.width, 2)}")
+            u_dev = None
+            if uniform is not None:
+                from .device import DevBuffer
+                u = np.ascontiguousarray(uniform, dtype=np.float64)
+                if u.shape != (self.height, self.width):
+                    raise ValueError("uniform field has the wrong shape")
+                if getattr(self, "_u_dev", None) is None:
+                    self._u_dev = DevBuffer(u.nbytes)
+                self._u_dev.upload(u)
+                u_dev = self._u_dev.ptr
+            flow.wait_on_stream()
+            self.update_dev(flow.dev_ptr, u_dev, seed)
+            flow.mark_used()
+            self.device_updates = getattr(self, "device_updates", 0) + 1
+            return
         flow = np.asarray(flow)
         if flow.dtype != np.float32 and np.issubdtype(flow.dtype, np.floating):
             # a float64 flow (post_process after a float64 convolution kernel returns one, source.py:344-348):
