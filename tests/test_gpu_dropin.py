@@ -349,6 +349,111 @@ def test_prefetching_flow_source_with_one_result_set(shape, no_overlap, lib_opti
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("direction", ["backward", "forward"])
+def test_device_flows_stay_on_the_device_and_give_the_same_frames(direction):
+    """FlowConfig.hip_device_flows: the source yields DeviceFlow objects (transflow_amd/deviceflow.py) -- the seam
+    pipeline.py:562-567 crosses with a host array, crossed in HBM.  Flows (brought down on demand) and the compositor's
+    frames are those of the plain path bit for bit, with and without the prefetching worker; flows the caller keeps --
+    more of them than the source's ring of buffers holds -- stay what they were; a flow modified through itself
+    (`flow *= 0`) is taken from the host, as the reference would take it; an ordinary pickle is the host array."""
+    import pickle
+
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import FlowConfig, LayerConfig
+    from transflow_amd.deviceflow import DeviceFlow
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 120, 168
+    frames = _bgr_frames(h, w, 12)
+    pix = np.random.default_rng(8).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+    class Src:
+        introduction_mask = np.ones((h, w), bool)
+
+        def next(self, timeout=1):
+            return pix
+
+    def run(cfg, zero_at=None):
+        comp = HipCompositor.from_args(h, w, [LayerConfig(0, reset_mode="random", reset_random_factor=0.05)], rng="device")
+        comp.set_sources({0: [Src()]})
+        kept, images = [], []
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction=direction, cv_config=cfg) as source:
+            for t, flow in enumerate(source):
+                if cfg is not None and cfg.hip_device_flows:
+                    assert isinstance(flow, DeviceFlow) and flow.shape == (h, w, 2) and flow.dtype == np.float32
+                if t == zero_at:
+                    flow *= 0                     # through the flow itself: the compositor must see zeros
+                comp.update(flow)
+                images.append(comp.render().copy())
+                kept.append(flow)
+        return kept, images
+    plain_flows, plain_images = run(None)
+    for cfg in (FlowConfig(hip_device_flows=True), FlowConfig(hip_device_flows=True, hip_prefetch=2),
+                FlowConfig(hip_device_flows=True, hip_prefetch=3, hip_batch=3)):
+        flows, images = run(cfg)
+        assert len(flows) == len(plain_flows) == 11
+        assert not any(f._host is not None for f in flows)           # nothing came down: the compositor read HBM
+        for a, b in zip(plain_images, images):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(plain_flows, flows):                         # eleven flows held, a ring of four: all intact
+            np.testing.assert_array_equal(a, np.asarray(b))
+        back = pickle.loads(pickle.dumps(flows[3]))
+        assert type(back) is np.ndarray
+        np.testing.assert_array_equal(back, plain_flows[3])
+    zero_plain = run(None, zero_at=4)[1]
+    zero_dev = run(FlowConfig(hip_device_flows=True), zero_at=4)[1]
+    for a, b in zip(zero_plain, zero_dev):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(zero_plain[6], plain_images[6])         # (the zeroed flow did change the recurrence)
+
+
+@pytest.mark.parametrize("direction", ["backward", "forward"])
+def test_batched_look_ahead_gives_the_flows_of_single_calls(direction):
+    """FlowConfig.hip_batch: the source reads n frames ahead and runs their pairs in one Farneback call (a ring of n + 1
+    frame slots, the last frame of a call the first of the next), never across the wrap of a repeated input
+    (source.py:286-291); flows come out one at a time, post-processed with their own t (a filter of t shows it).  Same
+    flows as the one-pair-per-call source, bit for bit: host arrays, with the prefetching worker, on the device."""
+    from transflow_amd.config import FlowConfig
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 96, 136
+    frames = _bgr_frames(h, w, 12, seed=9)
+
+    def run(cfg):
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction=direction, cv_config=cfg, repeat=2,
+                                     flow_filters="scale=1+t") as source:
+            assert source.length == 22
+            return [np.array(f) for f in source]
+    plain = run(None)
+    assert len(plain) == 22 and not np.array_equal(plain[0], plain[11])          # (the second pass has another t)
+    for cfg in (FlowConfig(hip_batch=4), FlowConfig(hip_batch=5, hip_prefetch=2),
+                FlowConfig(hip_batch=3, hip_prefetch=4, hip_device_flows=True), FlowConfig(hip_batch=16)):
+        got = run(cfg)
+        assert len(got) == 22
+        for a, b in zip(plain, got):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_device_flow_that_leaves_the_frame_raises_at_the_next_render():
+    """movement.py:33, 39: the reference raises IndexError when a rounded flow vector leaves the frame.  An update from a
+    DeviceFlow is only queued; the error comes at the first synchronisation behind it, HipCompositor.render."""
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import LayerConfig
+    from transflow_amd.device import DevBuffer
+    from transflow_amd.deviceflow import DeviceFlow
+    h, w = 32, 40
+    pix = np.zeros((h, w, 3), np.uint8)
+    comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
+    comp.set_sources({0: [FakeSource([pix], np.ones((h, w), bool))]})
+    bad = np.zeros((h, w, 2), np.float32)
+    bad[0, 0] = (-3.0, 0.0)
+    buf = DevBuffer.from_array(bad)
+    comp.update(DeviceFlow(bad.shape, buf.ptr, None))
+    with pytest.raises(IndexError):
+        comp.render()
+    good = DevBuffer.from_array(np.zeros((h, w, 2), np.float32))
+    comp.update(DeviceFlow(bad.shape, good.ptr, None))
+    comp.render()
+
+
 def test_prefetching_flow_source_passes_errors_on_and_stops_cleanly():
     """An exception in the worker thread (a provider that fails) surfaces in the consumer's thread at the flow it belongs
     to; closing a source whose worker is blocked on a full queue returns."""

@@ -8,7 +8,9 @@ ready-made grey frames instead, the form the round-2 figures were taken with).
 `prefetch` lets the flow source run two flows ahead in a worker thread with a stream of its own (FlowConfig.hip_prefetch --
 what the reference's child process + queue give it, pipeline.py:56-64): flow t + 1 is computed while the compositor
 works on flow t.
-Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch]"""
+`device` (FlowConfig.hip_device_flows): the flows stay in HBM between the source and the compositor (DeviceFlow) -- the
+frame still goes up and the rendered frame still comes down, the 66 MB per 4K flow no longer travel at all.
+Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch] [device] [batch=n]"""
 import os
 import sys
 import time
@@ -29,6 +31,8 @@ frames = [clip.frame(t) for t in range(n + 6)]
 kind = sys.argv[3] if len(sys.argv) > 3 else "bgr"
 exact = "exact" in sys.argv[4:]          # flows bit-identical to the CPU path's (option fb_exact_sums)
 prefetch = "prefetch" in sys.argv[4:]
+device = "device" in sys.argv[4:]
+batch = next((int(a.split("=")[1]) for a in sys.argv[4:] if a.startswith("batch=")), 1)   # FlowConfig.hip_batch
 if kind == "bgr":   # three channels around the texture, so that the grey value still carries it
     frames = [np.stack([f // 2 + 20, f, 255 - (255 - f) // 2], axis=2).astype(np.uint8) for f in frames]
 pix = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -45,9 +49,10 @@ comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
 comp.set_sources({0: [Src()]})
 t_flow = t_comp = 0.0
 cfg = None
-if exact or prefetch:
+if exact or prefetch or device or batch > 1:
     from transflow_amd.config import FlowConfig  # noqa: E402
-    cfg = FlowConfig(hip_exact_sums=exact, hip_prefetch=2 if prefetch else 0)
+    cfg = FlowConfig(hip_exact_sums=exact, hip_device_flows=device, hip_batch=batch,
+                     **({"hip_prefetch": max(2, batch)} if prefetch else {}))
 with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backward", cv_config=cfg) as source:
     it = iter(source)
     for _ in range(6):                   # warm-up: handle creation, first launches, the pools of page-locked arrays
@@ -68,5 +73,5 @@ with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backwa
         t_flow += t1 - t0
         t_comp += t2 - t1
         k += 1
-print(f"{name} ({kind} frames in{', exact sums' if exact else ''}{', flow source prefetching' if prefetch else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
-      f"{k / (t_flow + t_comp):.1f} frames/s end to end through host arrays (one process)")
+print(f"{name} ({kind} frames in{', exact sums' if exact else ''}{', flow source prefetching' if prefetch else ''}{', flows stay on the device' if device else ''}{f', {batch} pairs per call' if batch > 1 else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
+      f"{k / (t_flow + t_comp):.1f} frames/s end to end {'(frames in, frames out)' if device else 'through host arrays'} (one process)")

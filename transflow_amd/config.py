@@ -104,6 +104,11 @@ class FlowConfig:
         # HBM until something reads them on the host, and that HipCompositor.update takes by device address (no 66 MB per
         # 4K frame down the link and up again across pipeline.py:562-567).  "ipc": the same, and through a multiprocessing
         # queue (pipeline.py:85-86) such a flow travels as a 64-byte HIP IPC handle instead of the pickled array.
+        # "hip_batch": n > 1 -- where nothing can look at a raw flow in between (no lock expressions, no convolution kernel,
+        # no initial flow), the source reads n frames ahead and computes their n pairs in ONE Farneback call: a single 4K
+        # pair leaves most of the chip idle at the coarse levels, a batch of four costs 0.6 of four single calls.  Flows
+        # still come out one at a time, in order, each post-processed with its own t.
+        self.hip_batch = max(1, int(kwargs.pop("hip_batch", 1) or 1))
         v = kwargs.pop("hip_device_flows", None)
         self.hip_device_flows = "ipc" if isinstance(v, str) and v.lower() == "ipc" else parse_bool_arg(v, False)
         self.extra = dict(kwargs)  # hs_*, lk_*, show_window ...: not used by this backend
@@ -123,6 +128,8 @@ class FlowConfig:
             d["hip_prefetch"] = self.hip_prefetch
         if self.hip_device_flows:
             d["hip_device_flows"] = self.hip_device_flows
+        if self.hip_batch > 1:
+            d["hip_batch"] = self.hip_batch
         return d
 
     def to_file(self, path: str):

@@ -7,7 +7,8 @@ multiprocessing queue when the source runs in its child process (transflow/pipel
 
 * it looks like the float32 (H, W, 2) array it stands for -- `shape`, `dtype`, indexing, arithmetic, `numpy.asarray(flow)`,
   anything numpy does with an object that has `__array__` -- and comes down (once, into a page-locked array) only when
-  something actually reads it on the host;
+  something actually reads it on the host; readers get read-only views, writing goes through the flow itself
+  (`flow[...] = v`, `flow *= 2`) and marks the device copy stale;
 * `HipCompositor.update` (every layer class) takes its device address: no transfer at all, the consumer's stream waits on
   the device for the event the producer recorded behind the flow's last kernel;
 * `pickle.dumps(flow)` is the pickle of the host array (a checkpoint never holds a device address);
@@ -125,7 +126,10 @@ class DeviceFlow(NDArrayOperatorsMixin):
         self._ready = ready
         self._ring, self._slot, self._owner = ring, slot, owner
         self._host = None
+        self._dirty = False                # the host values were modified in place: the device copy is stale
         self._cross = cross_process        # "ipc": a multiprocessing queue carries the IPC handle, not the array
+        self.in_frame = False              # set by a source whose post_process clipped the flow on the device: no rounded
+                                           # vector of it can leave the frame (the compositor need not look for one)
 
     # ---- what the compositor uses -------------------------------------------------------------------------------
     @property
@@ -157,8 +161,7 @@ class DeviceFlow(NDArrayOperatorsMixin):
         return self.shape[0]
 
     def host(self) -> np.ndarray:
-        """The flow as a host array: downloaded on first use (page-locked memory), the same array afterwards -- like
-        the reference's flow, it may be modified in place; the compositor then takes the modified values."""
+        """The flow's values on the host: downloaded on first use (page-locked memory), the same array afterwards."""
         if self._host is None:
             from .device import pinned_empty
             out = pinned_empty(self.shape, np.float32)
@@ -167,50 +170,68 @@ class DeviceFlow(NDArrayOperatorsMixin):
             self._host = out
         return self._host
 
+    def _read(self) -> np.ndarray:
+        """What readers get: a READ-ONLY view of the host values, so that looking at a flow (saving it, rendering it,
+        numpy.asarray) leaves the device copy the current one.  Writing goes through the flow itself -- `flow[...] = v`,
+        `flow *= 2`, `numpy.clip(flow, a, b, out=flow)` -- which marks the device copy stale: the compositor then takes
+        the host values, as the reference would have."""
+        if self._dirty:
+            return self.host()
+        v = self.host().view()
+        v.flags.writeable = False
+        return v
+
+    def _written(self) -> np.ndarray:
+        self._dirty = True
+        return self.host()
+
     @property
     def on_host(self) -> bool:
-        return self._host is not None
+        """True once the host values differ (or may differ) from the device copy."""
+        return self._dirty
 
     def __array__(self, dtype=None, copy=None):
-        a = self.host()
+        a = self._read()
         if dtype is not None and np.dtype(dtype) != a.dtype:
             return a.astype(dtype)
         return a.copy() if copy else a
 
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
-        if out is not None:
-            if any(isinstance(o, DeviceFlow) for o in out):
-                out = tuple(o.host() if isinstance(o, DeviceFlow) else o for o in out)
-            kwargs["out"] = out
-        args = [x.host() if isinstance(x, DeviceFlow) else x for x in inputs]
-        return getattr(ufunc, method)(*args, **kwargs)
+        args = [x._read() if isinstance(x, DeviceFlow) else x for x in inputs]
+        if out is None:
+            return getattr(ufunc, method)(*args, **kwargs)
+        # `flow *= 2`, numpy.clip(flow, a, b, out=flow): the host values change in place and the flow stays a flow
+        res = getattr(ufunc, method)(*args, out=tuple(o._written() if isinstance(o, DeviceFlow) else o for o in out), **kwargs)
+        if isinstance(res, tuple):
+            return tuple(o if isinstance(o, DeviceFlow) else r for o, r in zip(out, res))
+        return out[0] if isinstance(out[0], DeviceFlow) else res
 
     def __array_function__(self, func, types, args, kwargs):
         def down(x):
             if isinstance(x, DeviceFlow):
-                return x.host()
+                return x._read()
             if isinstance(x, (list, tuple)):
                 return type(x)(down(v) for v in x)
             return x
         return func(*down(args), **{k: down(v) for k, v in kwargs.items()})
 
     def __getitem__(self, key):
-        return self.host()[key]
+        return self._read()[key]
 
     def __setitem__(self, key, value):
-        self.host()[key] = value
+        self._written()[key] = value
 
     def __iter__(self):
-        return iter(self.host())
+        return iter(self._read())
 
     def __getattr__(self, name):
         # anything else an ndarray has (copy, astype, reshape, T, min, tobytes ...): the host array's
         if name.startswith("_"):
             raise AttributeError(name)
-        return getattr(self.host(), name)
+        return getattr(self._read(), name)
 
     def __repr__(self):
-        where = "host copy made" if self._host is not None else "on the device"
+        where = "modified on the host" if self._dirty else ("read on the host" if self._host is not None else "on the device")
         return f"DeviceFlow(shape={self.shape}, float32, {where})"
 
     # ---- pickling -----------------------------------------------------------------------------------------------
@@ -232,7 +253,7 @@ _OPENED: dict = {}      # (producer pid, slot index, handle bytes) -> mapped dev
 
 def _reduce_for_queue(flow: DeviceFlow):
     """ForkingPickler's reducer (multiprocessing queues and pipes only).  Runs in the queue's feeder thread."""
-    if flow._cross == "ipc" and flow._slot is not None and not flow.on_host:
+    if flow._cross == "ipc" and flow._slot is not None and flow._host is None:
         try:
             slot = flow._slot
             if slot.ipc_handle is None:
@@ -241,13 +262,13 @@ def _reduce_for_queue(flow: DeviceFlow):
                 slot.ipc_handle = bytes(h.raw)
             if flow._ready is not None:
                 flow._ready.synchronize()            # the flow is complete before another process may read it
-            return (_open_from_queue, (slot.ipc_handle, os.getpid(), slot.index, flow.shape))
+            return (_open_from_queue, (slot.ipc_handle, os.getpid(), slot.index, flow.shape, flow.in_frame))
         except Exception:                            # no IPC on this system: the array crosses instead
             flow._cross = None
     return (np.array, (flow.host(),))
 
 
-def _open_from_queue(handle: bytes, pid: int, index: int, shape):
+def _open_from_queue(handle: bytes, pid: int, index: int, shape, in_frame: bool = False):
     """In the consumer's process: map the producer's buffer (once per buffer), copy the flow out of it into memory of
     our own and hand that out -- the producer's buffer is free again when queue.get() returns."""
     lib = _lib.load()
@@ -262,7 +283,9 @@ def _open_from_queue(handle: bytes, pid: int, index: int, shape):
     check(lib.tf_dev_copy(C.c_void_p(slot.buf.ptr), C.c_void_p(src), ring.nbytes))
     check(lib.tf_sync())                             # done with the producer's memory
     slot.ready.record()
-    return DeviceFlow(shape, slot.buf.ptr, slot.ready, ring=ring, slot=slot)
+    flow = DeviceFlow(shape, slot.buf.ptr, slot.ready, ring=ring, slot=slot)
+    flow.in_frame = bool(in_frame)
+    return flow
 
 
 _CONSUMER_RINGS: dict = {}

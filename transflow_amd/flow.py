@@ -577,6 +577,9 @@ class HipFlowSource(FlowSource):
         self._prev_frame = None  # the decoded frame behind prev_gray
         self._fb = None
         self._prev_slot = None   # frame slot holding prev_gray on the device
+        self._batch_left = 0     # FlowConfig.hip_batch: flows of the last call not handed out yet ...
+        self._batch_pos = 0      # ... and which pair of the call comes next
+        self._pending_pair = 0   # the pair of the call behind the array read_next_flow handed out
         self._pending = None     # array handed out by read_next_flow whose flow is still on the device
         self._mask_dev = None
         self._flow_pool = None
@@ -595,7 +598,8 @@ class HipFlowSource(FlowSource):
             from .farneback import Farneback
             # Exactness belongs to the handle (tf_fb_set_exact): this source states what its configuration says, on OR off,
             # and touches nothing process-wide -- sources that disagree may be open together, in any threads.
-            self._fb = Farneback(self.width, self.height, device=self.device,
+            batch = self._batch_size()
+            self._fb = Farneback(self.width, self.height, device=self.device, frame_slots=batch + 1, max_pairs=batch,
                                  exact=bool(getattr(self.config, "hip_exact_sums", False)), **self.config.fb_kwargs())
             self._fb.keep_expansions(True)  # the frame that was "next" stays expanded for its turn as "prev"
             if getattr(self.config, "hip_prefetch", 0):
@@ -640,30 +644,48 @@ class HipFlowSource(FlowSource):
         self.prev_flow = None
         self._prev_slot = None
 
-    def _advance(self) -> None:
-        """cv.py:460-490 up to the call: read a frame, make it grey in the slot the older of the two frames
-        held, order (prev, next) by direction, run Farnebäck on the two slots.  The flow stays on the device."""
-        frame = self.provider.read()
-        if frame is None:
+    def _batch_size(self) -> int:
+        return max(1, int(getattr(self.config, "hip_batch", 1))) if self._resident_ok() else 1
+
+    def _advance(self, want: int = 1) -> int:
+        """cv.py:460-490 up to the call: read a frame, make it grey in a slot no pair still needs, order (prev, next) by
+        direction, run Farnebäck on the two slots.  The flow stays on the device.  `want` > 1 (FlowConfig.hip_batch): read
+        up to that many frames and run their consecutive pairs in ONE call -- frame slots are a ring of hip_batch + 1, the
+        last frame of a call is the first of the next; returns how many pairs were computed."""
+        frames = []
+        for _ in range(max(1, want)):
+            frame = self.provider.read()
+            if frame is None:
+                break
+            frames.append(frame)
+        if not frames:
             raise StopIteration
         if self._prev_frame is None:
             raise ValueError("Missing reference frames")
-        fb = self._handle()
+        fb = self._handle()                          # (the first GPU call of a source: after the provider has spoken)
         if self._prev_slot is None:                  # first frame, or after a rewind
             self._ingest(0, self._prev_frame)
             self._prev_slot = 0
-        new_slot = self._prev_slot ^ 1
-        self._ingest(new_slot, frame)
+        ring = fb.frame_slots
+        older, newer = [], []
+        slot = self._prev_slot
+        for frame in frames:
+            new_slot = (slot + 1) % ring
+            self._ingest(new_slot, frame)
+            older.append(slot)
+            newer.append(new_slot)
+            slot = new_slot
         if self._uses_initial_flow():                # cv.py:478: a copy of the previous flow, zeros before the first
             init = self.prev_flow if self.prev_flow is not None else np.zeros((self.height, self.width, 2), np.float32)
             fb.set_initial_flow(0, init)
         if self.direction == FlowSource.Direction.FORWARD:      # cv.py:467-472
-            fb.calc_slots([self._prev_slot], [new_slot])
+            fb.calc_slots(older, newer)
         elif self.direction == FlowSource.Direction.BACKWARD:
-            fb.calc_slots([new_slot], [self._prev_slot])
+            fb.calc_slots(newer, older)
         else:
             raise ValueError(f"Invalid flow direction '{self.direction}'")
-        self._prev_slot, self._prev_frame = new_slot, frame
+        self._prev_slot, self._prev_frame = slot, frames[-1]
+        return len(frames)
 
     # ---- resident form of one iteration -------------------------------------------------------
     # __next__ (source.py:293-321) calls read_next_flow() and hands its result straight to
@@ -686,7 +708,15 @@ class HipFlowSource(FlowSource):
             return FlowSource.read_next_flow(self)
         if self.input_frame_index == self.end_frame:
             self.rewind()
-        self._advance()
+            self._batch_left = 0
+        if self._batch_left == 0:
+            # never across the wrap of the input (source.py:286-291: the frame after end_frame is start_frame's)
+            until_wrap = self.end_frame - self.input_frame_index if self.end_frame > self.input_frame_index else self._batch_size()
+            self._batch_left = self._advance(min(self._batch_size(), max(1, until_wrap)))
+            self._batch_pos = 0
+        self._pending_pair = self._batch_pos
+        self._batch_pos += 1
+        self._batch_left -= 1
         self.input_frame_index += 1
         if getattr(self.config, "hip_device_flows", False):
             # the flow stays in HBM: a DeviceFlow over a buffer of the source's ring, filled by post_process
@@ -716,21 +746,23 @@ class HipFlowSource(FlowSource):
                 self._mask_dev = DevBuffer.from_array(
                     np.ascontiguousarray(self.mask, dtype=np.float32).reshape(self.height, self.width))
             mask_dev = self._mask_dev.ptr
-        fb.post_process_ex(0, self.direction.value, ops, mask_dev)
+        pair = self._pending_pair
+        fb.post_process_ex(pair, self.direction.value, ops, mask_dev)
         if not isinstance(raw, np.ndarray):
             # a DeviceFlow: out of the handle's result buffer (the next call but one writes it again) into the flow's own,
             # device to device on this thread's stream; the event behind the copy is what consumers wait for
             from . import _lib
             import ctypes as C
-            _lib.check(_lib.load().tf_dev_copy(C.c_void_p(raw.dev_ptr), C.c_void_p(fb.flow_ptr(0)), raw.nbytes))
+            _lib.check(_lib.load().tf_dev_copy(C.c_void_p(raw.dev_ptr), C.c_void_p(fb.flow_ptr(pair)), raw.nbytes))
             raw._ready.record()
+            raw.in_frame = True          # both directions of post_process end with the clip (source.py:361-362)
             return raw
         if self._prefetch is not None:
             # the worker thread: the flow starts its way down and the worker goes on to the next frame; it hands this
             # array to the consumer only once the transfer has ended (_Prefetch._run)
-            self._download_token = fb.get_flow_begin(0, raw)
+            self._download_token = fb.get_flow_begin(pair, raw)
         else:
-            fb.get_flow_into(0, raw)
+            fb.get_flow_into(pair, raw)
         return raw
 
     def next(self):

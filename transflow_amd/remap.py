@@ -128,7 +128,8 @@ class RemapLayer:
             flow.wait_on_stream()
             self.update_dev(flow.dev_ptr, u_dev, seed)
             flow.mark_used()
-            self.device_updates = getattr(self, "device_updates", 0) + 1
+            if not getattr(flow, "in_frame", False):
+                self.device_updates = getattr(self, "device_updates", 0) + 1
             return
         flow = np.asarray(flow)
         if flow.dtype != np.float32 and np.issubdtype(flow.dtype, np.floating):
