@@ -628,7 +628,12 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=32, help="frame pairs per pass (per GPU); 32 = a rank's whole shard of the clip at 8 GPUs")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="frame pairs per pass (per GPU), capped at the rank's shard of the clip: 64 at 1, 2 and 4 GPUs, a rank's "
+                         "whole shard (32, one rank 31) at 8.  64 pairs put 1152 columns of workgroups side by side at level 1 "
+                         "of a 4K pyramid -- more than the chip's 768 slots, so that level's march runs in segments on a full "
+                         "chip like level 0's -- and 576 at level 2 (profiles/r05_batch_sweep_4k.txt: one lane 1776 -> 1891 "
+                         "frames/s, two lanes 1883 -> 1913)")
     ap.add_argument("--clip-frames", type=int, default=256, help="T: frames of the clip that is sharded over the ranks")
     ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
                     help="Farneback handles per rank that take the batches in turn (2: consecutive batches are in flight "

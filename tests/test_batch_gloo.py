@@ -197,8 +197,8 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
     for r, p in enumerate(d["plans"]):
         assert p["rank"] == r
         assert tuple(p["frames"]) == (p["pairs"][0], p["pairs"][1] + 1)        # the halo frame
-        assert p["pairs_per_pass"] == min(32, p["n_pairs"])                        # bench.py's default --batch
-        assert p["pass_starts"] == batch_starts(p["n_pairs"], 32)
+        assert p["pairs_per_pass"] == min(64, p["n_pairs"])                        # bench.py's default --batch
+        assert p["pass_starts"] == batch_starts(p["n_pairs"], 64)
     if world == 8:                                                               # the case that must not hang
         assert [p["pairs_per_pass"] for p in d["plans"]] == [32] * 7 + [31]
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--equal-batches"],

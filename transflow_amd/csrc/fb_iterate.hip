@@ -361,9 +361,11 @@ struct RowProducer {
 #endif
 // s_v in two planes, even and odd strip columns apart (the odd plane's index XOR 8: a producer's 8-byte stores of one
 // 16-lane group then fall in both halves of the 32 banks): the consumers' single columns at each end of a window and
-// their pair come as conflict-free 8-byte reads where the 16-byte lane stride of a [128] row made them two-way conflicts
+// their pair come as conflict-free 8-byte reads where the 16-byte lane stride of a [128] row made them two-way conflicts.
+// Level-0 launch at 4K x 32 (profiles/r05_pmc_lds_bank_conflicts.txt): SQ_LDS_BANK_CONFLICT 87.1 M cycles -> 0,
+// SQ_LDS_IDX_ACTIVE 688 M -> 639 M, SQ_BUSY_CU_CYCLES -1.6 %; bit-identical results.  (0: the [128] rows of rounds 1-4)
 #ifndef TF_PC_SVSPLIT
-#define TF_PC_SVSPLIT 0
+#define TF_PC_SVSPLIT 1
 #endif
 #ifndef TF_PC_CONS
 #define TF_PC_CONS 2 // consumer waves per workgroup: they take turns by row (1: 1701, 2: 1723 frames/s at 4K x 32)
