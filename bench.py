@@ -102,6 +102,16 @@ class ClipSynth:
             return list(ex.map(self.frame, range(lo, hi)))
 
 
+def pick_lanes(w, h, pairs_per_pass):
+    """One lane or two for a rank's passes.  A second lane runs the part-empty launches of one batch -- the coarse levels,
+    the whole-column marches of levels whose columns of workgroups do not fill the chip's 768 slots -- beside the full ones
+    of the other.  From ~64 pairs of 4K per pass (530 M level-0 pixels) every level down to 1/4 scale fills the chip by
+    itself and there is nothing left to fill: 4K x 64 runs 1922 frames/s on one lane, 1905 on two (two batches in flight
+    only share the chip); 4K x 32, a rank's whole shard at 8 GPUs, 1776 on one and 1883 on two; 1080p x 64 6763 and 6984
+    (profiles/r05_batch_sweep_*.txt, r05_bench_4k_*)."""
+    return 1 if pairs_per_pass * w * h >= 64 * 3840 * 2160 else 2
+
+
 def make_plan(total_frames, batch, rank, world, equal=False):
     """Which pairs, frames and passes rank `rank` of `world` owns.  Shards differ by at
     most one pair, so the ranks' passes may differ in length (T = 256 over 8 ranks: 32 pairs on seven
@@ -599,7 +609,11 @@ def line_skeleton(args, wl, world, plans):
     return {
         "metric": "frames/sec (Farneback+remap)", "value": None, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        # every rank runs --batch pairs per step: weak; passes capped at the ranks' shards of the ONE clip (the default
+        # from 4 GPUs up): a step covers the whole clip whatever N is -- the total is fixed: strong
+        "higher_is_better": True,
+        "scaling": "weak" if all(p["pairs_per_pass"] == args.batch for p in plans) else "strong",
+        "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: one clip of T={args.clip_frames} {w}x{h} uint8 frames sharded over the ranks "
                                f"(rank r owns pairs shard_range({args.clip_frames - 1}, r, {world}) + a one-frame halo), "
@@ -611,7 +625,7 @@ def line_skeleton(args, wl, world, plans):
                    "frame_pairs_per_step_per_gpu": [p["pairs_per_pass"] for p in plans],
                    "frame_pairs_per_step": pairs_per_step,
                    "equal_batches": bool(args.equal_batches),
-                   "lanes": args.lanes,
+                   "lanes": [args.lanes or pick_lanes(w, h, p["pairs_per_pass"]) for p in plans],
                    "pairs_per_rank": [p["n_pairs"] for p in plans],
                    "frame_expansions": "pairs t and t+1 of a step share frame t+1: its pyramid levels and polynomial "
                                        "expansion (A1+A2, functions of the frame alone) are computed once per step and "
@@ -628,16 +642,18 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=64,
-                    help="frame pairs per pass (per GPU), capped at the rank's shard of the clip: 64 at 1, 2 and 4 GPUs, a rank's "
-                         "whole shard (32, one rank 31) at 8.  64 pairs put 1152 columns of workgroups side by side at level 1 "
-                         "of a 4K pyramid -- more than the chip's 768 slots, so that level's march runs in segments on a full "
-                         "chip like level 0's -- and 576 at level 2 (profiles/r05_batch_sweep_4k.txt: one lane 1776 -> 1891 "
-                         "frames/s, two lanes 1883 -> 1913)")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="frame pairs per pass (per GPU), capped at the rank's shard of the clip: 128 at 1 and 2 GPUs, a rank's "
+                         "whole shard at 4 (64, one rank 63) and 8 (32, one rank 31).  The more pairs a pass holds, the more "
+                         "of the pyramid's levels put at least as many columns of workgroups side by side as the chip has "
+                         "slots (768) and march in segments on a full chip like level 0: with 128 pairs of 4K levels 0 - 2 do "
+                         "(1152 columns at level 2), with 64 levels 0 - 1, with 32 level 0 alone.  One lane, 4K: 1776 / 1922 / "
+                         "1927 / 1973 frames/s at 32 / 64 / 96 / 128 pairs per pass (profiles/r05_batch_sweep_4k.txt)")
     ap.add_argument("--clip-frames", type=int, default=256, help="T: frames of the clip that is sharded over the ranks")
-    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
                     help="Farneback handles per rank that take the batches in turn (2: consecutive batches are in flight "
-                         "together on the library's two call streams, tf_fb_create_lane)")
+                         "together on the library's two call streams, tf_fb_create_lane).  0 (default): chosen per rank from "
+                         "what a pass holds (pick_lanes): one lane where a pass fills the chip by itself, two below that")
     ap.add_argument("--size", default=None, help="WxH: run the chosen workload's configuration at another frame size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed side measurements")
@@ -742,8 +758,9 @@ def main():
                 rccl.close()
             rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
         rccl_error = next((e for e in errs if e), None)
+    lanes = args.lanes or pick_lanes(w, h, plan["pairs_per_pass"])     # this rank's
     job = Job(wl, args.batch, plan, args.clip_frames, seed=2000, device=device, pixmap=pixmap, reset_mask=reset_mask,
-              pixmap_dev=pixmap_dev, lanes=args.lanes)
+              pixmap_dev=pixmap_dev, lanes=lanes)
     if pixmap_dev is not None:
         job.pixmap_buffer = pix_buf     # the job gathers from this buffer: it lives as long as the job
 
@@ -785,7 +802,7 @@ def main():
     elapsed = host.max_over_ranks(time.perf_counter() - t0)
     job.prof(False)
     dom_cnt, dom_ms = job.prof_report()[dominant]
-    recheck = host.gather(timed_region_recheck(job, args.lanes))
+    recheck = host.gather(timed_region_recheck(job, lanes))
     # the same kernel with nothing beside it: a few steps with a synchronisation after each, so neither the other lane's
     # batch nor the previous batch's remap shares the chip with it (in the timed region they do: that is what two lanes
     # are for, and a launch's duration there includes the time it shares)
@@ -863,7 +880,7 @@ def main():
     # The kernel's own figure: with one lane the timed region's launches have the chip to themselves and ARE it; with two
     # lanes a launch of the timed region shares the chip with the other lane's batch (its duration includes the time it
     # shares: `overlapped`), and the kernel's own figure is the `alone` measurement.
-    own = timed if args.lanes == 1 else alone
+    own = timed if lanes == 1 else alone
     step_frac = step_built * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS
     out.update({
         "rccl_ranks": world if rccl_version is not None else 0, "rccl_version": rccl_version,
@@ -873,16 +890,16 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant,
                      "achieved": own["achieved"] if own else None, "peak": rf.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": own["frac"] if own else None,
-                     "frac_source": ("timed region (one lane: nothing runs beside a launch)" if args.lanes == 1 else
+                     "frac_source": ("timed region (one lane: nothing runs beside a launch)" if lanes == 1 else
                                      "`alone`: the timed workload's launches with nothing beside them, right after the "
                                      "timed region" if alone else "not measured (--no-alone with two lanes): see `overlapped`"),
                      "avg_launch_ms": own["avg_launch_ms"] if own else None,
                      "step_frac": step_frac,     # = whole_step.frac: everything a step launches, built bytes / wall time
-                     "frac_overlapped": timed["frac"] if args.lanes > 1 else None,
+                     "frac_overlapped": timed["frac"] if lanes > 1 else None,
                      "overlapped": dict(timed, what="the timed region's own launches: with two lanes each shares the chip "
                                                     "with the other lane's batch and its duration includes that -- how long "
                                                     "a launch took, not how well the kernel uses the memory system")
-                                   if args.lanes > 1 else None,
+                                   if lanes > 1 else None,
                      "bytes_model": "bytes the kernel as built must move per launch (DESIGN.md §5): for the one-kernel "
                                     "iteration R0 20 + R1 20 + flow in 8 + flow out 8 = 56 B/px (M never leaves the CU).  "
                                     "SURVEY §8(d)'s stage-once model charges the reference's stages 96 B/px (M stored and "
@@ -954,7 +971,8 @@ def main():
                 w2 = WORKLOADS[name]
                 # the same bytes per call as the main workload: more pairs of the smaller frames
                 b2 = max(1, min(64, args.batch * (w * h) // (w2["w"] * w2["h"])))
-                j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=device, lanes=args.lanes)
+                j = Job(w2, b2, make_plan(b2 + 1, b2, 0, 1), b2 + 1, seed=2000, device=device,
+                        lanes=args.lanes or pick_lanes(w2["w"], w2["h"], b2))
                 g2 = None
                 if not args.no_gate:            # the same gate as the main workload, before its rate is reported
                     g2, _ = parity_gate(j, n_check=1)

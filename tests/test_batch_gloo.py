@@ -190,15 +190,16 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_gate", "rccl_ranks", "gather",
                 "per_rank_frames_per_s", "kernels_ms_per_step"):
         assert key in d, key
-    assert d["value"] is None and d["scaling"] == "weak" and d["config"]["clip_frames"] == 256
+    # passes capped at the ranks' shards: a step covers the whole clip at every N from 2 up (the total is fixed: strong)
+    assert d["value"] is None and d["scaling"] == "strong" and d["config"]["clip_frames"] == 256
     assert d["config"]["frame_pairs_per_step"] == sum(p["pairs_per_pass"] for p in d["plans"])
     pairs = [tuple(p["pairs"]) for p in d["plans"]]
     assert pairs == [shard_range(255, r, world) for r in range(world)]
     for r, p in enumerate(d["plans"]):
         assert p["rank"] == r
         assert tuple(p["frames"]) == (p["pairs"][0], p["pairs"][1] + 1)        # the halo frame
-        assert p["pairs_per_pass"] == min(64, p["n_pairs"])                        # bench.py's default --batch
-        assert p["pass_starts"] == batch_starts(p["n_pairs"], 64)
+        assert p["pairs_per_pass"] == min(128, p["n_pairs"])                       # bench.py's default --batch
+        assert p["pass_starts"] == batch_starts(p["n_pairs"], 128)
     if world == 8:                                                               # the case that must not hang
         assert [p["pairs_per_pass"] for p in d["plans"]] == [32] * 7 + [31]
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--equal-batches"],

@@ -298,7 +298,6 @@ static int fb_create(tf_fb **out, int width, int height, const tf_fb_params *par
         fb->frames.borrow(share->frames.p, N0 * frame_slots);
     if ((!share && (rc = fb->frames.alloc(N0 * frame_slots))) || (rc = fb->img.alloc(P * 2 * N0 * 4)) ||
         (rc = fb->R.alloc(P * 10 * N0 * 4)) ||
-        (rc = fb->M.alloc(P * 5 * N0 * 4)) ||
         (rc = fb->lflow[0].alloc(P * N0 * 8)) || (rc = fb->lflow[1].alloc(P * N0 * 8)) ||
         (rc = fb->lflow[2].alloc(P * N0 * 8)) ||
         (fb->nsets > 1 && ((rc = fb->lflow[3].alloc(P * N0 * 8)) || (rc = fb->lflow[4].alloc(P * N0 * 8)))) ||

@@ -392,6 +392,7 @@ bool fb_can_fuse_half_level(tf_fb *fb, int k);
 int fb_level1_polyexp(tf_fb *fb, int k, int n_images);
 int fb_level0_polyexp(tf_fb *fb, int k, int n_images);
 // ---- fb_matrices.hip ----
+int fb_m_room(tf_fb *fb, int w, int h, int n_pairs);
 int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int k = -1);
 int fb_carry_room(tf_fb *fb, size_t carry_doubles, size_t flags);
 int fb_check_fault(tf_fb *fb, const char *where);

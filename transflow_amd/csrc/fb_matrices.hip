@@ -633,8 +633,19 @@ __global__ void k_flow_area_init(const float2 *__restrict__ init, float2 *__rest
 namespace tf {
 namespace fb {
 
+// M is sized by the largest level that ever takes the two-kernel path (levels the one-kernel iteration serves never
+// store it: at 4K x 128 pairs that is levels 0 - 4, and a full-resolution M would be 21 GB nobody touches)
+int fb_m_room(tf_fb *fb, int w, int h, int n_pairs)
+{
+    const size_t need = (size_t)n_pairs * 5 * w * h * sizeof(float);
+    if (fb->M.bytes < need)
+        TF_TRY(fb->M.alloc(need)); // (hipFree waits for whatever still reads the old one)
+    return TF_OK;
+}
+
 int fb_update_matrices(tf_fb *fb, int w, int h, int n_pairs, const FlowInit &fi, int k)
 {
+    TF_TRY(fb_m_room(fb, w, h, n_pairs));
     dim3 grid(cdiv(w, UM_TW), cdiv(h, UM_TH), n_pairs);
     FlowInit f = fi;
     f.rmap = fb->rmap_dev;

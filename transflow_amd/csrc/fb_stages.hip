@@ -197,6 +197,7 @@ TF_API int tf_fb_stage_blur_solve(tf_fb *fb, const float *m, int w, int h, float
     TF_TRY(check_stage_size(fb, w, h));
     TF_TRY(ensure_init());
     size_t n = (size_t)w * h;
+    TF_TRY(fb_m_room(fb, w, h, 1));
     TF_TRY(upload_planar5(fb->M.as<float>(), m, n, fb->scratch));
     if (fb->gaussian()) // FarnebackUpdateFlow_GaussianBlur's window on a handle created with flags & 256
         TF_TRY(fb_gauss_solve(fb, w, h, 1, fb->lflow[0].as<float2>()));

@@ -193,7 +193,7 @@ def profile_traffic(name, width, height, levels, pairs, launches_per_step, itera
     pixel measured at 4K level 0, scaled to the pixels this workload's launches cover.  A PROFILE
     CONSTANT, not a measurement of the run that quotes it.  None when the kernel was never measured."""
     table = None
-    for fname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for fname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(_ROOT, "profiles", fname)
         if os.path.exists(path):
             with open(path) as f:
