@@ -388,6 +388,11 @@ int tf_remap_check(tf_remap *layer, int *out_of_frame);
    (reference.py:94-105); static: the masked copy of static.py:14-17. */
 int tf_remap_gather(tf_remap *layer, int source_index, const uint8_t *pixmap, int channels);
 int tf_remap_gather_dev(tf_remap *layer, int source_index, const void *pixmap_dev, int channels);
+/* tf_remap_gather with the pixmap going up on the library's upload stream, beside whatever the caller queued before it
+   (the same iteration of reference.py:94-105 / static.py:14-17; the call still returns with the host pixmap consumed):
+   for an update whose flow was on the device already (transflow/pipeline.py:562-567 with a DeviceFlow), where the
+   upload would otherwise wait for the update kernel. */
+int tf_remap_gather_beside(tf_remap *layer, int source_index, const uint8_t *pixmap, int channels);
 
 /* Introduction layer: one iteration of introduction.py:46-63 -- every target selected by the
    mask tf_remap_update left and by the source's introduction mask takes the record

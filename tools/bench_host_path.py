@@ -32,6 +32,10 @@ kind = sys.argv[3] if len(sys.argv) > 3 else "bgr"
 exact = "exact" in sys.argv[4:]          # flows bit-identical to the CPU path's (option fb_exact_sums)
 prefetch = "prefetch" in sys.argv[4:]
 device = "device" in sys.argv[4:]
+if "nobeside" in sys.argv[4:]:        # A/B: the pixmap's upload on the caller's stream even behind a device-flow update
+    from transflow_amd import remap as _remap
+    _g = _remap.RemapLayer.gather
+    _remap.RemapLayer.gather = lambda self, i, pm, beside=False: _g(self, i, pm, False)
 batch = next((int(a.split("=")[1]) for a in sys.argv[4:] if a.startswith("batch=")), 1)   # FlowConfig.hip_batch
 if kind == "bgr":   # three channels around the texture, so that the grey value still carries it
     frames = [np.stack([f // 2 + 20, f, 255 - (255 - f) // 2], axis=2).astype(np.uint8) for f in frames]

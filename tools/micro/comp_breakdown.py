@@ -48,7 +48,7 @@ with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backwa
         dev = layer._layer()
         dev.update(flow, None, 0)
         t2 = time.perf_counter()
-        dev.gather(0, pix)
+        dev.gather(0, pix, beside=True)
         t3 = time.perf_counter()
         c = comp._image()
         c.begin()

@@ -102,6 +102,14 @@ class _HipLayer:
     def update(self, flow):
         raise NotImplementedError()                                                    # layer.py:29-30
 
+    def _pixmap_beside(self, layer) -> bool:
+        """Whether this update's pixmaps go up on the library's upload stream (tf_remap_gather_beside) instead of the
+        caller's: when the flow was on the device already -- nothing of this update is on the link yet, and on the
+        caller's stream the upload would wait for the update kernel, itself behind the flow source's long kernels -- and
+        the frame is large enough for that wait to outweigh a second stream's bookkeeping (one box, alternating runs,
+        prefetching source: 4K 618 -> 637 frames/s, 1080p 1945 -> 1694; profiles/r05_host_path_experiments.txt)."""
+        return bool(getattr(layer, "flow_was_on_device", False)) and self.height * self.width >= (1 << 22)
+
     def render_into(self, comp):
         self._layer().render(comp)
 
@@ -175,8 +183,9 @@ class HipMoveReferenceLayer(_HipDataLayer):
         """move_reference.py:12-14: MovementLayer.update, then ReferenceLayer.update."""
         layer = self._layer()
         layer.update(flow, self._reset_field(), self.seed)
+        beside = self._pixmap_beside(layer)
         for i, source in enumerate(self.sources):                                      # reference.py:94-105
-            layer.gather(i, source.next())
+            layer.gather(i, source.next(), beside=beside)
 
 
 class HipSumLayer(_HipDataLayer):
@@ -188,8 +197,9 @@ class HipSumLayer(_HipDataLayer):
     def update(self, flow):
         layer = self._layer()
         layer.update(flow, self._reset_field(), self.seed)                             # sum.py:10 + reference.py:108
+        beside = self._pixmap_beside(layer)
         for i, source in enumerate(self.sources):                                      # reference.py:109
-            layer.gather(i, source.next())
+            layer.gather(i, source.next(), beside=beside)
 
 
 class HipStaticLayer(_HipLayer):

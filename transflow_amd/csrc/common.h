@@ -18,7 +18,7 @@ namespace tf {
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 hipStream_t stream();      // the stream launches go to: the library stream unless a StreamScope is active
 hipStream_t main_stream(); // the library stream (tf_stream)
-int side_stream(int which, hipStream_t *out); // 0: background work (lowest priority), 1, 2: a call's kernels (highest), 3, 4: uploads / downloads of a streaming caller
+int side_stream(int which, hipStream_t *out); // 0: background work (lowest priority), 1, 2: a call's kernels (highest), 3, 4: uploads / downloads of a streaming caller (3 also a compositor layer's pixmap)
 int ensure_init();
 
 // Documented run-time options (tf_set_option / tf_get_option, include/tfhip.h).

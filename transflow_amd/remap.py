@@ -128,9 +128,11 @@ class RemapLayer:
             flow.wait_on_stream()
             self.update_dev(flow.dev_ptr, u_dev, seed)
             flow.mark_used()
+            self.flow_was_on_device = True
             if not getattr(flow, "in_frame", False):
                 self.device_updates = getattr(self, "device_updates", 0) + 1
             return
+        self.flow_was_on_device = False
         flow = np.asarray(flow)
         if flow.dtype != np.float32 and np.issubdtype(flow.dtype, np.floating):
             # a float64 flow (post_process after a float64 convolution kernel returns one, source.py:344-348):
@@ -162,11 +164,14 @@ class RemapLayer:
         check(self._lib.tf_remap_check(self._h, C.byref(v)))
         return bool(v.value)
 
-    def gather(self, source_index: int, pixmap: np.ndarray) -> None:
+    def gather(self, source_index: int, pixmap: np.ndarray, beside: bool = False) -> None:
+        """beside: the pixmap goes up on the library's upload stream, beside the update queued before it
+        (tf_remap_gather_beside: for updates whose flow was on the device already)."""
         pm = np.ascontiguousarray(pixmap, dtype=np.uint8)
         if pm.ndim != 3 or pm.shape[:2] != (self.height, self.width):
             raise ValueError(f"pixmap shape {pm.shape} does not match the layer")
-        check(self._lib.tf_remap_gather(self._h, int(source_index), _ptr(pm), int(pm.shape[2])))
+        fn = self._lib.tf_remap_gather_beside if beside else self._lib.tf_remap_gather
+        check(fn(self._h, int(source_index), _ptr(pm), int(pm.shape[2])))
 
     def introduce(self, source_index: int, pixmap: np.ndarray, frame_number: int) -> None:
         """Introduction layer: one iteration of introduction.py:46-63."""
