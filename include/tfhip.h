@@ -393,6 +393,13 @@ int tf_remap_gather_dev(tf_remap *layer, int source_index, const void *pixmap_de
    for an update whose flow was on the device already (transflow/pipeline.py:562-567 with a DeviceFlow), where the
    upload would otherwise wait for the update kernel. */
 int tf_remap_gather_beside(tf_remap *layer, int source_index, const uint8_t *pixmap, int channels);
+/* The upload alone: the pixmap of `source.next()` (reference.py:99) into the layer's staging buffer -- on the library's
+   upload stream if `beside` -- for a caller that runs the frame's kernels later in one launch (tf_remap_step_dev with
+   *pixmap_dev: HipCompositor does, between update() and render(), compositor.py:27-40).  Returns with the host pixmap
+   consumed.  tf_remap_staged_used: call after queueing the last kernel that reads the staging buffer (the next
+   upload waits for it on the device). */
+int tf_remap_stage_pixmap(tf_remap *layer, const uint8_t *pixmap, int channels, int beside, void **pixmap_dev);
+int tf_remap_staged_used(tf_remap *layer);
 
 /* Introduction layer: one iteration of introduction.py:46-63 -- every target selected by the
    mask tf_remap_update left and by the source's introduction mask takes the record

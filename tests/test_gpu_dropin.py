@@ -375,7 +375,7 @@ def test_device_flows_stay_on_the_device_and_give_the_same_frames(direction):
     def run(cfg, zero_at=None):
         comp = HipCompositor.from_args(h, w, [LayerConfig(0, reset_mode="random", reset_random_factor=0.05)], rng="device")
         comp.set_sources({0: [Src()]})
-        kept, images = [], []
+        kept, images, states = [], [], []
         with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction=direction, cv_config=cfg) as source:
             for t, flow in enumerate(source):
                 if cfg is not None and cfg.hip_device_flows:
@@ -383,9 +383,15 @@ def test_device_flows_stay_on_the_device_and_give_the_same_frames(direction):
                 if t == zero_at:
                     flow *= 0                     # through the flow itself: the compositor must see zeros
                 comp.update(flow)
+                if t == 5:                        # looking at the layer between update() and render() (a device flow's
+                    states.append(comp.layers[0].data.copy())   # frame waits for render() to run as one launch: it is
+                if t == 7:                        # run the ordinary way first) -- and a checkpoint at that moment
+                    states.append(pickle.loads(pickle.dumps(comp)).layers[0]._pending_state[0].copy())
                 images.append(comp.render().copy())
                 kept.append(flow)
+        all_states.append(states)
         return kept, images
+    all_states = []
     plain_flows, plain_images = run(None)
     for cfg in (FlowConfig(hip_device_flows=True), FlowConfig(hip_device_flows=True, hip_prefetch=2),
                 FlowConfig(hip_device_flows=True, hip_prefetch=3, hip_batch=3)):
@@ -399,6 +405,9 @@ def test_device_flows_stay_on_the_device_and_give_the_same_frames(direction):
         back = pickle.loads(pickle.dumps(flows[3]))
         assert type(back) is np.ndarray
         np.testing.assert_array_equal(back, plain_flows[3])
+    for states in all_states[1:]:                 # the layer's state as seen between the two calls, and as checkpointed
+        for a, b in zip(all_states[0], states):
+            np.testing.assert_array_equal(a, b)
     zero_plain = run(None, zero_at=4)[1]
     zero_dev = run(FlowConfig(hip_device_flows=True), zero_at=4)[1]
     for a, b in zip(zero_plain, zero_dev):

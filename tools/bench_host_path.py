@@ -10,7 +10,7 @@ what the reference's child process + queue give it, pipeline.py:56-64): flow t +
 works on flow t.
 `device` (FlowConfig.hip_device_flows): the flows stay in HBM between the source and the compositor (DeviceFlow) -- the
 frame still goes up and the rendered frame still comes down, the 66 MB per 4K flow no longer travel at all.
-Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch] [device] [batch=n]"""
+Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch] [device] [batch=n] [reps=r]"""
 import os
 import sys
 import time
@@ -39,6 +39,10 @@ if "nobeside" in sys.argv[4:]:        # A/B: the pixmap's upload on the caller's
 batch = next((int(a.split("=")[1]) for a in sys.argv[4:] if a.startswith("batch=")), 1)   # FlowConfig.hip_batch
 if kind == "bgr":   # three channels around the texture, so that the grey value still carries it
     frames = [np.stack([f // 2 + 20, f, 255 - (255 - f) // 2], axis=2).astype(np.uint8) for f in frames]
+reps = next((int(a.split("=")[1]) for a in sys.argv[4:] if a.startswith("reps=")), 1)
+if reps > 1:            # a longer run over the same frames, there and back again (no jump between the last and the first)
+    frames = (frames + frames[-2:0:-1]) * reps + frames[:1]
+    n = len(frames) - 6
 pix = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
 
 

@@ -44,6 +44,6 @@ fi
 if [ "$part" = c ]; then
   python3 tools/fuzz_fused.py ${FUZZ_CASES:-1000} 12 > $out/r05_fuzz.txt 2>&1 || true
   tail -10 $out/r05_fuzz.txt
-  (for a in "1080p 96 bgr" "1080p 96 bgr prefetch" "1080p 96 bgr prefetch device" "1080p 96 bgr prefetch device batch=8" "4k 96 bgr" "4k 96 bgr prefetch" "4k 96 bgr prefetch device" "4k 96 bgr prefetch device batch=4" "4k 96 bgr exact prefetch device batch=4"; do python3 tools/bench_host_path.py $a; done) > $out/r05_host_path.txt 2>&1
+  (for a in "1080p 96 bgr" "1080p 96 bgr prefetch" "1080p 96 bgr prefetch device" "1080p 96 bgr prefetch device batch=8" "1080p 96 bgr prefetch device batch=16" "4k 48 bgr" "4k 48 bgr prefetch" "4k 48 bgr prefetch device" "4k 48 bgr prefetch device batch=2" "4k 48 bgr prefetch device batch=4" "4k 48 bgr exact prefetch device batch=2"; do python3 tools/bench_host_path.py $a reps=6; done) > $out/r05_host_path.txt 2>&1
   cat $out/r05_host_path.txt
 fi

@@ -126,6 +126,8 @@ PROTOTYPES = {
     "tf_remap_gather": (_I, [_P, _I, _P, _I]),
     "tf_remap_gather_dev": (_I, [_P, _I, _P, _I]),
     "tf_remap_gather_beside": (_I, [_P, _I, _P, _I]),
+    "tf_remap_stage_pixmap": (_I, [_P, _P, _I, _I, _PP]),
+    "tf_remap_staged_used": (_I, [_P]),
     "tf_flow_merge_dev": (_I, [_I, _I, _PP, _P, C.c_size_t]),
     "tf_flow_upscale_dev": (_I, [_P, _P, _I, _I, _I, _I]),
     "tf_flow_convolve_dev": (_I, [_P, _P, _I, _I, _I, _P, _I, _I]),

@@ -53,6 +53,8 @@ class _HipLayer:
         self._dev = None
         self._pending_state = None  # (data, rgba) to upload when the device layer is created
         self._sources_dirty = False
+        self._deferred = None       # a frame whose kernels wait for render() to run as ONE launch (_defer_step)
+        self._alone = False         # set by HipCompositor.update: this is the compositor's only layer
 
     # ---- device side -------------------------------------------------------------------
     def _layer(self):
@@ -110,10 +112,48 @@ class _HipLayer:
         prefetching source: 4K 618 -> 637 frames/s, 1080p 1945 -> 1694; profiles/r05_host_path_experiments.txt)."""
         return bool(getattr(layer, "flow_was_on_device", False)) and self.height * self.width >= (1 << 22)
 
+    # ---- one launch per frame where a frame allows it ---------------------------------------------------------
+    # Compositor.update and .render are two calls (compositor.py:27-40), three launches and a fill here: move + reset,
+    # gather, background, paint.  Where the layer is the compositor's only one, a moveref layer with one source, and the
+    # flow is on the device, update() only brings the pixmap up and remembers the frame; render() then runs
+    # tf_remap_step_dev -- the kernel bench.py times -- as the frame's ONE launch.  Anything that looks at the layer in
+    # between (data / rgba, a checkpoint, another update) first runs the remembered frame the ordinary way: same state.
+    def _defer_step(self, layer, flow) -> bool:
+        if not (self._alone and self.LAYER_CLASS == "moveref" and len(self.sources) == 1
+                and getattr(flow, "dev_ptr", None) is not None and not flow.on_host
+                and tuple(flow.shape) == (self.height, self.width, 2)):
+            return False
+        if self.HAS_RESET and self.config.reset_mode == "random" and self.rng == "numpy":
+            return False                    # the reset field is drawn on the host: it has to go up, the ordinary way
+        ptr, channels = layer.stage_pixmap(self.sources[0].next(), beside=self.height * self.width >= (1 << 22))
+        self._deferred = (flow, ptr, channels, self.seed)
+        return True
+
+    def _run_deferred(self, comp=None) -> None:
+        """comp: render() is asking -- one launch moves, resets, gathers, fills and paints; None: someone looks at the
+        layer first -- move + reset and gather as two launches, render() will paint as usual."""
+        if self._deferred is None:
+            return
+        flow, ptr, channels, seed = self._deferred
+        self._deferred = None
+        layer = self._dev
+        flow.wait_on_stream()
+        if comp is not None:
+            layer.step_dev(comp, flow.dev_ptr, ptr, channels, clip_flow=False, seed=seed)
+        else:
+            layer.update_dev(flow.dev_ptr, None, seed)
+            layer.gather_dev(0, ptr, channels)
+        flow.mark_used()
+        layer.staged_used()
+        if not getattr(flow, "in_frame", False):
+            layer.device_updates = getattr(layer, "device_updates", 0) + 1
+
     def render_into(self, comp):
+        self._run_deferred()
         self._layer().render(comp)
 
     def _state(self, which: int):
+        self._run_deferred()
         if self._dev is None:
             if self._pending_state is not None and self._pending_state[which] is not None:
                 return self._pending_state[which]
@@ -126,7 +166,8 @@ class _HipLayer:
 
     # ---- pickling (checkpoints, pipeline.py:225-242) --------------------------------------
     def __getstate__(self):
-        state = {k: v for k, v in self.__dict__.items() if k not in ("_dev", "_pending_state", "sources")}
+        self._run_deferred()
+        state = {k: v for k, v in self.__dict__.items() if k not in ("_dev", "_pending_state", "sources", "_deferred")}
         state["sources"] = []   # the pipeline strips sources before pickling (pipeline.py:236-238)
         if self._dev is not None:
             state["_saved_state"] = self._dev.get_state()
@@ -140,8 +181,10 @@ class _HipLayer:
         self._dev = None
         self._pending_state = saved
         self._sources_dirty = False
+        self._deferred = None
 
     def close(self):
+        self._deferred = None
         if self._dev is not None:
             self._dev.close()
             self._dev = None
@@ -182,6 +225,9 @@ class HipMoveReferenceLayer(_HipDataLayer):
     def update(self, flow):
         """move_reference.py:12-14: MovementLayer.update, then ReferenceLayer.update."""
         layer = self._layer()
+        self._run_deferred()
+        if self._defer_step(layer, flow):
+            return
         layer.update(flow, self._reset_field(), self.seed)
         beside = self._pixmap_beside(layer)
         for i, source in enumerate(self.sources):                                      # reference.py:94-105
@@ -274,14 +320,19 @@ class HipCompositor:
 
     def update(self, flow):
         for layer in self.layers:
+            layer._alone = len(self.layers) == 1
             layer.update(flow)
 
     def render(self) -> np.ndarray:
         """compositor.py:31-40: background, then every layer's opaque pixels in order."""
         comp = self._image()
-        comp.begin()
-        for layer in self.layers:
-            layer.render_into(comp)
+        only = self.layers[0] if len(self.layers) == 1 else None
+        if only is not None and getattr(only, "_deferred", None) is not None:
+            only._run_deferred(comp)      # the frame's one launch: move, reset, gather, background, paint
+        else:
+            comp.begin()
+            for layer in self.layers:
+                layer.render_into(comp)
         if self._frame_pool is None:
             from .device import ArrayPool
             self._frame_pool = ArrayPool((self.height, self.width, 3), np.uint8, pinned=True)

@@ -1212,13 +1212,10 @@ TF_API int tf_remap_gather(tf_remap *L, int source_index, const uint8_t *pixmap,
 // was on the device already (nothing else of this thread is on the link): 4K beside a prefetching flow source 0.78 ->
 // 0.65 ms per call, 617 -> 650 frames/s; behind an update that uploaded its flow it only adds a second stream to the link
 // (359 -> 289 frames/s), so the compositor asks for it per update.
-TF_API int tf_remap_gather_beside(tf_remap *L, int source_index, const uint8_t *pixmap, int channels)
+// The pixmap into the layer's staging buffer, on the library's upload stream (`beside`) or on the caller's; returns with
+// the host pixmap consumed and the caller's stream ordered behind the copy.
+static int stage_pixmap(tf_remap *L, const uint8_t *pixmap, int channels, bool beside)
 {
-    TF_REQUIRE(L && (pixmap || L->N == 0), "tf_remap_gather_beside: null pointer");
-    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_gather_beside: pixmap must have 3 or 4 channels, got %d", channels);
-    TF_TRY(ensure_init());
-    if (L->N == 0)
-        return TF_OK;
     const size_t bytes = (size_t)L->N * channels;
     if (L->scratch_pix.bytes < bytes)
         TF_TRY(L->scratch_pix.alloc(bytes));
@@ -1226,17 +1223,53 @@ TF_API int tf_remap_gather_beside(tf_remap *L, int source_index, const uint8_t *
         TF_HIP(hipEventCreateWithFlags(&L->pix_up, hipEventDisableTiming));
         TF_HIP(hipEventCreateWithFlags(&L->pix_used, hipEventDisableTiming));
     }
-    hipStream_t up;
-    TF_TRY(side_stream(3, &up)); // (a streaming flow source's frames go up on it too: one after the other at the link's rate)
-    if (L->pix_used_pending) // the copy waits, on the device, for the last kernel that read the staging buffer
+    hipStream_t up = stream();
+    if (beside)
+        TF_TRY(side_stream(3, &up)); // (a streaming flow source's frames go up on it too: one after the other at the link's rate)
+    if (beside && L->pix_used_pending) // the copy waits, on the device, for the last kernel that read the staging buffer
         TF_HIP(hipStreamWaitEvent(up, L->pix_used, 0));
     TF_HIP(hipMemcpyAsync(L->scratch_pix.p, pixmap, bytes, hipMemcpyHostToDevice, up));
     TF_HIP(hipEventRecord(L->pix_up, up));
-    TF_HIP(hipStreamWaitEvent(stream(), L->pix_up, 0));
+    if (beside)
+        TF_HIP(hipStreamWaitEvent(stream(), L->pix_up, 0));
+    TF_HIP(hipEventSynchronize(L->pix_up));
+    return TF_OK;
+}
+
+TF_API int tf_remap_gather_beside(tf_remap *L, int source_index, const uint8_t *pixmap, int channels)
+{
+    TF_REQUIRE(L && (pixmap || L->N == 0), "tf_remap_gather_beside: null pointer");
+    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_gather_beside: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_TRY(ensure_init());
+    if (L->N == 0)
+        return TF_OK;
+    TF_TRY(stage_pixmap(L, pixmap, channels, true));
     TF_TRY(tf_remap_gather_dev(L, source_index, L->scratch_pix.p, channels));
     TF_HIP(hipEventRecord(L->pix_used, stream()));
     L->pix_used_pending = true;
-    TF_HIP(hipEventSynchronize(L->pix_up));
+    return TF_OK;
+}
+
+TF_API int tf_remap_stage_pixmap(tf_remap *L, const uint8_t *pixmap, int channels, int beside, void **pixmap_dev)
+{
+    TF_REQUIRE(L && pixmap_dev && (pixmap || L->N == 0), "tf_remap_stage_pixmap: null pointer");
+    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_stage_pixmap: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_TRY(ensure_init());
+    *pixmap_dev = nullptr;
+    if (L->N == 0)
+        return TF_OK;
+    TF_TRY(stage_pixmap(L, pixmap, channels, beside != 0));
+    *pixmap_dev = L->scratch_pix.p;
+    return TF_OK;
+}
+
+TF_API int tf_remap_staged_used(tf_remap *L)
+{
+    TF_REQUIRE(L, "tf_remap_staged_used: null handle");
+    if (L->pix_up) {
+        TF_HIP(hipEventRecord(L->pix_used, stream()));
+        L->pix_used_pending = true;
+    }
     return TF_OK;
 }
 

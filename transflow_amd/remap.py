@@ -173,6 +173,19 @@ class RemapLayer:
         fn = self._lib.tf_remap_gather_beside if beside else self._lib.tf_remap_gather
         check(fn(self._h, int(source_index), _ptr(pm), int(pm.shape[2])))
 
+    def stage_pixmap(self, pixmap: np.ndarray, beside: bool = False):
+        """The upload of gather() alone (tf_remap_stage_pixmap): (device address, channels) of the staged pixmap, for
+        gather_dev / step_dev later on this thread's stream; staged_used() after the last kernel that reads it."""
+        pm = np.ascontiguousarray(pixmap, dtype=np.uint8)
+        if pm.ndim != 3 or pm.shape[:2] != (self.height, self.width):
+            raise ValueError(f"pixmap shape {pm.shape} does not match the layer")
+        p = C.c_void_p()
+        check(self._lib.tf_remap_stage_pixmap(self._h, _ptr(pm), int(pm.shape[2]), int(bool(beside)), C.byref(p)))
+        return p.value, int(pm.shape[2])
+
+    def staged_used(self) -> None:
+        check(self._lib.tf_remap_staged_used(self._h))
+
     def introduce(self, source_index: int, pixmap: np.ndarray, frame_number: int) -> None:
         """Introduction layer: one iteration of introduction.py:46-63."""
         pm = np.ascontiguousarray(pixmap, dtype=np.uint8)
