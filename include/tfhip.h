@@ -51,7 +51,9 @@ int tf_device_count(int *count);
      "fb_no_share"    0   1 = pairs of a call that share a frame expand it once each (read per call)
      "fb_no_overlap"  0   1 = a call's kernels stay on the library stream (read by tf_fb_create)
      "remap_px"       4   pixels per thread of tf_remap_step_dev's kernel: 1, 2 or 4
-     "remap_no_pack"  0   1 = tf_remap_step_dev keeps the layer state as int32 x 4 between steps
+     "remap_no_pack"  0   0 = tf_remap_step_dev keeps the layer state as ONE 32-bit word per pixel between steps where row,
+                          column, alpha and source index fit 13 + 13 + 1 + 5 bits (frames up to 8192 x 8192, 32
+                          sources), as int16 x 4 otherwise; 2 = as int16 x 4 at most; 1 = as int32 x 4 (never packed)
      "prof_levels"    0   1 = profiler labels carry the pyramid level
      "fb_exact_sums"  0   1 = the box window (flags without OPTFLOW_FARNEBACK_GAUSSIAN) is summed exactly as
                           FarnebackUpdateFlow_Blur sums it -- one set of running sums per image, float-differenced

@@ -370,11 +370,14 @@ def test_fused_step_finishes_forward_post_process(tf, leave_empty, shape):
     fb.close()
 
 
-def test_fused_step_state_in_int16_round_trips(tf):
-    """The fused step keeps the layer state as int16 x 4 between its own launches; any other entry point
-    sees the reference's int32 layout again.  Interleaves fused steps, a host update, state reads and a
-    restored checkpoint whose values do not fit int16 (the step then stays on int32)."""
+@pytest.mark.parametrize("no_pack", [0, 2])
+def test_fused_step_state_in_int16_round_trips(tf, lib_option, no_pack):
+    """The fused step keeps the layer state as one 32-bit word per pixel (row 13, column 13, alpha 1, source 5 bits; option
+    remap_no_pack = 0, the default) or as int16 x 4 (= 2) between its own launches; any other entry point sees the
+    reference's int32 layout again.  Interleaves fused steps, a host update, state reads and restored checkpoints whose
+    values do not fit the word (an alpha of 3: the step goes on in int16), then not int16 either (it stays on int32)."""
     from transflow_amd.device import DevBuffer
+    lib_option("remap_no_pack", no_pack)
     _, remap = tf
     h, w = 120, 173
     rng = np.random.default_rng(14)
@@ -422,6 +425,19 @@ def test_fused_step_state_in_int16_round_trips(tf):
     layer.set_state(np.clip(layer.get_state()[0], 0, 100), None)
     ora.data[...] = np.clip(ora.data, 0, 100)
     fused(flow_t(7))
+    np.testing.assert_array_equal(layer.get_state()[0], ora.data)
+    # a checkpoint with an alpha the 32-bit word cannot hold (it has one bit for it): int16 x 4 takes over
+    data = layer.get_state()[0].copy()
+    data[3, 4, 2] = 3
+    data[60:70, 80:90, 2] = 2
+    layer.set_state(data, None)
+    ora.data[...] = data
+    zero = np.zeros((h, w, 2), np.float32)
+    fused(zero)                                   # nothing moves: the odd alphas must come through the step unchanged
+    got = layer.get_state()[0]
+    np.testing.assert_array_equal(got, ora.data)
+    assert got[3, 4, 2] == 3 and (got[60:70, 80:90, 2] == 2).all()
+    fused(flow_t(8))
     np.testing.assert_array_equal(layer.get_state()[0], ora.data)
     assert not layer.out_of_frame()
 

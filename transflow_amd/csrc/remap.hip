@@ -297,14 +297,33 @@ __device__ __forceinline__ void state_store(short4s *p, size_t t, int4 d)
                                                  ((unsigned)d.z & 0xffffu) | ((unsigned)d.w << 16));
 }
 
-__global__ void k_state_pack(const int4 *__restrict__ src, short4s *__restrict__ dst, int N)
+// ... or, where they fit, ONE 32-bit word (round 5): row 13 bits, column 13 bits, alpha 1 bit, source index 5 bits --
+// frames up to 8192 x 8192, up to 32 sources, alpha 0 or 1 (all the layer itself ever writes: 1 at creation, on a move
+// and on a reset, 0 where a moving pixel leaves an empty spot).  The step reads the state twice per pixel (at the pixel
+// and at its source) and writes it once: 12 of its ~34 bytes per pixel instead of 24 of ~44.
+struct packed32 {
+    unsigned v;
+};
+__device__ __forceinline__ int4 state_load(const packed32 *p, size_t t)
+{
+    const unsigned v = p[t].v;
+    return make_int4((int)(v & 0x1fffu), (int)((v >> 13) & 0x1fffu), (int)((v >> 26) & 1u), (int)(v >> 27));
+}
+__device__ __forceinline__ void state_store(packed32 *p, size_t t, int4 d)
+{
+    p[t].v = ((unsigned)d.x & 0x1fffu) | (((unsigned)d.y & 0x1fffu) << 13) | (((unsigned)d.z & 1u) << 26) | ((unsigned)d.w << 27);
+}
+
+template <typename S>
+__global__ void k_state_pack(const int4 *__restrict__ src, S *__restrict__ dst, int N)
 {
     int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t < N)
         state_store(dst, t, src[t]);
 }
 
-__global__ void k_state_unpack(const short4s *__restrict__ src, int4 *__restrict__ dst, int N)
+template <typename S>
+__global__ void k_state_unpack(const S *__restrict__ src, int4 *__restrict__ dst, int N)
 {
     int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t < N)
@@ -431,7 +450,12 @@ k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *_
 {
     __shared__ uint32_t s_rgb[PX * BLOCK * 3 / 4];
     uint8_t *s8 = reinterpret_cast<uint8_t *>(s_rgb);
-    const int t0 = blockIdx.x * (PX * BLOCK) + threadIdx.x;
+    // Blocks are dealt round-robin over the 8 XCDs, each with its own L2: renumbered so that one XCD walks a contiguous
+    // eighth of the frame, the state a pixel reads at its SOURCE -- a few rows and columns away -- is the state the
+    // neighbouring blocks of the same XCD read at their own pixels: one fetch per L2 instead of two (round 5).
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, qn = nb >> 3, rn = nb & 7;
+    const unsigned bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+    const int t0 = bid * (PX * BLOCK) + threadIdx.x;
     int t[PX], tc[PX];
     bool live[PX];
 #pragma unroll
@@ -577,7 +601,7 @@ k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *_
         s8[k + 2] = o.z;
     }
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * (PX * BLOCK) * 3; // multiple of 4
+    const size_t base = (size_t)bid * (PX * BLOCK) * 3; // multiple of 4
     const size_t total = (size_t)N * 3;
     for (int idx = threadIdx.x; idx < PX * BLOCK * 3 / 4; idx += BLOCK) {
         const size_t b = base + (size_t)idx * 4;
@@ -838,12 +862,13 @@ struct tf_remap {
     DevBuf scratch_flow, scratch_u, scratch_pix;
     DevBuf flow_scratch; // tf_remap_step_dev's unfused form on a winner map: the flow it stands for
     uint64_t frame = 0;
-    // the fused step keeps the state as int16 x 4 (k_remap_step's note); every other entry point that
-    // touches `data` converts it back first (state_unpacked)
+    // the fused step keeps the state as one 32-bit word or as int16 x 4 (k_remap_step's note); every other entry point
+    // that touches `data` converts it back first (state_unpacked)
     DevBuf pdata[2];
     int pcur = 0;
-    bool packed = false;       // pdata[pcur] is current, data[cur] is stale
+    int packed = 0;            // 0: data[cur] is current; 1: pdata[pcur] as int16 x 4; 2: pdata[pcur] as one word (data[cur] stale)
     bool state_fits = true;    // false after a set_state with values outside int16
+    bool state_fits32 = true;  // false after a set_state with a row / column outside [0, 8191], an alpha other than 0 / 1 or a source index outside [0, 31]
     // tf_remap_gather_beside: the pixmap goes up on the library's upload stream, beside the update kernel queued before it
     hipEvent_t pix_up = nullptr, pix_used = nullptr; // the upload's end; the end of the last kernel that read scratch_pix
     bool pix_used_pending = false;
@@ -861,29 +886,46 @@ static int state_unpacked(tf_remap *L)
 {
     if (!L->packed)
         return TF_OK;
-    TF_TRY(launch("remap_state_unpack", k_state_unpack, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
-                  (const short4s *)L->pdata[L->pcur].as<short4s>(), L->cur_data(), L->N));
-    L->packed = false;
+    const dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
+    if (L->packed == 2)
+        TF_TRY(launch("remap_state_unpack", k_state_unpack<packed32>, grid, block, 0,
+                      (const packed32 *)L->pdata[L->pcur].as<packed32>(), L->cur_data(), L->N));
+    else
+        TF_TRY(launch("remap_state_unpack", k_state_unpack<short4s>, grid, block, 0,
+                      (const short4s *)L->pdata[L->pcur].as<short4s>(), L->cur_data(), L->N));
+    L->packed = 0;
     return TF_OK;
 }
 
-static bool state_can_pack(const tf_remap *L)
+// How the fused step may keep the state: 2 = one word per pixel, 1 = int16 x 4, 0 = as it is (option remap_no_pack: 1 = never
+// packed, 2 = never as one word)
+static int state_can_pack(const tf_remap *L)
 {
-    const bool off = option(OPT_REMAP_NO_PACK) != 0;
-    return !off && L->state_fits && L->H <= 32767 && L->W <= 32767 && L->n_sources <= 32767;
+    const long off = option(OPT_REMAP_NO_PACK);
+    if (off == 1)
+        return 0;
+    if (off != 2 && L->state_fits32 && L->H <= 8192 && L->W <= 8192 && L->n_sources <= 32)
+        return 2;
+    return (L->state_fits && L->H <= 32767 && L->W <= 32767 && L->n_sources <= 32767) ? 1 : 0;
 }
 
-// Makes pdata[pcur] (int16) the current state.
-static int state_packed(tf_remap *L)
+// Makes pdata[pcur] in form `kind` (1: int16 x 4, 2: one word) the current state.
+static int state_packed(tf_remap *L, int kind)
 {
-    if (L->packed)
+    if (L->packed == kind)
         return TF_OK;
+    TF_TRY(state_unpacked(L));
     for (auto &b : L->pdata)
         if (!b.p)
-            TF_TRY(b.alloc((size_t)L->N * sizeof(short4s)));
-    TF_TRY(launch("remap_state_pack", k_state_pack, dim3(cdiv((size_t)L->N, BLOCK)), dim3(BLOCK), 0,
-                  (const int4 *)L->cur_data(), L->pdata[L->pcur].as<short4s>(), L->N));
-    L->packed = true;
+            TF_TRY(b.alloc((size_t)L->N * sizeof(short4s))); // (room for either form)
+    const dim3 grid(cdiv((size_t)L->N, BLOCK)), block(BLOCK);
+    if (kind == 2)
+        TF_TRY(launch("remap_state_pack", k_state_pack<packed32>, grid, block, 0, (const int4 *)L->cur_data(),
+                      L->pdata[L->pcur].as<packed32>(), L->N));
+    else
+        TF_TRY(launch("remap_state_pack", k_state_pack<short4s>, grid, block, 0, (const int4 *)L->cur_data(),
+                      L->pdata[L->pcur].as<short4s>(), L->N));
+    L->packed = kind;
     return TF_OK;
 }
 
@@ -1350,10 +1392,15 @@ TF_API int tf_remap_set_state(tf_remap *L, const int32_t *data, const uint8_t *r
     TF_TRY(state_unpacked(L));
     size_t n = (size_t)L->N;
     if (data && n && L->depth() == 4) { // a checkpoint may hold anything: the int16 form only for values that fit
-        bool fits = true;
-        for (size_t q = 0; q < n * 4 && fits; q++)
-            fits = data[q] >= -32768 && data[q] <= 32767;
+        bool fits = true, fits32 = true;
+        for (size_t q = 0; q < n * 4 && (fits || fits32); q++) {
+            const int32_t v = data[q];
+            fits = fits && v >= -32768 && v <= 32767;
+            const int c = (int)(q & 3);
+            fits32 = fits32 && v >= 0 && v <= (c < 2 ? 8191 : (c == 2 ? 1 : 31));
+        }
         L->state_fits = fits;
+        L->state_fits32 = fits32;
     }
     if (data && n && L->depth())
         TF_HIP(hipMemcpyAsync(L->cur_data(), data, n * 4 * L->depth(), hipMemcpyHostToDevice, stream()));
@@ -1425,9 +1472,12 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
                                  : go(k_remap_step_px<3, S, 2>, "remap_step_rgb", 2);
         return channels == 4 ? go(k_remap_step<4, S>, "remap_step_rgba", 1) : go(k_remap_step<3, S>, "remap_step_rgb", 1);
     };
-    if (state_can_pack(L)) {
-        TF_TRY(state_packed(L));
-        TF_TRY(run((const short4s *)L->pdata[L->pcur].as<short4s>(), L->pdata[L->pcur ^ 1].as<short4s>()));
+    if (const int kind = state_can_pack(L)) {
+        TF_TRY(state_packed(L, kind));
+        if (kind == 2)
+            TF_TRY(run((const packed32 *)L->pdata[L->pcur].as<packed32>(), L->pdata[L->pcur ^ 1].as<packed32>()));
+        else
+            TF_TRY(run((const short4s *)L->pdata[L->pcur].as<short4s>(), L->pdata[L->pcur ^ 1].as<short4s>()));
         L->pcur ^= 1;
         L->frame++;
         return TF_OK;

@@ -175,9 +175,11 @@ BUILT_FB_KERNELS = ("fb_flow_iter", "fb_update_matrices", "fb_blur_solve", "fb_l
 
 def built_remap_bytes(width, height, reset_mask=False, forward=False) -> int:
     """The one-kernel remap step per frame: flow 8 (FORWARD: winner map 4, plus the scatter pass that makes
-    it: flow 8 read + map 4 initialised + 4 claimed), layer state int16 x 4 read at the source and written
-    (8 + 8), pixmap 3, rgba 4, RGB frame 3, reset mask 4."""
-    per_px = (4 + 16 if forward else 8) + 16 + 3 + 4 + 3 + (4 if reset_mask else 0)
+    it: flow 8 read + map 4 initialised + 4 claimed), layer state read at the source and written -- one 32-bit word
+    per pixel for frames up to 8192 x 8192 (4 + 4; round 5), int16 x 4 beyond (8 + 8) --, pixmap 3, rgba 4, RGB frame 3,
+    reset mask 4."""
+    state = 8 if width <= 8192 and height <= 8192 else 16
+    per_px = (4 + 16 if forward else 8) + state + 3 + 4 + 3 + (4 if reset_mask else 0)
     return per_px * width * height
 
 
