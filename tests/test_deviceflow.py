@@ -65,3 +65,29 @@ def test_through_a_multiprocessing_pickler_without_ipc_it_is_the_array_too():
     f._cross = "ipc"            # asked for, but the values are on the host already: still the array
     back = pickle.loads(bytes(ForkingPickler.dumps(f)))
     assert type(back) is np.ndarray
+
+
+def test_a_buffer_that_left_as_an_ipc_token_stays_out_of_rotation(monkeypatch):
+    """A flow that crosses a multiprocessing queue as an IPC handle is garbage in the producer as soon as it is pickled;
+    the other process reads the buffer later, inside its queue.get().  The ring must not hand that buffer out again until
+    EXPORT_HOLD more flows have left the same way (CPU: the device buffers and events are stood in for)."""
+    from transflow_amd import deviceflow as DF
+
+    class Slot:
+        def __init__(self, nbytes, index):
+            self.index, self.used, self.exported_at, self.ipc_handle = index, None, None, None
+    monkeypatch.setattr(DF, "_Slot", Slot)
+    ring = DF.FlowRing((4, 5, 2), slots=4)
+    a = ring.take()
+    ring.give_back(a)
+    assert ring.take() is a                       # an ordinary buffer: back at once
+    ring.exported(a)                              # a flow in it left as a token ...
+    ring.give_back(a)                             # ... and was dropped by the producer
+    seen = []
+    for _ in range(DF.FlowRing.EXPORT_HOLD - 1):
+        s = ring.take()
+        assert s is not a
+        seen.append(s)
+        ring.exported(s)
+        ring.give_back(s)
+    assert ring.take() is a                       # EXPORT_HOLD exports later it is in rotation again

@@ -125,7 +125,14 @@ class _HipLayer:
             return False
         if self.HAS_RESET and self.config.reset_mode == "random" and self.rng == "numpy":
             return False                    # the reset field is drawn on the host: it has to go up, the ordinary way
-        ptr, channels = layer.stage_pixmap(self.sources[0].next(), beside=self.height * self.width >= (1 << 22))
+        try:
+            pixmap = self.sources[0].next()
+        except BaseException:
+            # the reference has moved the layer by the time a source runs dry (movement.py:20-60 come before
+            # reference.py:99): so has this one when the exception reaches the pipeline (pipeline.py:580-586)
+            layer.update(flow, None, self.seed)
+            raise
+        ptr, channels = layer.stage_pixmap(pixmap, beside=self.height * self.width >= (1 << 22))
         self._deferred = (flow, ptr, channels, self.seed)
         return True
 

@@ -70,6 +70,7 @@ class _Slot:
         self.ready = _Event()
         self.used = None
         self.ipc_handle = None          # exported once, on first use
+        self.exported_at = None         # the ring's export count when a flow in this buffer last left as an IPC token
 
     def close(self):
         self.buf.close()
@@ -80,9 +81,13 @@ class _Slot:
 
 class FlowRing:
     """The device buffers a flow source's DeviceFlows live in.  A buffer goes back into rotation when the DeviceFlow over
-    it is garbage; the producer's stream then waits (on the device) for the last kernel that read it.  Flows that crossed
-    a process boundary were copied out by the consumer inside its queue.get() (see the module text), so in that mode the
-    ring only has to outlast the queue's depth: `slots` >= queue depth + 3."""
+    it is garbage; the producer's stream then waits (on the device) for the last kernel that read it.  A flow that left
+    as an IPC token is garbage here as soon as it is pickled, long before the other process has read it (it copies the flow
+    out inside its queue.get(), see the module text): such a buffer stays out of rotation until EXPORT_HOLD more flows
+    have left the same way -- a producer can only be that far ahead of its consumer through a queue deeper than
+    EXPORT_HOLD - 2 (transflow/pipeline.py:326: maxsize = 1)."""
+
+    EXPORT_HOLD = 8
 
     def __init__(self, shape, slots: int = 4):
         self.shape = tuple(int(v) for v in shape)
@@ -90,13 +95,20 @@ class FlowRing:
         self.slots = max(2, int(slots))
         self._all: list[_Slot] = []
         self._free: list[_Slot] = []
+        self.exports = 0
+
+    def exported(self, slot: "_Slot") -> None:
+        slot.exported_at = self.exports
+        self.exports += 1
 
     def take(self) -> _Slot:
-        if self._free:
-            slot = self._free.pop(0)
+        slot = next((s for s in self._free
+                     if s.exported_at is None or self.exports - s.exported_at >= self.EXPORT_HOLD), None)
+        if slot is not None:
+            self._free.remove(slot)
         else:
             slot = _Slot(self.nbytes, len(self._all))
-            self._all.append(slot)           # (more flows held by the caller than `slots`: the ring grows)
+            self._all.append(slot)           # (more flows held -- or on their way to another process -- than `slots`: the ring grows)
         if slot.used is not None:
             slot.used.stream_wait()          # the producer's writes stay behind the consumer's last read
         return slot
@@ -262,6 +274,8 @@ def _reduce_for_queue(flow: DeviceFlow):
                 slot.ipc_handle = bytes(h.raw)
             if flow._ready is not None:
                 flow._ready.synchronize()            # the flow is complete before another process may read it
+            if flow._ring is not None:
+                flow._ring.exported(slot)            # ... and its buffer stays untouched until that process has had time to
             return (_open_from_queue, (slot.ipc_handle, os.getpid(), slot.index, flow.shape, flow.in_frame))
         except Exception:                            # no IPC on this system: the array crosses instead
             flow._cross = None
