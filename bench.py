@@ -556,6 +556,99 @@ def gather_leg(job, host, rccl, plans, reps=3):
             "frames_per_s_with_gather_beside_the_next_step": sum(per_pass) / dt_beside}
 
 
+def flows_to_root_leg(job, host, rccl, plans):
+    """SURVEY.md §8e mode F, outside the timed region: the whole clip's flows go to rank 0, each pass's to the clip
+    position of its first pair (transflow_amd.batch.flows_to_root_calls, one tf_batch_gather_at per pass index), and
+    rank 0 runs ONE remap recurrence over them in clip order -- the frames the reference's one compositor would paint for
+    the clip (pipeline.py:565), which the per-rank streams of the timed region are not beyond each rank's first pair.
+    Checked: the CRC of the first and the last flow of every rank's last pass as they sit in the root's clip buffer
+    against what that rank computed; and the frame the root's stream paints at the end of rank 0's first pass against
+    the frame rank 0 paints from its own flows with a fresh layer (same flows, same order, same state: same bytes)."""
+    from transflow_amd.batch import flows_to_root_calls
+    from transflow_amd.device import DevBuffer
+    if job.wl["direction"] == 0:
+        return {"skipped": "a FORWARD workload hands the compositor winner maps made beside the flow buffer "
+                           "(Farneback.post_process_scatter); the leg runs on BACKWARD workloads"}
+    w, h = job.wl["w"], job.wl["h"]
+    flow_bytes = w * h * 8
+    world, rank = host.world, host.rank
+    calls = flows_to_root_calls(plans, flow_bytes)
+    total_pairs = calls[0][0]["recv_capacity"] // flow_bytes
+    clip = DevBuffer(total_pairs * flow_bytes) if rank == 0 else None
+
+    def collect(sync_each):
+        for k, call in enumerate(calls):
+            me = call[rank]
+            send = 0
+            if me["send_bytes"]:
+                job.calc_pass(k)
+                send = job.fb.flow_ptr(0)
+            rccl.gather_at(send, me["send_bytes"], None if clip is None else clip.ptr, me["recv_bytes"], me["recv_offsets"],
+                           me["recv_capacity"])
+            if sync_each:
+                job.sync()
+
+    def paint(layer, flow_of, n, stop_after=None):
+        """the serial remap over n flows; -> CRC of the frame painted for flow `stop_after`"""
+        crc = None
+        for j in range(n):
+            layer.step_dev(job.comps[j % job.batch], flow_of(j), job.pixmap_dev, 3, clip_flow=True, seed=SEED_U)
+            if j == stop_after:
+                crc = zlib.crc32(job.comps[j % job.batch].download().tobytes())
+        return crc
+
+    # what each rank knows of its own: the first and last flow of its last pass; rank 0 also the frame that ends its first pass
+    collect(True)
+    base = job.fb.flow_ptr(0)
+    own = []
+    for i in (0, job.batch - 1):
+        a = np.empty(flow_bytes, np.uint8)
+        job.check(job.lib.tf_dev_download(C.c_void_p(a.ctypes.data), C.c_void_p(base + i * flow_bytes), flow_bytes))
+        own.append(zlib.crc32(a.tobytes()))
+    own_all = host.gather(own)
+    ok_flows = ok_stream = None
+    if rank == 0:
+        ok_flows = True
+        for r, p in enumerate(plans):
+            at = (p["pairs"][0] - plans[0]["pairs"][0] + p["pass_starts"][-1]) * flow_bytes
+            got = []
+            for i in (0, p["pairs_per_pass"] - 1):
+                got.append(zlib.crc32(clip.download((flow_bytes,), np.uint8, offset=at + i * flow_bytes).tobytes()))
+            ok_flows = ok_flows and got == list(own_all[r])
+        job.calc_pass(0)
+        mine = job.fb.flow_ptr(0)
+        want = paint(job.make_layer(), lambda j: mine + j * flow_bytes, job.batch, job.batch - 1)
+        root_layer = job.make_layer()
+        got = paint(root_layer, lambda j: clip.ptr + j * flow_bytes, total_pairs, job.batch - 1)
+        job.sync()
+        ok_stream = got == want
+        oob = bool(root_layer.out_of_frame())
+    # the rate of the mode: every pass of every rank, the gathers, the root's remap of the clip, end to end
+    host.barrier()
+    t0 = time.perf_counter()
+    collect(False)
+    job.sync()
+    t_collect = time.perf_counter() - t0
+    if rank == 0:
+        paint(job.make_layer(), lambda j: clip.ptr + j * flow_bytes, total_pairs)
+        job.sync()
+    host.barrier()
+    dt = host.max_over_ranks(time.perf_counter() - t0)
+    t_collect = host.max_over_ranks(t_collect)
+    if clip is not None:
+        clip.close()
+    if rank != 0:
+        return None
+    into_root = sum(c[r]["send_bytes"] for c in calls for r in range(1, world))
+    return {"what": "untimed region, SURVEY 8e mode F: every pass's flows (float32 u, v) to their clip positions on rank 0, one "
+                    "tf_batch_gather_at per pass index; rank 0 then runs ONE remap recurrence over the clip in order",
+            "clip_pairs": total_pairs, "gathers": len(calls), "bytes_into_root": into_root,
+            "ms_passes_and_gathers": t_collect * 1e3, "ms_root_remap": (dt - t_collect) * 1e3, "ms": dt * 1e3,
+            "frames_per_s": total_pairs / dt, "verified_flow_crc": bool(ok_flows), "verified_stream": bool(ok_stream),
+            "remap_out_of_frame": oob}
+
+
+FLOWS_TO_ROOT_LEG = flows_to_root_leg
 GATHER_LEG = gather_leg     # (a name of its own: tests replace it to see what a failing or hanging side leg does to the line)
 
 
@@ -692,7 +785,7 @@ def main():
             line = line_skeleton(args, wl, world, plans)     # the keys of a measured line, nulls where a GPU would speak
             line.update({"rccl_ranks": None, "rccl_version": None, "per_rank_frames_per_s": None,
                          "parity_gate": "skipped (--dry-run)", "timed_region_recheck": None, "roofline": None, "cpu_baseline": None,
-                         "kernels_ms_per_step": None, "remap_out_of_frame": None, "gather": None,
+                         "kernels_ms_per_step": None, "remap_out_of_frame": None, "gather": None, "flows_to_root": None,
                          "dry_run": True, "clip_frames": args.clip_frames, "plans": plans})
             print(json.dumps(line))
         host.close()
@@ -828,17 +921,23 @@ def main():
     # Everything the result line needs from the other ranks has been collected by now.  What follows are
     # untimed side legs: each runs under a time limit and reports its failure in the line instead of losing it.
     leg_errors = {}
-    gather, rccl_version = None, None
+    gather, flows_to_root, rccl_version = None, None, None
     if rccl is not None:
         rccl_version = rccl.rccl_version
 
         def leg():
             g = GATHER_LEG(job, host, rccl, plans)
-            rccl.close()
-            return g
+            f = None
+            try:
+                f = FLOWS_TO_ROOT_LEG(job, host, rccl, plans)
+            except Exception as err:    # noqa: BLE001 -- reported in the line; the gather leg's result stands
+                leg_errors["flows_to_root"] = f"{type(err).__name__}: {err}"
+            finally:
+                rccl.close()
+            return g, f
 
         try:
-            gather = run_with_timeout(leg, float(os.environ.get("TF_BENCH_LEG_TIMEOUT", 240)))
+            gather, flows_to_root = run_with_timeout(leg, float(os.environ.get("TF_BENCH_LEG_TIMEOUT", 240)))
         except TimeoutError as err:
             STUCK_THREADS = True        # a helper thread sits in a call that never returned; the sockets are its
             rccl.abandon()
@@ -932,6 +1031,8 @@ def main():
         out["library_options"] = options   # not the defaults: an A/B run
     if gather is not None:
         out["gather"] = gather
+    if flows_to_root is not None:
+        out["flows_to_root"] = flows_to_root
     leg_limit = float(os.environ.get("TF_BENCH_LEG_TIMEOUT", 240))
     if not args.no_cpu_baseline and gate_times is not None:      # rank 0, at every N (the other ranks are done)
         try:

@@ -470,6 +470,14 @@ int tf_batch_broadcast(tf_batch *batch, void *dev, size_t bytes, int root);
    (all its inbound links at once), not a ring. */
 int tf_batch_gather(tf_batch *batch, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
                     int root);
+/* The gather with explicit places: rank r's send_bytes land on root at recv_dev + recv_offsets[r] (ranges inside
+   recv_capacity, not overlapping; a rank with nothing to send passes 0).  "Flows to root" (mode F): the
+   flows of a rank's pass land at the clip position of the pass's first pair, and the root's one compositor consumes
+   the clip's flows in order, as the reference's one compositor does (transflow/pipeline.py:565 hands every flow of
+   the clip to Compositor.update in turn; compositor/layers/movement.py:51-52 is the recurrence that makes the
+   order matter). */
+int tf_batch_gather_at(tf_batch *batch, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                       const size_t *recv_offsets, size_t recv_capacity, int root);
 /* The same gather beside the library stream's next work (transflow/pipeline.py:518 takes one frame at a time; a batch of
    finished frames need not hold up the next batch): _begin starts it, on a stream of the communicator's own, once the
    library stream has reached the point of the call; _end makes the library stream wait for it on the device.  One at

@@ -100,6 +100,63 @@ def test_gather_call_sequence_has_a_send_for_every_receive(world, clip_frames, b
         assert hi == lo                                     # frames of all ranks side by side, no gap, no overlap
 
 
+def replay_gather_at(calls):
+    """csrc/batch.hip's rules for ONE tf_batch_gather_at: as replay_gather, but rank r's bytes land at
+    recv_offsets[r]; the root refuses ranges that leave the buffer or overlap (TF_ERR_ARG)."""
+    root = calls[0]["root"]
+    rc = calls[root]
+    counts, offs = rc["recv_bytes"], rc["recv_offsets"]
+    assert len(counts) == len(offs) == len(calls) and counts[root] == rc["send_bytes"]
+    sends = {c["rank"]: c["send_bytes"] for c in calls if c["rank"] != root and c["send_bytes"] > 0}
+    ranges = []
+    for r, (n, at) in enumerate(zip(counts, offs)):
+        if n == 0:
+            continue
+        assert at + n <= rc["recv_capacity"], f"rank {r}'s bytes leave the receive buffer"
+        if r != root:
+            assert r in sends, f"the root waits for rank {r}, which sends nothing: deadlock"
+            assert sends.pop(r) == n
+        ranges.append((r, at, at + n))
+    assert not sends, f"ranks {sorted(sends)} send but the root posts no receive: deadlock"
+    srt = sorted(ranges, key=lambda t: t[1])
+    for (_, _, hi), (_, lo, _) in zip(srt, srt[1:]):
+        assert hi <= lo, "ranges overlap"
+    return ranges
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("clip_frames", [256, 257, 40, 9])
+@pytest.mark.parametrize("batch", [128, 32, 7])
+def test_flows_to_root_calls_place_every_pair_of_the_clip_once(world, clip_frames, batch):
+    """SURVEY 8e mode F: one tf_batch_gather_at per pass index; after the last one the root's buffer holds the flow of
+    every pair of the clip at its clip position (a rank's last pass may repeat pairs of the one before: same place,
+    same flow), every receive has its send, and a rank that has run out of passes sends nothing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from transflow_amd.batch import flows_to_root_calls
+    fb = 64                                                    # bytes per flow, small: positions are what is checked
+    plans = [bench.make_plan(clip_frames, batch, r, world) for r in range(world)]
+    if any(p["pairs_per_pass"] < 1 for p in plans):
+        pytest.skip("the clip does not reach every rank (bench.py refuses such a launch)")
+    calls = flows_to_root_calls(plans, fb)
+    assert len(calls) == max(len(p["pass_starts"]) for p in plans)
+    placed = {}
+    for k, call in enumerate(calls):
+        assert [c["rank"] for c in call] == list(range(world))
+        for r, lo, hi in replay_gather_at(call):
+            p = plans[r]
+            assert k < len(p["pass_starts"]) and hi - lo == p["pairs_per_pass"] * fb
+            first = p["pairs"][0] + p["pass_starts"][k]
+            assert lo == first * fb
+            for j in range(p["pairs_per_pass"]):
+                assert placed.setdefault(first + j, r) == r    # a pair only ever comes from the rank that owns it
+        for c in call:
+            p = plans[c["rank"]]
+            assert (c["send_bytes"] > 0) == (k < len(p["pass_starts"]))
+    assert sorted(placed) == list(range(clip_frames - 1))
+    assert calls[0][0]["recv_capacity"] == (clip_frames - 1) * fb
+
+
 def test_replay_catches_the_round2_deadlock():
     """The per-image form of round 2 (equal counts assumed): on the 32nd image rank 7 has nothing to send."""
     per_pass = pass_pairs(255, 32, 8)
@@ -188,7 +245,7 @@ def test_bench_launches_its_own_ranks_and_shards_the_clip(world):
     # would have spoken, and the workload's configuration as the measured line states it
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_gate", "rccl_ranks", "gather",
-                "per_rank_frames_per_s", "kernels_ms_per_step"):
+                "flows_to_root", "per_rank_frames_per_s", "kernels_ms_per_step"):
         assert key in d, key
     # passes capped at the ranks' shards: a step covers the whole clip at every N from 2 up (the total is fixed: strong)
     assert d["value"] is None and d["scaling"] == "strong" and d["config"]["clip_frames"] == 256

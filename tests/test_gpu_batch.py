@@ -43,6 +43,18 @@ def test_rccl_group_of_one_rank_through_the_c_abi():
     g.gather_end()                                                 # nothing pending: a no-op
     _lib.check(_lib.load().tf_sync())
     np.testing.assert_array_equal(out2.download(a.shape, np.uint8), a)
+    # the gather with a place of its own for the bytes (flows to root: a pass's flows at their clip position)
+    out3 = DevBuffer.from_array(np.zeros(a.nbytes + 4096, np.uint8))
+    g.gather_at(buf.ptr, a.nbytes, out3.ptr, [a.nbytes], [4096], a.nbytes + 4096)
+    _lib.check(_lib.load().tf_sync())
+    got = out3.download((a.nbytes + 4096,), np.uint8)
+    assert not got[:4096].any()
+    np.testing.assert_array_equal(got[4096:], a)
+    g.gather_at(0, 0, out3.ptr, [0], [0], a.nbytes + 4096)        # a rank that has run out of passes
+    with pytest.raises(ValueError):
+        g.gather_at(buf.ptr, a.nbytes, out3.ptr, [a.nbytes], [4097], a.nbytes + 4096)   # leaves the buffer
+    with pytest.raises(ValueError):
+        g.gather_at(buf.ptr, a.nbytes, out3.ptr, [a.nbytes - 1], [0], a.nbytes + 4096)  # root's own count
     assert g.reduce([1.5, -2.0], "max") == [1.5, -2.0]
     assert g.reduce([1.5, -2.0], "sum") == [1.5, -2.0]
     g.barrier()
@@ -70,6 +82,62 @@ def test_bench_runs_its_rccl_legs_with_one_rank():
     assert d["gather"]["frames_per_s_with_gather_beside_the_next_step"] > 0
     assert d["config"]["pairs_per_rank"] == [39] and d["config"]["frame_pairs_per_step_per_gpu"] == [7]
     assert d["value"] > 0
+    # flows to root (SURVEY 8e mode F): six passes of seven pairs (the last moved back to end with the clip) land at
+    # their clip positions; the root's one stream paints what rank 0 paints from the same flows
+    f = d["flows_to_root"]
+    assert f["clip_pairs"] == 39 and f["gathers"] == 6 and f["bytes_into_root"] == 0
+    assert f["verified_flow_crc"] is True and f["verified_stream"] is True and f["frames_per_s"] > 0
+
+
+def test_flows_to_root_paints_the_clip_as_one_compositor_would():
+    """SURVEY 8e mode F end to end on a communicator of one rank: the passes' flows gathered to their clip positions
+    (the last pass repeats a pair of the one before), ONE remap recurrence over the clip in order on the root; layer
+    state, rgba and every frame bit-exact against the oracle's moveref layer fed the same flows in the same order --
+    what the reference's one compositor paints for the clip (pipeline.py:565)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import remap_ref as OR
+    from transflow_amd.batch import HostGroup, RcclGroup, flows_to_root_calls
+    from transflow_amd.device import DevBuffer
+    from transflow_amd.remap import CompImage
+    wl = dict(bench.WORKLOADS["4k"], w=208, h=120)
+    w, h = wl["w"], wl["h"]
+    plan = bench.make_plan(12, 4, 0, 1)
+    assert plan["pass_starts"] == [0, 4, 7]
+    job = bench.Job(wl, 4, plan, 12, 77, 0, lanes=1)
+    host = HostGroup(0, 1)
+    g = RcclGroup(host)
+    flow_bytes = w * h * 8
+    calls = flows_to_root_calls([plan], flow_bytes)
+    clip = DevBuffer(11 * flow_bytes)
+    for k, call in enumerate(calls):
+        me = call[0]
+        job.calc_pass(k)
+        g.gather_at(job.fb.flow_ptr(0), me["send_bytes"], clip.ptr, me["recv_bytes"], me["recv_offsets"], me["recv_capacity"])
+    job.sync()
+    flows = clip.download((11, h, w, 2), np.float32)
+    for k, s0 in enumerate(plan["pass_starts"]):               # every pass sits at its clip position
+        job.calc_pass(k)
+        job.sync()
+        for i in range(4):
+            np.testing.assert_array_equal(job.fb.get_flow(i), flows[s0 + i])
+    layer = job.make_layer()
+    comp = CompImage(h, w, (255, 255, 255))
+    ora = OR.MoveRefLayer(h, w, OR.LayerParams(reset_mode="random", reset_random_factor=0.5), reset_mask=job.reset_mask,
+                          introduction_masks=[np.ones((h, w), bool)])
+    white = np.full((h, w, 3), 255, np.uint8)
+    ubuf = DevBuffer(h * w * 8)
+    for j in range(11):
+        layer.uniform_dev(bench.SEED_U, ubuf.ptr)
+        u = ubuf.download((h, w), np.float64)
+        layer.step_dev(comp, clip.ptr + j * flow_bytes, job.pixmap_dev, 3, clip_flow=True, seed=bench.SEED_U)
+        ora.update(OR.post_process(flows[j].copy(), wl["direction"]), [job.pixmap], u)
+        np.testing.assert_array_equal(comp.download(), OR.composite(white, [ora.render()]))
+    data, rgba = layer.get_state()
+    np.testing.assert_array_equal(data, ora.data)
+    np.testing.assert_array_equal(rgba, ora.rgba)
+    g.close()
+    host.close()
 
 
 def test_compositor_image_in_the_callers_buffer():
@@ -169,3 +237,6 @@ def test_bench_on_two_gpus_with_real_rccl_when_the_box_has_them():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "rccl_error" not in d and "side_leg_errors" not in d
     assert d["parity_gate"]["ok"]
     assert d["gather"]["verified_crc"] is True and d["gather"]["frames_per_rank"] == [20, 20]
+    f = d["flows_to_root"]
+    assert f["clip_pairs"] == 40 and f["gathers"] == 1 and f["bytes_into_root"] == 20 * 640 * 360 * 8
+    assert f["verified_flow_crc"] is True and f["verified_stream"] is True

@@ -155,6 +155,7 @@ PROTOTYPES = {
     "tf_batch_info": (_I, [_P, _PI, _PI, _PI]),
     "tf_batch_broadcast": (_I, [_P, _P, C.c_size_t, _I]),
     "tf_batch_gather": (_I, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), _I]),
+    "tf_batch_gather_at": (_I, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t, _I]),
     "tf_batch_gather_begin": (_I, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), _I]),
     "tf_batch_gather_end": (_I, [_P]),
     "tf_batch_reduce": (_I, [_P, C.POINTER(C.c_double), _I, _I]),

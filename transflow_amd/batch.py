@@ -99,6 +99,32 @@ def gather_calls(pairs_per_pass: list[int], frame_bytes: int, root: int = 0) -> 
              "recv_capacity": total if r == root else 0, "root": root} for r in range(len(counts))]
 
 
+def flows_to_root_calls(plans: list[dict], flow_bytes: int, root: int = 0) -> list[list[dict]]:
+    """"Flows to root" (mode F): the argument lists of the tf_batch_gather_at calls that bring the
+    whole clip's flows to one rank in clip order, so that ONE compositor consumes them as the reference's does
+    (transflow/pipeline.py:565; the remap is a recurrence over the clip, compositor/layers/movement.py:51-52, so
+    per-rank streams are not the reference's frames, the root's are).  One call per pass index k on every
+    rank: rank r sends the flows of its pass k (pairs_per_pass[r] of them; nothing when it has no pass k) and they
+    land at the clip position of that pass's first pair, plans[r]["pairs"][0] + plans[r]["pass_starts"][k].  A rank's
+    last pass may repeat a few pairs of the one before (batch_starts): the same flows land on the same place.
+    Every rank derives the same lists from the all-gathered plans.  -> calls[k][r]."""
+    total = max((p["pairs"][1] for p in plans), default=0) - min((p["pairs"][0] for p in plans), default=0)
+    first = min((p["pairs"][0] for p in plans), default=0)
+    n_pass = max((len(p["pass_starts"]) for p in plans), default=0)
+    calls = []
+    for k in range(n_pass):
+        counts, offsets = [], []
+        for p in plans:
+            has = k < len(p["pass_starts"])
+            counts.append(int(p["pairs_per_pass"]) * int(flow_bytes) if has else 0)
+            offsets.append((p["pairs"][0] - first + p["pass_starts"][k]) * int(flow_bytes) if has else 0)
+        calls.append([{"rank": r, "send_bytes": counts[r], "recv_bytes": counts if r == root else None,
+                       "recv_offsets": offsets if r == root else None,
+                       "recv_capacity": total * int(flow_bytes) if r == root else 0, "root": root}
+                      for r in range(len(plans))])
+    return calls
+
+
 # ---- rendezvous ------------------------------------------------------------------------------------
 def _private_dir() -> str:
     """A directory only this user can enter (0700, owned by us, not a symlink): the rendezvous file of a launch
@@ -357,6 +383,17 @@ class RcclGroup:
             counts = (C.c_size_t * self.world)(*[int(v) for v in recv_bytes])
         self._check(self._lib.tf_batch_gather(self._h, C.c_void_p(send_ptr) if send_ptr else None, int(send_bytes),
                                               C.c_void_p(recv_ptr) if recv_ptr else None, counts, int(root)))
+
+    def gather_at(self, send_ptr: int, send_bytes: int, recv_ptr: int | None = None, recv_bytes=None, recv_offsets=None,
+                  recv_capacity: int = 0, root: int = 0) -> None:
+        """tf_batch_gather_at: rank r's bytes land on root at recv_ptr + recv_offsets[r] (flows_to_root_calls)."""
+        counts = offs = None
+        if recv_bytes is not None:
+            counts = (C.c_size_t * self.world)(*[int(v) for v in recv_bytes])
+            offs = (C.c_size_t * self.world)(*[int(v) for v in recv_offsets])
+        self._check(self._lib.tf_batch_gather_at(self._h, C.c_void_p(send_ptr) if send_ptr else None, int(send_bytes),
+                                                 C.c_void_p(recv_ptr) if recv_ptr else None, counts, offs,
+                                                 int(recv_capacity), int(root)))
 
     def gather_begin(self, send_ptr: int, send_bytes: int, recv_ptr: int | None = None, recv_bytes=None, root: int = 0) -> None:
         """gather_dev beside what the library stream does next (tf_batch_gather_begin); gather_end() before the send

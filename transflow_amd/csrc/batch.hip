@@ -190,8 +190,9 @@ TF_API int tf_batch_broadcast(tf_batch *b, void *dev, size_t bytes, int root)
 
 // Rank r's `send_bytes` land at recv_dev + sum(recv_bytes[0..r)) on root.  A gather to one root uses
 // all of the root's inbound xGMI links at once (point-to-point sends, not a ring: SURVEY.md §8e).
+// `recv_offsets` (root only, may be null): where each rank's bytes land instead of the prefix sums.
 static int gather_on(tf_batch *b, hipStream_t s, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
-                     int root)
+                     int root, const size_t *recv_offsets = nullptr)
 {
     if (b->rank == root) {
         TF_REQUIRE(recv_dev, "tf_batch_gather: root needs a receive buffer");
@@ -208,7 +209,7 @@ static int gather_on(tf_batch *b, hipStream_t s, const void *send_dev, size_t se
     TF_RCCL(g_rccl.GroupStart());
     for (int r = 0; r < b->world; r++) {
         const size_t n = recv_bytes ? recv_bytes[r] : send_bytes;
-        char *dst = (char *)recv_dev + off;
+        char *dst = (char *)recv_dev + (recv_offsets ? recv_offsets[r] : off);
         off += n;
         if (n == 0)
             continue;
@@ -241,6 +242,33 @@ TF_API int tf_batch_gather(tf_batch *b, const void *send_dev, size_t send_bytes,
     TF_TRY(ensure_init());
     ProfScope ps("batch_gather");
     return gather_on(b, main_stream(), send_dev, send_bytes, recv_dev, recv_bytes, root);
+}
+
+// The gather with a place of its own for every rank's bytes: rank r's send_bytes land at recv_dev + recv_offsets[r].
+// What "flows to root" needs (SURVEY.md §8e mode F): the flows of a rank's pass k belong at the clip position of that
+// pass's first pair, so that the root's ONE compositor consumes the clip's flows in order, as transflow/pipeline.py:565
+// hands them to the reference's one compositor.  The ranges must not overlap (checked on root).
+TF_API int tf_batch_gather_at(tf_batch *b, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *recv_bytes,
+                              const size_t *recv_offsets, size_t recv_capacity, int root)
+{
+    TF_REQUIRE(b, "tf_batch_gather_at: null handle");
+    TF_REQUIRE(root >= 0 && root < b->world, "tf_batch_gather_at: root %d of %d", root, b->world);
+    TF_REQUIRE(send_dev || send_bytes == 0, "tf_batch_gather_at: null send buffer");
+    if (b->rank == root) {
+        TF_REQUIRE(recv_bytes && recv_offsets, "tf_batch_gather_at: root needs every rank's count and offset");
+        for (int r = 0; r < b->world; r++) {
+            TF_REQUIRE(recv_bytes[r] <= recv_capacity && recv_offsets[r] <= recv_capacity - recv_bytes[r],
+                       "tf_batch_gather_at: rank %d's %zu bytes at %zu leave the %zu-byte buffer", r, recv_bytes[r],
+                       recv_offsets[r], recv_capacity);
+            for (int q = 0; q < r; q++)
+                TF_REQUIRE(recv_bytes[r] == 0 || recv_bytes[q] == 0 || recv_offsets[r] >= recv_offsets[q] + recv_bytes[q] ||
+                               recv_offsets[q] >= recv_offsets[r] + recv_bytes[r],
+                           "tf_batch_gather_at: the ranges of ranks %d and %d overlap", q, r);
+        }
+    }
+    TF_TRY(ensure_init());
+    ProfScope ps("batch_gather");
+    return gather_on(b, main_stream(), send_dev, send_bytes, recv_dev, recv_bytes, root, recv_offsets);
 }
 
 // The same gather BESIDE what the library stream does next: it starts when the library stream reaches the point of this
