@@ -331,7 +331,7 @@ static int fb_create(tf_fb **out, int width, int height, const tf_fb_params *par
         if (nsplit) {
             fb->rp_rmax = rmax;
             fb->rp_r4 = (rmax + 3) & ~3;
-            int pitch = (fb->rp_r4 + width + rmax + 8 + 3) & ~3;
+            int pitch = (fb->rp_r4 + width + rmax + 16 + 3) & ~3; // (the unrolled row pass reads whole aligned dwords up to 10 bytes past a window)
             while (((pitch / 4) % 8) != 1)
                 pitch += 4;
             fb->rp_pitch = pitch;

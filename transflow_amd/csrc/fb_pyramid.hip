@@ -351,6 +351,87 @@ struct RowPassArgs {
     RowPassLevel lv[RP_MAX_LEVELS];
 };
 
+// One level's row pass for a kernel length known at compile time (round 5).  The general loop below spends two thirds
+// of its instructions outside the taps -- an item's set-up (four table loads, two divisions), the peeled first four
+// taps, the up-to-three left over, the register moves that slide the window -- and at ksz = 9 an item is one trip
+// through the loop.  Here the taps are unrolled (the window's bytes are converted once each, straight from the
+// aligned dwords; no moves, no remainder), the set-up is done once per column group and reused for every row block of
+// the workgroup, and the item order needs no division.  Same lanes (R rows x 64/R groups), same LDS reads, the same
+// statements per output: acc = t0 * w0, then acc += t_i * w_i left to right.
+template <int KSZ, int RSHIFT>
+__device__ __forceinline__ void rowpass_level_t(const RowPassLevel &L, const uint8_t *sS, const float *sK, int nrows, int pitch,
+                                                int r4, size_t out_row0, int lane, int wave)
+{
+    constexpr int R = 1 << RSHIFT, G = 64 >> RSHIFT, r = KSZ >> 1;
+    constexpr int NB = KSZ + 1;        // bytes of a window: outputs at columns c and c + 1
+    constexpr int NW = (NB + 3) / 4;   // aligned words of it
+    const int NC = L.NC;
+    const int li = lane & (R - 1), lg = lane >> RSHIFT;
+    const int ngroups = (NC + 3) >> 2;
+    const int n_gb = (ngroups + G - 1) / G, n_rb = (nrows + R - 1) >> RSHIFT;
+    for (int gb = wave; gb < n_gb; gb += 4) {
+        const int grp = gb * G + lg;
+        if (grp >= ngroups)
+            continue;
+        const int oA = 4 * grp, oB = min(4 * grp + 2, NC - 2);
+        const int cA = L.colsrc[oA], cB = L.colsrc[oB];
+        const bool dupA = L.colsrc[oA + 1] == cA, dupB = L.colsrc[oB + 1] == cB; // pair at the right frame border: sx+1 clamps to sx
+        const int a0 = r4 + cA - r, b0 = r4 + cB - r;
+        const int da = a0 >> 2, db = b0 >> 2;
+        const unsigned sa = a0 & 3, sb = b0 & 3;
+        const bool four = 4 * grp + 2 < NC;
+        for (int rb = 0; rb < n_rb; rb++) {
+            const int row = rb * R + li;
+            if (row >= nrows)
+                continue;
+            const uint32_t *q32 = reinterpret_cast<const uint32_t *>(sS + row * pitch);
+            uint32_t rA[NW + 1], rB[NW + 1];
+#pragma unroll
+            for (int j = 0; j <= NW; j++) {
+                rA[j] = q32[da + j];
+                rB[j] = q32[db + j];
+            }
+            f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}; // {A, B} and {A+1, B+1}
+#pragma unroll
+            for (int wv = 0; wv < NW; wv++) {
+                const uint32_t wA = __builtin_amdgcn_alignbyte(rA[wv + 1], rA[wv], sa);
+                const uint32_t wB = __builtin_amdgcn_alignbyte(rB[wv + 1], rB[wv], sb);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int i = 4 * wv + b; // byte i of the window: tap i of the left output, tap i - 1 of the right one
+                    if (i < NB) {
+                        const f32x2 p = {(float)((wA >> (8 * b)) & 0xff), (float)((wB >> (8 * b)) & 0xff)};
+                        if (i < KSZ) {
+                            if (i == 0)
+                                acc0 = sK[0] * p;
+                            else
+                                acc0 += sK[i] * p;
+                        }
+                        if (i >= 1) {
+                            if (i == 1)
+                                acc1 = sK[0] * p;
+                            else
+                                acc1 += sK[i - 1] * p;
+                        }
+                    }
+                }
+            }
+            // a clamped pair reads the same column twice: the same sum
+            if (dupA)
+                acc1.x = acc0.x;
+            if (dupB)
+                acc1.y = acc0.y;
+            float *out = L.rowf + (out_row0 + row) * NC + 4 * grp;
+            out[0] = acc0.x;
+            out[1] = acc1.x;
+            if (four) {
+                out[2] = acc0.y;
+                out[3] = acc1.y;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, int W, int H, RowPassArgs args, int RB,
                 int pitch, int r4, int rmax)
@@ -372,10 +453,24 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
     }
     // stage nrows frame rows: the interior as dwords (W % 4 == 0 is required by the host), rmax reflected bytes each side
     const int nq = W >> 2;
-    for (int idx = threadIdx.x; idx < nrows * nq; idx += 256) {
-        const int i = idx / nq, c = idx - i * nq;
-        *reinterpret_cast<uint32_t *>(sS + i * pitch + r4 + 4 * c) =
-            *reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + i) * W + 4 * c);
+    {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        constexpr int U = 4;
+        for (int i = wave_; i < nrows; i += 4) { // a wave copies whole rows: 256 contiguous bytes per instruction, U in flight
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + i) * W);
+            uint32_t *d = reinterpret_cast<uint32_t *>(sS + i * pitch + r4);
+            for (int c0 = lane_; c0 < nq; c0 += 64 * U) {
+                uint32_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (c0 + 64 * u < nq)
+                        v[u] = g[c0 + 64 * u];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (c0 + 64 * u < nq)
+                        d[c0 + 64 * u] = v[u];
+            }
+        }
     }
     for (int idx = threadIdx.x; idx < nrows * 2 * rmax; idx += 256) {
         const int i = idx / (2 * rmax), j = idx - i * 2 * rmax;
@@ -389,6 +484,24 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
         const RowPassLevel &L = args.lv[l];
         const float *sK = sKall + kbase;
         kbase += L.ksz;
+        const size_t out_row0 = (size_t)pi * H + y0;
+        // the kernel lengths of a pyr_scale = 0.5 pyramid (scales 1/4 .. 1/32) with their lane mappings
+        if (L.ksz == 9 && L.rshift == 1) {
+            rowpass_level_t<9, 1>(L, sS, sK, nrows, pitch, r4, out_row0, lane, wave);
+            continue;
+        }
+        if (L.ksz == 19 && L.rshift == 2) {
+            rowpass_level_t<19, 2>(L, sS, sK, nrows, pitch, r4, out_row0, lane, wave);
+            continue;
+        }
+        if (L.ksz == 39 && L.rshift == 3) {
+            rowpass_level_t<39, 3>(L, sS, sK, nrows, pitch, r4, out_row0, lane, wave);
+            continue;
+        }
+        if (L.ksz == 79 && L.rshift == 3) {
+            rowpass_level_t<79, 3>(L, sS, sK, nrows, pitch, r4, out_row0, lane, wave);
+            continue;
+        }
         const int ksz = L.ksz, r = ksz >> 1, NC = L.NC, rshift = L.rshift;
         const int R = 1 << rshift, G = 64 >> rshift;
         const int li = lane & (R - 1), lg = lane >> rshift;
