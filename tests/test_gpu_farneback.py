@@ -25,7 +25,10 @@ def FB():
     return Farneback
 
 
-@pytest.mark.parametrize("shape,levels", [((270, 480), 3), ((135, 241), 2), ((480, 854), 3), ((1080, 1920), 5)])
+@pytest.mark.parametrize("shape,levels", [((270, 480), 3), ((135, 241), 2), ((480, 854), 3), ((1080, 1920), 5),
+                                          # frames that are exactly 4 x their scale-1/4 level (k_level_quarter_image): one tile
+                                          # that is all border, partial tiles, interior tiles between border ones
+                                          ((128, 256), 2), ((132, 260), 2), ((520, 1028), 2)])
 def test_level_images_bit_exact(FB, shape, levels):
     h, w = shape
     a, _ = synth_pair(h, w, seed=11)

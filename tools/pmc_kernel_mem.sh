@@ -10,9 +10,11 @@ P4="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"
 P5="TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_sum"
 P6="FETCH_SIZE"
 P7="WRITE_SIZE"
-for p in P1 P2 P3 P4 P5 P6 P7; do
+P8="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
+P9="SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_WAIT_INST_ANY"
+for p in P1 P2 P3 P4 P5 P6 P7 P8 P9; do
   echo "pass $p: ${!p}"
   timeout -k 10 150 tools/pmc_pass.sh ${out}_$p 4k $batch ${!p} || echo "pass $p failed or timed out"
 done
-for p in P1 P2 P3 P4 P5 P6 P7; do python3 tools/pmc_top.py gpurun_out/pmc_${out}_$p $k || true; done > gpurun_out/${out}.txt
+for p in P1 P2 P3 P4 P5 P6 P7 P8 P9; do python3 tools/pmc_top.py gpurun_out/pmc_${out}_$p $k || true; done > gpurun_out/${out}.txt
 cat gpurun_out/${out}.txt

@@ -266,7 +266,8 @@ static int fb_create(tf_fb **out, int width, int height, const tf_fb_params *par
         L->tile = choose_tile(width, height, L->W, L->H, L->ksz, k);
         {
             std::vector<int> colsrc;
-            L->split = plan_split_level(width, height, *L, colsrc);
+            L->quarter = plan_quarter_level(width, height, *L);
+            L->split = !L->quarter && plan_split_level(width, height, *L, colsrc);
             if (L->split) {
                 if ((rc = L->colsrc.alloc(colsrc.size() * 4)))
                     return fail(rc);

@@ -122,6 +122,21 @@ __device__ __forceinline__ void xcd_tile(unsigned &bx, unsigned &by)
     by = t / gridDim.x;
 }
 
+// The same over a whole 3-D grid (x fastest, then y, then z = image): the hardware deals workgroups to the XCDs by their
+// place in the whole launch, so with gridDim.x * gridDim.y not a multiple of 8 the per-slice form above groups the
+// wrong blocks from the second image on.  Each XCD walks a contiguous eighth of the launch in (z, y, x) order.
+__device__ __forceinline__ void xcd_tile3(unsigned &bx, unsigned &by, unsigned &bz)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, nt = gx * gy * gridDim.z;
+    const unsigned lin = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const unsigned xcd = lin & 7, qn = nt >> 3, rn = nt & 7;
+    const unsigned t = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3);
+    bz = t / (gx * gy);
+    const unsigned rem = t - bz * gx * gy;
+    by = rem / gx;
+    bx = rem - by * gx;
+}
+
 // The same for the one-kernel iteration's grid of (strip, segment, pair): XCD x takes a contiguous run of the PAIRS (pairs
 // [x P / 8, (x + 1) P / 8)) and, of those, all strips and segments -- the strips of a pair share their halo columns in one
 // L2, and consecutive pairs the frame they both read (R0 of one is R1 of the next).  Bijective for any grid.
@@ -265,6 +280,7 @@ struct Level {
     DevBuf img, R;     // this level's image / polynomial coefficients (levels >= 1; level 0 uses the handle's)
     LerpDev img_lerp;  // frame -> this level (unused when sizes are equal)
     // long blur kernels: row pass over whole frame rows, then column pass + lerps (k_level_rowpass / _colpass)
+    bool quarter = false;   // exactly the frame / 4 with the 9-tap blur: one kernel, no plane (k_level_quarter_image)
     bool split = false;
     DevBuf colsrc;          // source column of each of the NC = 2*W row-pass columns
     int NC = 0, rp_rshift = 0;
@@ -385,6 +401,7 @@ const char *lvl_name(const char *base, int k);
 // ---- fb_pyramid.hip ----
 int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone = false);
 bool plan_split_level(int W, int H, Level &L, std::vector<int> &colsrc);
+bool plan_quarter_level(int W, int H, const Level &L);
 ImgTile choose_tile(int W, int H, int Wk, int Hk, int ksz, int level);
 int fb_polyexp(tf_fb *fb, int w, int h, int n_images, int k = -1);
 bool fb_can_fuse_level(tf_fb *fb, int k);

@@ -358,6 +358,9 @@ struct RowPassArgs {
 // aligned dwords; no moves, no remainder), the set-up is done once per column group and reused for every row block of
 // the workgroup, and the item order needs no division.  Same lanes (R rows x 64/R groups), same LDS reads, the same
 // statements per output: acc = t0 * w0, then acc += t_i * w_i left to right.
+// threads of a row-pass workgroup (512 with registers capped at 64 for eight waves per SIMD: 1.80 -> 3.13 ms, spills and idle waves)
+constexpr int RP_THREADS = 256, RP_WAVES = RP_THREADS / 64;
+
 template <int KSZ, int RSHIFT>
 __device__ __forceinline__ void rowpass_level_t(const RowPassLevel &L, const uint8_t *sS, const float *sK, int nrows, int pitch,
                                                 int r4, size_t out_row0, int lane, int wave)
@@ -369,7 +372,7 @@ __device__ __forceinline__ void rowpass_level_t(const RowPassLevel &L, const uin
     const int li = lane & (R - 1), lg = lane >> RSHIFT;
     const int ngroups = (NC + 3) >> 2;
     const int n_gb = (ngroups + G - 1) / G, n_rb = (nrows + R - 1) >> RSHIFT;
-    for (int gb = wave; gb < n_gb; gb += 4) {
+    for (int gb = wave; gb < n_gb; gb += RP_WAVES) {
         const int grp = gb * G + lg;
         if (grp >= ngroups)
             continue;
@@ -422,7 +425,7 @@ __device__ __forceinline__ void rowpass_level_t(const RowPassLevel &L, const uin
             if (dupB)
                 acc1.y = acc0.y;
             float *out = L.rowf + (out_row0 + row) * NC + 4 * grp;
-            out[0] = acc0.x;
+            out[0] = acc0.x; // (one 16-byte store per lane instead of four: 1.80 -> 1.89 ms)
             out[1] = acc1.x;
             if (four) {
                 out[2] = acc0.y;
@@ -432,7 +435,7 @@ __device__ __forceinline__ void rowpass_level_t(const RowPassLevel &L, const uin
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(RP_THREADS)
 k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, int W, int H, RowPassArgs args, int RB,
                 int pitch, int r4, int rmax)
 {
@@ -446,7 +449,7 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
     {
         int base = 0;
         for (int l = 0; l < args.n; l++) {
-            for (int i = threadIdx.x; i < args.lv[l].ksz; i += 256)
+            for (int i = threadIdx.x; i < args.lv[l].ksz; i += RP_THREADS)
                 sKall[base + i] = args.lv[l].kern[i];
             base += args.lv[l].ksz;
         }
@@ -456,7 +459,7 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
     {
         const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
         constexpr int U = 4;
-        for (int i = wave_; i < nrows; i += 4) { // a wave copies whole rows: 256 contiguous bytes per instruction, U in flight
+        for (int i = wave_; i < nrows; i += RP_WAVES) { // a wave copies whole rows: 256 contiguous bytes per instruction, U in flight
             const uint32_t *g = reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + i) * W);
             uint32_t *d = reinterpret_cast<uint32_t *>(sS + i * pitch + r4);
             for (int c0 = lane_; c0 < nq; c0 += 64 * U) {
@@ -472,7 +475,7 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
             }
         }
     }
-    for (int idx = threadIdx.x; idx < nrows * 2 * rmax; idx += 256) {
+    for (int idx = threadIdx.x; idx < nrows * 2 * rmax; idx += RP_THREADS) {
         const int i = idx / (2 * rmax), j = idx - i * 2 * rmax;
         const int c = j < rmax ? j - rmax : W + (j - rmax); // -rmax..-1, W..W+rmax-1
         sS[i * pitch + r4 + c] = src[(size_t)(y0 + i) * W + reflect101(c, W)];
@@ -507,7 +510,7 @@ k_level_rowpass(const uint8_t *__restrict__ frames, const int2 *__restrict__ pai
         const int li = lane & (R - 1), lg = lane >> rshift;
         const int ngroups = (NC + 3) >> 2;
         const int n_rb = (nrows + R - 1) >> rshift, n_gb = (ngroups + G - 1) / G;
-        for (int item = wave; item < n_rb * n_gb; item += 4) {
+        for (int item = wave; item < n_rb * n_gb; item += RP_WAVES) {
             const int gb = item % n_gb, rb = item / n_gb;
             const int row = rb * R + li, grp = gb * G + lg;
             if (row >= nrows || grp >= ngroups)
@@ -667,6 +670,130 @@ k_level_colpass(const float *__restrict__ rowf, float *__restrict__ img, int W, 
         h1 = v1.x * (1.f - fx) + v1.y * fx;
     }
     img[(size_t)pi * Wk * Hk + (size_t)dy * Wk + dx] = h0 * (1.f - fy) + h1 * fy;
+}
+
+// ---------------------------------------------------------------------------------
+// A1 for a level that is exactly a QUARTER of the frame in both directions, whose blur has 9 taps (scale 1/4 of a
+// pyr_scale = 0.5 pyramid: sigma 1.5), in one kernel and without the row-pass plane (round 5).  As two kernels this level
+// alone writes and reads 2 x 16.6 MB of plane per 4K frame -- 4.3 GB per pass of 129 frames, moved at 1.8 - 2.5 TB/s:
+// 0.73 ms of the row pass and the 0.97 ms of its column pass are that traffic.  resize.cpp's coordinates are
+// (4X + 1.5, 4Y + 1.5): a level pixel is the lerp (both fractions exactly 0.5; the host checks its tables) of the blurred
+// frame at columns 4X + 1, 4X + 2 and rows 4Y + 1, 4Y + 2, so it needs the row pass at those two columns on frame rows
+// 4Y - 3 .. 4Y + 6, and the pixel below it needs six of the same ten rows.  A lane owns a level column and walks down
+// eight level rows with the row-pass values of ten frame rows in registers: four new frame rows per level row (two at
+// a time, packed), then the column pass (centre, then pairs outwards) and both lerps -- k_level_image's statements in
+// k_level_image's order.  Tile 64 x 32 level pixels = 264 x 134 staged bytes; a wave per eight level rows.
+// ---------------------------------------------------------------------------------
+constexpr int QI_TW = 64, QI_TH = 16;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_level_quarter_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W, int H,
+                      const float *__restrict__ kern, const float *__restrict__ xfrac, const float *__restrict__ yfrac)
+{
+    constexpr int S = 4, K = 9, r = 4, SEG = QI_TH / 4;
+    constexpr int NR = S * (QI_TH - 1) + 2 + 2 * r; // 134 frame rows behind 32 level rows
+    constexpr int PD = QI_TW + 2;                   // dwords per staged row: lane l reads dwords l .. l + 2
+    __shared__ uint32_t sS[NR * PD];
+    const int Wk = W >> 2, Hk = H >> 2;
+    // neighbouring tiles share six frame rows and the cache lines at their sides: one after the other on the same XCD
+    unsigned tbx, tby, tbz;
+    xcd_tile3(tbx, tby, tbz);
+    const int pi = tbz;
+    const int2 pr = pairs[pi >> 1];
+    const uint8_t *src = frames + (size_t)((pi & 1) ? pr.y : pr.x) * W * H;
+    const int X0 = tbx * QI_TW, Y0 = tby * QI_TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // staged row j = frame row 4 Y0 - 3 + j; staged byte b = frame column 4 X0 - 4 + b (REFLECT_101 outside the frame):
+    // level column X0 + l reads bytes 4 l + 1 .. 4 l + 10
+    const int xs = S * X0 - 4, ys = S * Y0 - 3;
+    const bool dwords = xs >= 0 && xs + 4 * PD <= W && ys >= 0 && ys + NR <= H;
+    if (dwords) {
+        constexpr int U = (NR + 3) / 4; // all of a wave's rows in flight at once: one round trip to memory per tile
+        for (int j0 = wave; j0 < NR; j0 += 4 * U) {
+            uint32_t v[U], v2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = min(j0 + 4 * u, NR - 1);
+                const uint32_t *g = reinterpret_cast<const uint32_t *>(src + (size_t)(ys + j) * W + xs);
+                v[u] = g[lane];
+                v2[u] = g[64 + (lane & 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + 4 * u;
+                if (j < NR) {
+                    sS[j * PD + lane] = v[u];
+                    if (lane < 2)
+                        sS[j * PD + 64 + lane] = v2[u];
+                }
+            }
+        }
+    } else {
+        uint8_t *s8 = reinterpret_cast<uint8_t *>(sS);
+        for (int j = wave; j < NR; j += 4) {
+            const uint8_t *g = src + (size_t)reflect101(ys + j, H) * W;
+            for (int b = lane; b < 4 * PD; b += 64)
+                s8[j * 4 * PD + b] = g[reflect101(xs + b, W)];
+        }
+    }
+    __syncthreads();
+    const int X = X0 + lane, Yw = Y0 + SEG * wave;
+    if (X >= Wk || Yw >= Hk)
+        return;
+    float t[K];
+#pragma unroll
+    for (int i = 0; i < K; i++)
+        t[i] = kern[i];
+    const float fx = xfrac[X];
+    const uint32_t *q = sS + (S * SEG * wave) * PD + lane; // the wave's first staged row
+    constexpr int NROWS = S * (SEG - 1) + 2 + 2 * r;       // 38 frame rows behind a wave's eight level rows
+    float c0[NROWS], c1[NROWS];                            // row pass at columns 4X + 1 and 4X + 2
+    // the row pass of staged rows j and j + 1 (of the wave), the two rows in the halves of packed operations
+    auto row_pair = [&](int j) {
+        const uint32_t *qa = q + j * PD, *qb = qa + PD;
+        const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+        const uint32_t wa[3] = {__builtin_amdgcn_alignbyte(a1, a0, 1), __builtin_amdgcn_alignbyte(a2, a1, 1), a2 >> 8};
+        const uint32_t wb[3] = {__builtin_amdgcn_alignbyte(b1, b0, 1), __builtin_amdgcn_alignbyte(b2, b1, 1), b2 >> 8};
+        f32x2 p[K + 1];
+#pragma unroll
+        for (int i = 0; i <= K; i++)
+            p[i] = f32x2{(float)((wa[i >> 2] >> (8 * (i & 3))) & 0xff), (float)((wb[i >> 2] >> (8 * (i & 3))) & 0xff)};
+        f32x2 A0 = t[0] * p[0], A1 = t[0] * p[1];
+#pragma unroll
+        for (int i = 1; i < K; i++) {
+            A0 += t[i] * p[i];
+            A1 += t[i] * p[i + 1];
+        }
+        c0[j] = A0.x;
+        c0[j + 1] = A0.y;
+        c1[j] = A1.x;
+        c1[j + 1] = A1.y;
+    };
+#pragma unroll
+    for (int j = 0; j < 6; j += 2)
+        row_pair(j);
+    float *dst = img + (size_t)pi * Wk * Hk + X;
+#pragma unroll
+    for (int y = 0; y < SEG; y++) {
+        if (Yw + y >= Hk)
+            break;
+        row_pair(S * y + 6);
+        row_pair(S * y + 8);
+        // rows 4y .. 4y + 9 of the wave are frame rows 4Y - 3 .. 4Y + 6: the pixel's source rows are 4y + 4 and 4y + 5
+        const int m = S * y + r;
+        float v00 = t[r] * c0[m], v01 = t[r] * c1[m], v10 = t[r] * c0[m + 1], v11 = t[r] * c1[m + 1];
+#pragma unroll
+        for (int i = 1; i <= r; i++) {
+            const float k = t[r + i];
+            v00 += k * (c0[m + i] + c0[m - i]);
+            v01 += k * (c1[m + i] + c1[m - i]);
+            v10 += k * (c0[m + 1 + i] + c0[m + 1 - i]);
+            v11 += k * (c1[m + 1 + i] + c1[m + 1 - i]);
+        }
+        const float fy = yfrac[Yw + y];
+        const float h0 = v00 * (1.f - fx) + v01 * fx, h1 = v10 * (1.f - fx) + v11 * fx;
+        dst[(size_t)(Yw + y) * Wk] = h0 * (1.f - fy) + h1 * fy;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1169,6 +1296,11 @@ namespace fb {
 int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone)
 {
     Level &L = *fb->lv[k];
+    if (L.quarter)
+        return launch(lvl_name("fb_level_image", k), k_level_quarter_image, dim3(cdiv(L.W, QI_TW), cdiv(L.H, QI_TH), n_images),
+                      dim3(256), 0, (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->imgk(k), fb->W, fb->H,
+                      (const float *)L.kern.as<float>(), (const float *)L.img_lerp.xfrac.as<float>(),
+                      (const float *)L.img_lerp.yfrac.as<float>());
     if (L.split) {
         if (k == fb->rp_first || standalone) { // the coarsest split level comes first in the preparation: row pass of all of them now
             RowPassArgs a;
@@ -1189,7 +1321,7 @@ int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone)
             }
             const size_t smem_rp = (size_t)fb->rp_RB * fb->rp_pitch + taps * sizeof(float);
             TF_TRY(launch(lvl_name("fb_level_rowpass", -1), k_level_rowpass, dim3(cdiv(fb->H, fb->rp_RB), n_images),
-                          dim3(256), smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(),
+                          dim3(RP_THREADS), smem_rp, (const uint8_t *)fb->frames.as<uint8_t>(),
                           fb->image_list(), fb->W, fb->H, a, fb->rp_RB, fb->rp_pitch, fb->rp_r4,
                           fb->rp_rmax));
         }
@@ -1205,6 +1337,26 @@ int fb_level_image(tf_fb *fb, int k, int n_images, bool standalone)
     return launch(lvl_name("fb_level_image", k), k_level_image, grid, dim3(256), smem,
                   (const uint8_t *)fb->frames.as<uint8_t>(), fb->image_list(), fb->imgk(k),
                   fb->W, fb->H, L.W, L.H, (const float *)L.kern.as<float>(), L.ksz, t);
+}
+
+// Does k_level_quarter_image apply?  The level is the frame / 4 in both directions with the 9-tap blur, and resize.cpp's
+// tables say what the kernel assumes: source column 4X + 1 (row 4Y + 1), fraction 0.5, nothing clamped.
+bool plan_quarter_level(int W, int H, const Level &L)
+{
+    static const bool off = tune("TF_IMG_NO_QUARTER", 0) != 0;
+    if (off || L.ksz != 9 || 4 * L.W != W || 4 * L.H != H)
+        return false;
+    std::vector<int> o;
+    std::vector<float> f;
+    make_lerp(W, L.W, true, o, f);
+    for (int x = 0; x < L.W; x++)
+        if (o[x] != 4 * x + 1 || f[x] != 0.5f)
+            return false;
+    make_lerp(H, L.H, false, o, f);
+    for (int y = 0; y < L.H; y++)
+        if (o[y] != 4 * y + 1 || f[y] != 0.5f)
+            return false;
+    return true;
 }
 
 // Plans the two-kernel form of A1 for a level with a long blur kernel (returns false where it does not
