@@ -199,11 +199,21 @@ class Job:
         if self.flow_ptrs is None or self.flow_ptrs[0] != base:
             self.flow_ptrs = [base + i * self.wl["w"] * self.wl["h"] * 8 for i in range(self.batch)]
 
+    def remap_pass(self, layer):
+        """the remap recurrence over the pass's flows, in order.  BACKWARD: the steps of the pass as ONE call
+        (tf_remap_steps_dev: the same state and frames as the single calls, which the parity gate and the GPU tests
+        compare it with; the library then knows which of a step's stores the next step overwrites unread).  FORWARD:
+        a pair's winner map is made beside its flow just before its step (one map per handle), so step by step."""
+        if self.wl["direction"] == 0:
+            for i in range(self.batch):
+                self.remap_pair(layer, self.comps[i], i)
+        else:
+            layer.steps_dev(self.comps, self.flow_ptrs, self.pixmap_dev, 3, clip_flow=True, seed=SEED_U)
+
     def step(self):
         self.calc_pass(self.n_steps)
         self.n_steps += 1
-        for i in range(self.batch):
-            self.remap_pair(self.layer, self.comps[i], i)
+        self.remap_pass(self.layer)
 
     def sync(self):
         self.check(self.lib.tf_sync())
@@ -331,6 +341,23 @@ def parity_gate(job, n_check=2):
             rep["exact_bit_identical"] = rep["exact_bit_identical"] and bool(np.array_equal(got, refs[i]))
     finally:
         job.fb.set_exact(None)
+    # the pass's remap steps as ONE call (what the timed loop does on a BACKWARD workload) against the same steps one by one:
+    # layer state, rgba and every frame must be the same bytes
+    if wl["direction"] != 0 and job.batch >= 2:
+        m = min(job.batch, 3)
+        job.calc_pass(0)
+        one, many = job.make_layer(), job.make_layer()
+        singles = []
+        for i in range(m):
+            job.remap_pair(one, comp, i)
+            singles.append(comp.download())
+        many.steps_dev(job.comps[:m], job.flow_ptrs[:m], job.pixmap_dev, 3, clip_flow=True, seed=SEED_U)
+        same = all(np.array_equal(singles[i], job.comps[i].download()) for i in range(m))
+        (d1, r1), (d2, r2) = one.get_state(), many.get_state()
+        rep["remap_steps_call_equals_single_steps"] = bool(same and np.array_equal(d1, d2) and np.array_equal(r1, r2))
+        rep["remap_bit_exact"] = bool(rep["remap_bit_exact"] and rep["remap_steps_call_equals_single_steps"])
+        one.close()
+        many.close()
     rep["flow_pixels_over_tol"] = rep["outliers_default"]
     rep["flow_ok"] = bool(rep["flow_ok"] and rep["exact_bit_identical"] and rep["lanes_bit_identical"])
     rep["out_of_frame"] = bool(layer.out_of_frame())
@@ -537,8 +564,7 @@ def gather_leg(job, host, rccl, plans, reps=3):
         job.calc_pass(job.n_steps)
         job.n_steps += 1
         rccl.gather_end()
-        for i in range(job.batch):
-            job.remap_pair(job.layer, job.comps[i], i)
+        job.remap_pass(job.layer)
         rccl.gather_begin(job.out_frames.ptr, counts[rank], None if recv is None else recv.ptr,
                           counts if rank == 0 else None)
     rccl.gather_end()

@@ -54,6 +54,8 @@ int tf_device_count(int *count);
      "remap_no_pack"  0   0 = tf_remap_step_dev keeps the layer state as ONE 32-bit word per pixel between steps where row,
                           column, alpha and source index fit 13 + 13 + 1 + 5 bits (frames up to 8192 x 8192, 32
                           sources), as int16 x 4 otherwise; 2 = as int16 x 4 at most; 1 = as int32 x 4 (never packed)
+     "remap_keep_rgba" 0  1 = tf_remap_steps_dev stores the layer's rgba in every step (it stores it in the last one alone where
+                          every pixel is selected by source 0: nothing reads the others')
      "prof_levels"    0   1 = profiler labels carry the pyramid level
      "fb_exact_sums"  0   1 = the box window (flags without OPTFLOW_FARNEBACK_GAUSSIAN) is summed exactly as
                           FarnebackUpdateFlow_Blur sums it -- one set of running sums per image, float-differenced
@@ -427,6 +429,15 @@ int tf_remap_render(tf_remap *layer, tf_comp *comp);
    it stands for (source.py:359-362) is formed in registers. */
 int tf_remap_step_dev(tf_remap *layer, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev,
                       uint64_t seed, const void *pixmap_dev, int channels);
+/* n consecutive tf_remap_step_dev calls as one: step i takes flows_dev[i], paints comps[i] from pixmaps_dev[i] and
+   draws from uniforms_dev[i] (uniforms_dev NULL: the generator, as a NULL uniform_dev above).  The layer state and the n
+   frames are those of the n calls (pipeline.py:565 + :518 for n consecutive flows of a clip whose frames stay on
+   the device).  Knowing the steps that follow, the call leaves out stores nothing reads: while every pixel is
+   selected by source 0 -- checked on the device before the first step; a one-source moveref layer that takes the
+   one-kernel step keeps it so -- a step's rgba (reference.py:93-105) is overwritten whole by the next step without
+   having been read, so only the last step stores it (option "remap_keep_rgba" = 1 stores it every time). */
+int tf_remap_steps_dev(tf_remap *layer, int n, tf_comp *const *comps, const void *const *flows_dev, int clip_flow,
+                       const void *const *uniforms_dev, uint64_t seed, const void *const *pixmaps_dev, int channels);
 
 /* State exchange for checkpoints (pipeline.py:225-242 pickles the compositor) and
    for extra/control.py:146-162 which reads layer.data.  data int32 [H][W][4]

@@ -442,6 +442,80 @@ def test_fused_step_state_in_int16_round_trips(tf, lib_option, no_pack):
     assert not layer.out_of_frame()
 
 
+@pytest.mark.parametrize("keep", [0, 1])
+@pytest.mark.parametrize("case", ["all selected", "holes", "leave empty", "rgba pixmaps"])
+def test_steps_call_equals_the_single_steps(tf, lib_option, case, keep):
+    """tf_remap_steps_dev = n tf_remap_step_dev calls: layer state, rgba and every frame the same bytes, and both equal to
+    the oracle's layer.  The call stores the layer's rgba in its last step alone while every pixel is selected by source 0
+    ("all selected": a fresh layer with a random reset through a mask); with pixels that are not ("holes": a checkpoint
+    with alpha 0 in a region, whose pixels must keep the colour they had) every step stores it; "leave empty" takes the
+    separate kernels; option remap_keep_rgba = 1 is the call without the elision."""
+    from transflow_amd.device import DevBuffer
+    lib_option("remap_keep_rgba", keep)
+    _, remap = tf
+    h, w, n = 97, 141, 5
+    ch = 4 if case == "rgba pixmaps" else 3
+    rng = np.random.default_rng(31)
+    pms = [rng.integers(0, 256, (h, w, ch), dtype=np.uint8) for _ in range(n)]
+    if ch == 4:
+        for pm in pms:
+            pm[..., 3] = rng.integers(0, 2, (h, w))
+    mask = rng.random((h, w), dtype=np.float32)
+    kw = dict(moving_pixels_leave_empty_spot=True) if case == "leave empty" else dict(reset_mode="random", reset_random_factor=0.3)
+
+    def make():
+        layer = remap.RemapLayer(h, w, reset_mask=None if case == "leave empty" else mask, **kw)
+        layer.set_sources([np.ones((h, w), np.uint8)])
+        return layer
+
+    one, many = make(), make()
+    prm = R.LayerParams(**kw)
+    ora = R.MoveRefLayer(h, w, prm, reset_mask=None if case == "leave empty" else mask, introduction_masks=[np.ones((h, w), bool)])
+    if case == "holes":
+        data, rgba = one.get_state()
+        data = data.copy()
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        data[20:50, 30:90, 2] = 0
+        for layer in (one, many):
+            layer.set_state(data, rgba)
+        ora.data[...] = data
+        ora.rgba[...] = rgba
+    flows = [R.post_process(rng.normal(0, 2.5, (h, w, 2)).astype(np.float32), R.BACKWARD) for _ in range(n)]
+    fbuf = [DevBuffer.from_array(f) for f in flows]
+    pbuf = [DevBuffer.from_array(pm) for pm in pms]
+    ubuf = [DevBuffer(h * w * 8) for _ in range(n)]
+    comp1 = remap.CompImage(h, w, (3, 2, 1))
+    compn = [remap.CompImage(h, w, (3, 2, 1)) for _ in range(n)]
+    singles = []
+    bg = np.broadcast_to(np.uint8([3, 2, 1]), (h, w, 3))
+    for i in range(n):
+        one.uniform_dev(77, ubuf[i].ptr)           # the field step i draws: the oracle is handed the same one
+        u = ubuf[i].download((h, w), np.float64)
+        one.step_dev(comp1, fbuf[i].ptr, pbuf[i].ptr, ch, seed=77)
+        singles.append(comp1.download())
+        if case == "leave empty":
+            ora.update(flows[i], [pms[i]])
+        else:
+            ora.update(flows[i], [pms[i]], u)
+        np.testing.assert_array_equal(singles[-1], R.composite(bg, [ora.render()]), err_msg=f"single step {i} vs oracle")
+    many.steps_dev(compn, [b.ptr for b in fbuf], [b.ptr for b in pbuf], ch, seed=77)
+    for i in range(n):
+        np.testing.assert_array_equal(compn[i].download(), singles[i], err_msg=f"frame {i}")
+    (d1, r1), (d2, r2) = one.get_state(), many.get_state()
+    np.testing.assert_array_equal(d2, d1)
+    np.testing.assert_array_equal(r2, r1)
+    np.testing.assert_array_equal(d2, ora.data)
+    np.testing.assert_array_equal(r2, ora.rgba)
+    # the call again on the layer it left: the state it left is the state the single steps left
+    many.steps_dev(compn[:2], [fbuf[0].ptr, fbuf[1].ptr], [pbuf[0].ptr, pbuf[1].ptr], ch, seed=77)
+    for i in range(2):
+        one.step_dev(comp1, fbuf[i].ptr, pbuf[i].ptr, ch, seed=77)
+        np.testing.assert_array_equal(compn[i].download(), comp1.download())
+    np.testing.assert_array_equal(many.get_state()[1], one.get_state()[1])
+    with pytest.raises(ValueError):
+        many.steps_dev(compn[:2], [fbuf[0].ptr], [pbuf[0].ptr, pbuf[1].ptr], ch)
+
+
 def test_flow_presteps_golden_gpu(tf):
     """scale / threshold / clip filters and the flow mask on the GPU (tf_fb_post_process_host_ex),
     through the FlowSource mirror, against the reference's outputs -- bit for bit, including which

@@ -141,6 +141,8 @@ PROTOTYPES = {
     "tf_remap_data_depth": (_I, [_P, _PI]),
     "tf_remap_render": (_I, [_P, _P]),
     "tf_remap_step_dev": (_I, [_P, _P, _P, _I, _P, C.c_uint64, _P, _I]),
+    "tf_remap_steps_dev": (_I, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), C.c_uint64,
+                                C.POINTER(C.c_void_p), _I]),
     "tf_remap_get_state": (_I, [_P, _P, _P]),
     "tf_remap_set_state": (_I, [_P, _P, _P]),
     "tf_comp_create": (_I, [_PP, _I, _I, C.POINTER(C.c_uint8)]),

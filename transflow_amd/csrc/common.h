@@ -22,7 +22,7 @@ int side_stream(int which, hipStream_t *out); // 0: background work (lowest prio
 int ensure_init();
 
 // Documented run-time options (tf_set_option / tf_get_option, include/tfhip.h).
-enum Opt { OPT_FB_FUSED = 0, OPT_FB_FUSE_MIN_PX, OPT_FB_NO_SHARE, OPT_FB_NO_OVERLAP, OPT_REMAP_PX, OPT_REMAP_NO_PACK,
+enum Opt { OPT_FB_FUSED = 0, OPT_FB_FUSE_MIN_PX, OPT_FB_NO_SHARE, OPT_FB_NO_OVERLAP, OPT_REMAP_PX, OPT_REMAP_NO_PACK, OPT_REMAP_KEEP_RGBA,
            OPT_PROF_LEVELS, OPT_FB_EXACT_SUMS, OPT_FB_CHAIN, OPT_FB_SEGS, OPT_COUNT };
 long option(Opt which);
 

@@ -276,6 +276,9 @@ struct StepParams {
     int n_sources;
     uint64_t seed, frame;
     uchar4 bg;
+    // tf_remap_steps_dev, every step but the last: where *rgba_dead != 0 the layer's rgba is not stored -- the next step
+    // of the same call overwrites every pixel of it without reading it (see there).  Null: always stored.
+    const int *rgba_dead;
 };
 
 // The layer state in HBM: int32 x 4 per pixel as the reference keeps it (data.py:6-17), or -- while only
@@ -414,7 +417,8 @@ k_remap_step(const float2 *__restrict__ flow, const S *__restrict__ old, S *__re
         // --- Layer.render (layer.py:32-34)
         if (mask_alpha)
             px.w = (unsigned char)(int)(mask_alpha[t] * (float)px.w);
-        rgba[t] = px;
+        if (!(sp.rgba_dead && *sp.rgba_dead))
+            rgba[t] = px;
         // --- Compositor.render over the background (compositor.py:35-39)
         uchar4 o = px.w != 0 ? px : sp.bg;
         s8[threadIdx.x * 3 + 0] = o.x;
@@ -571,6 +575,7 @@ k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *_
         gidx[p] = sel[p] ? (size_t)gi * W + gj : 0;
     }
     // --- phase 5: gather of source 0 (reference.py:94-105); pixels not selected keep their previous colour
+    const bool store_rgba = !(sp.rgba_dead && *sp.rgba_dead);
     uchar4 px[PX];
 #pragma unroll
     for (int p = 0; p < PX; p++) {
@@ -591,7 +596,7 @@ k_remap_step_px(const float2 *__restrict__ flow, const S *__restrict__ old, S *_
         // --- Layer.render (layer.py:32-34)
         if (mask_alpha)
             px[p].w = (unsigned char)(int)(ma[p] * (float)px[p].w);
-        if (live[p])
+        if (live[p] && store_rgba)
             rgba[t[p]] = px[p];
         // --- Compositor.render over the background (compositor.py:35-39)
         const uchar4 o = px[p].w != 0 ? px[p] : sp.bg;
@@ -861,6 +866,7 @@ struct tf_remap {
     DevBuf err;
     DevBuf scratch_flow, scratch_u, scratch_pix;
     DevBuf flow_scratch; // tf_remap_step_dev's unfused form on a winner map: the flow it stands for
+    DevBuf sel_flag;     // tf_remap_steps_dev: 1 while every pixel is selected by source 0
     uint64_t frame = 0;
     // the fused step keeps the state as one 32-bit word or as int16 x 4 (k_remap_step's note); every other entry point
     // that touches `data` converts it back first (state_unpacked)
@@ -880,6 +886,19 @@ struct tf_remap {
                 (void)hipEventDestroy(e);
     }
 };
+
+// *flag := 0 if any pixel of the state is NOT "selected" by source 0 (alpha != 0 and source index 0); the caller sets it to 1 first
+template <typename S>
+__global__ void k_state_all_selected(const S *__restrict__ state, int N, int *flag)
+{
+    bool bad = false;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < (size_t)N; t += (size_t)gridDim.x * BLOCK) {
+        const int4 d = state_load(state, t);
+        bad = bad || !(d.w == 0 && d.z != 0);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0)
+        atomicAnd(flag, 0);
+}
 
 // Makes data[cur] (int32) the current state.
 static int state_unpacked(tf_remap *L)
@@ -1410,8 +1429,10 @@ TF_API int tf_remap_set_state(tf_remap *L, const int32_t *data, const uint8_t *r
     return TF_OK;
 }
 
-TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev,
-                             uint64_t seed, const void *pixmap_dev, int channels)
+static bool step_fusable(const tf_remap *L) { return !L->fl.leave_empty && (L->cfg.reset_mode == 0 || L->cfg.reset_mode == 1); }
+
+static int step_dev_impl(tf_remap *L, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev, uint64_t seed,
+                         const void *pixmap_dev, int channels, const int *rgba_dead)
 {
     TF_REQUIRE(L && comp && (flow_dev || L->N == 0) && (pixmap_dev || L->N == 0), "tf_remap_step_dev: null pointer");
     TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_step_dev: pixmap must have 3 or 4 channels, got %d", channels);
@@ -1425,7 +1446,7 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     if (L->N == 0)
         return TF_OK;
     TF_REQUIRE(clip_flow >= 0 && clip_flow <= 2, "tf_remap_step_dev: clip_flow must be 0, 1 or 2, got %d", clip_flow);
-    const bool fusable = !L->fl.leave_empty && (L->cfg.reset_mode == 0 || L->cfg.reset_mode == 1);
+    const bool fusable = step_fusable(L);
     if (!fusable) { // same statements, one launch each
         if (clip_flow == 2) { // the winner map becomes a flow array first (kept in the layer's own scratch)
             if (!L->flow_scratch.p)
@@ -1452,6 +1473,7 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     sp.seed = seed;
     sp.frame = L->frame;
     sp.bg = comp->bg;
+    sp.rgba_dead = rgba_dead;
     const int px_per_thread = (int)option(OPT_REMAP_PX);
     dim3 block(BLOCK);
     auto run = [&](auto *old, auto *neu) {
@@ -1486,5 +1508,55 @@ TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, i
     TF_TRY(run((const int4 *)L->data[L->cur].as<int4>(), L->data[L->cur ^ 1].as<int4>()));
     L->cur ^= 1;
     L->frame++;
+    return TF_OK;
+}
+
+TF_API int tf_remap_step_dev(tf_remap *L, tf_comp *comp, const void *flow_dev, int clip_flow, const void *uniform_dev,
+                             uint64_t seed, const void *pixmap_dev, int channels)
+{
+    return step_dev_impl(L, comp, flow_dev, clip_flow, uniform_dev, seed, pixmap_dev, channels, nullptr);
+}
+
+// n consecutive tf_remap_step_dev calls in one: step i takes flows[i], paints comps[i] from pixmaps[i] (and draws from
+// uniforms[i], if given).  Same results, state and frames, as the n calls.  What the one call can do that n cannot: it
+// knows which stores of a step nobody will read.  The layer's rgba (reference.py:93-105) is read by the one-kernel step
+// only at pixels that source 0 does NOT select (alpha 0, or another source's index: they keep their previous colour),
+// and a step stores it at every pixel.  If every pixel is selected before the first step -- checked on the device, one
+// pass over the state -- it stays so through these steps (a move copies a selected pixel's state, the random reset of a
+// one-source layer writes alpha 1 and leaves the index 0; leave_empty and the other reset modes do not take the
+// one-kernel step at all), so each step's rgba is overwritten whole by the next without having been read: steps
+// 0 .. n-2 do not store it (4 of the step's 30 bytes per pixel), step n-1 does, and the layer leaves the call as the n
+// calls leave it.
+TF_API int tf_remap_steps_dev(tf_remap *L, int n, tf_comp *const *comps, const void *const *flows_dev, int clip_flow,
+                              const void *const *uniforms_dev, uint64_t seed, const void *const *pixmaps_dev, int channels)
+{
+    TF_REQUIRE(L && n >= 0 && (n == 0 || (comps && flows_dev && pixmaps_dev)), "tf_remap_steps_dev: null argument");
+    TF_TRY(ensure_init());
+    const int *dead = nullptr;
+    if (n >= 2 && L->N > 0 && L->cfg.layer_class == TF_LAYER_MOVEREF && L->n_sources == 1 && step_fusable(L) &&
+        option(OPT_REMAP_KEEP_RGBA) == 0) {
+        if (!L->sel_flag.p)
+            TF_TRY(L->sel_flag.alloc(sizeof(int)));
+        const int one = 1;
+        TF_HIP(hipMemcpyAsync(L->sel_flag.p, &one, sizeof(int), hipMemcpyHostToDevice, main_stream())); // (pageable source: copied before the call returns)
+        const dim3 grid((unsigned)std::min<size_t>(cdiv((size_t)L->N, BLOCK), 4096)), block(BLOCK);
+        if (const int kind = state_can_pack(L)) { // the form the steps will keep the state in
+            TF_TRY(state_packed(L, kind));
+            if (kind == 2)
+                TF_TRY(launch("remap_all_selected", k_state_all_selected<packed32>, grid, block, 0,
+                              (const packed32 *)L->pdata[L->pcur].as<packed32>(), L->N, L->sel_flag.as<int>()));
+            else
+                TF_TRY(launch("remap_all_selected", k_state_all_selected<short4s>, grid, block, 0,
+                              (const short4s *)L->pdata[L->pcur].as<short4s>(), L->N, L->sel_flag.as<int>()));
+        } else {
+            TF_TRY(state_unpacked(L));
+            TF_TRY(launch("remap_all_selected", k_state_all_selected<int4>, grid, block, 0, (const int4 *)L->cur_data(), L->N,
+                          L->sel_flag.as<int>()));
+        }
+        dead = L->sel_flag.as<int>();
+    }
+    for (int i = 0; i < n; i++)
+        TF_TRY(step_dev_impl(L, comps[i], flows_dev[i], clip_flow, uniforms_dev ? uniforms_dev[i] : nullptr, seed, pixmaps_dev[i],
+                             channels, i + 1 < n ? dead : nullptr));
     return TF_OK;
 }

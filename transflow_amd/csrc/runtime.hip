@@ -39,6 +39,7 @@ static OptDef g_opts[OPT_COUNT] = {
     {"fb_no_overlap", 0, 0, 1},                // 1: a call's work stays on the library stream (read at tf_fb_create)
     {"remap_px", 4, 1, 4},                     // pixels per thread of the one-kernel remap step: 1, 2 or 4 (4: 1.98 ms per 32 4K frames, 2: 2.04, 1: 2.45)
     {"remap_no_pack", 0, 0, 2},                // 1: the one-kernel remap step keeps its state as int32 x 4; 2: as int16 x 4 at most (0: one 32-bit word where row, column, alpha and source index fit 13 + 13 + 1 + 5 bits)
+    {"remap_keep_rgba", 0, 0, 1},              // 1: tf_remap_steps_dev stores the layer's rgba in every step (A/B of the elided stores)
     {"prof_levels", 0, 0, 1},                  // 1: profiler labels carry the pyramid level ("fb_polyexp.k2")
     {"fb_exact_sums", 0, 0, 1},                // 1: the box window's sums in OpenCV's own order (bit-identical flow, ~5x slower; read per call)
     {"fb_chain", -1, -1, 1},                   // how a segmented march gets OpenCV's column sums: -1 the cheaper way per launch; 0 a pre-pass; 1 handed down inside the launch

@@ -205,6 +205,20 @@ class RemapLayer:
                                           C.c_void_p(uniform_dev) if uniform_dev else None,
                                           C.c_uint64(seed & (2**64 - 1)), C.c_void_p(pixmap_dev), int(channels)))
 
+    def steps_dev(self, comps, flows_dev, pixmaps_dev, channels: int = 3, clip_flow=False, uniforms_dev=None, seed: int = 0) -> None:
+        """len(comps) consecutive step_dev calls as one (tf_remap_steps_dev): step i takes flows_dev[i] and paints comps[i]
+        from pixmaps_dev[i] (one pointer for all steps may be given as an int).  Same state and frames as the single
+        calls; the library leaves out the rgba stores nothing reads (tfhip.h)."""
+        n = len(comps)
+        if isinstance(pixmaps_dev, int):
+            pixmaps_dev = [pixmaps_dev] * n
+        if len(flows_dev) != n or len(pixmaps_dev) != n or (uniforms_dev is not None and len(uniforms_dev) != n):
+            raise ValueError("steps_dev: one flow, one pixmap (and one uniform field) per compositor image")
+        arr = lambda ptrs: (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ptrs])
+        check(self._lib.tf_remap_steps_dev(self._h, n, arr([c._h.value for c in comps]),
+                                           arr(flows_dev), int(clip_flow), None if uniforms_dev is None else arr(uniforms_dev),
+                                           C.c_uint64(seed & (2**64 - 1)), arr(pixmaps_dev), int(channels)))
+
     def render(self, comp: CompImage) -> None:
         check(self._lib.tf_remap_render(self._h, comp._h))
 

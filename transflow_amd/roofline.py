@@ -184,8 +184,13 @@ def built_remap_bytes(width, height, reset_mask=False, forward=False) -> int:
 
 
 def built_step_bytes(width, height, levels, pairs, iterations=3, reset_mask=False, forward=False, fused=-1) -> int:
+    """A pass of `pairs` pairs.  BACKWARD: its remap steps are ONE tf_remap_steps_dev call, which stores the layer's rgba
+    (4 B/px) in the last step alone while every pixel is selected (the bench's layers: one source, random reset)."""
     fb = sum(built_kernel_bytes(k, width, height, levels, pairs, iterations, fused) for k in BUILT_FB_KERNELS)
-    return fb + pairs * built_remap_bytes(width, height, reset_mask, forward)
+    rm = pairs * built_remap_bytes(width, height, reset_mask, forward)
+    if not forward and pairs >= 2:
+        rm -= (pairs - 1) * 4 * width * height
+    return fb + rm
 
 
 # ---- counters ------------------------------------------------------------------------------------
