@@ -7,8 +7,9 @@ The workload is BASELINE.json configs[4] (and configs[3] at N = 1): ONE clip of 
 frames, its 255 frame pairs sharded over the N ranks (`shard_range`, one-frame halo).  A "step" is
 one pass of the hot path over one batch of B consecutive pairs of the rank's shard: batched
 Farnebäck over the B pairs, then per pair, in stream order, post_process -> moveref update
-(+ random reset) -> pixmap gather -> render; consecutive steps walk down the shard and start over
-at its end.  The rank's frames, the pixmap and the masks are resident in HBM before the timed
+(+ random reset) -> pixmap gather -> render (BACKWARD workloads: the B remap steps as one
+tf_remap_steps_dev call -- the same state and frames as B single calls, the parity gate compares
+them); consecutive steps walk down the shard and start over at its end.  The rank's frames, the pixmap and the masks are resident in HBM before the timed
 region; output frames stay in HBM (the PCIe-inclusive rate is noted in DESIGN.md, never `value`).
 
 N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (fresh child
@@ -17,7 +18,8 @@ bench.py --gpus N` the ranks already exist and RANK / LOCAL_RANK / WORLD_SIZE co
 environment.  Either way no rank imports torch: the ranks meet through a rendezvous file + TCP star
 (transflow_amd.batch.HostGroup: barrier, max over ranks), the shared pixmap and reset mask come from
 rank 0 through RCCL (tf_batch_broadcast), and the gather of finished frames to rank 0
-(tf_batch_gather) is exercised and timed after the timed region -- results stay per rank in the
+(tf_batch_gather), and of the clip's flows to one remap recurrence on rank 0 (tf_batch_gather_at,
+"flows to root"), are exercised and timed after the timed region -- results stay per rank in the
 timed region, the path has no data-path collective.  Weak scaling: every rank does
 one batch per step.
 
