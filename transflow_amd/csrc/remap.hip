@@ -1537,8 +1537,7 @@ TF_API int tf_remap_steps_dev(tf_remap *L, int n, tf_comp *const *comps, const v
         option(OPT_REMAP_KEEP_RGBA) == 0) {
         if (!L->sel_flag.p)
             TF_TRY(L->sel_flag.alloc(sizeof(int)));
-        const int one = 1;
-        TF_HIP(hipMemcpyAsync(L->sel_flag.p, &one, sizeof(int), hipMemcpyHostToDevice, main_stream())); // (pageable source: copied before the call returns)
+        TF_HIP(hipMemsetD32Async((hipDeviceptr_t)L->sel_flag.p, 1, 1, main_stream()));
         const dim3 grid((unsigned)std::min<size_t>(cdiv((size_t)L->N, BLOCK), 4096)), block(BLOCK);
         if (const int kind = state_can_pack(L)) { // the form the steps will keep the state in
             TF_TRY(state_packed(L, kind));
