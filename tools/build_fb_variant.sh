@@ -11,7 +11,7 @@ mkdir -p $out/_common $out/$name
 for f in runtime remap flowops batch; do
   if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ]; then $CC -c $f.hip -o $out/_common/$f.o & fi
 done
-FB="farneback fb_pyramid fb_matrices fb_iterate fb_exact fb_postprocess fb_stages"
+FB="farneback fb_level_image fb_pyramid fb_matrices fb_iterate fb_exact fb_postprocess fb_stages"
 for f in $FB; do $CC "$@" -c $f.hip -o $out/$name/$f.o & done
 wait
 objs=""; for f in $FB; do objs="$objs $out/$name/$f.o"; done
