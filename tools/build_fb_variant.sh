@@ -8,12 +8,13 @@ cd "$(dirname "$0")/../transflow_amd/csrc"
 out=../../build_abl
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result -DTF_EXPERIMENT"
 mkdir -p $out/_common $out/$name
-for f in runtime remap flowops batch; do
-  if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ]; then $CC -c $f.hip -o $out/_common/$f.o & fi
+COMMON="runtime remap remap_step flowops batch"
+for f in $COMMON; do
+  if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ] || [ remap_common.h -nt $out/_common/$f.o ]; then $CC -c $f.hip -o $out/_common/$f.o & fi
 done
 FB="farneback fb_level_image fb_pyramid fb_matrices fb_iterate fb_exact fb_postprocess fb_stages"
 for f in $FB; do $CC "$@" -c $f.hip -o $out/$name/$f.o & done
 wait
 objs=""; for f in $FB; do objs="$objs $out/$name/$f.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libtfhip_$name.so $out/_common/runtime.o $out/_common/remap.o $out/_common/flowops.o $out/_common/batch.o $objs -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libtfhip_$name.so $(for f in $COMMON; do echo $out/_common/$f.o; done) $objs -ldl
 echo built $out/libtfhip_$name.so

@@ -261,13 +261,15 @@ __device__ __forceinline__ void tile_expansion(const float *sI, float (*sT)[TH][
     }
 }
 
-// rows of a tile of the fused expansion kernels (4K x 33 frames: level 0 with 12 / 16 / 20 rows 2.43 / 2.10 / 2.18 ms,
-// level 1 with 16 / 20 / 24 / 32 rows 1.31 (before its 2 x 2 blocks) / 0.87 / 0.95 / 1.05 ms)
+// rows of a tile of the fused expansion kernels (4K x 33 frames, round 3: level 0 with 12 / 16 / 20 rows 2.43 / 2.10 / 2.18 ms,
+// level 1 with 16 / 20 / 24 / 32 rows 1.31 (before its 2 x 2 blocks) / 0.87 / 0.95 / 1.05 ms; 4K x 129 frames, round 5: level 0
+// with 12 / 16 / 20 / 24 rows 9.55 / 8.79 - 8.88 / 8.81 / 8.76 ms, level 1 with 16 / 20 / 24 / 28 / 32 rows 4.20 / 3.96 - 4.02 /
+// 3.78 - 3.80 / 4.37 / 4.00 ms)
 #ifndef TF_EXP_TH0
 #define TF_EXP_TH0 16
 #endif
 #ifndef TF_EXP_TH1
-#define TF_EXP_TH1 20
+#define TF_EXP_TH1 24
 #endif
 // A1+A2 fused for the full-resolution level (resize is a copy, the blur has 3 taps): the level
 // image never leaves the CU.  Stages the u8 region by REAL image coordinates (REFLECT_101 ring of
