@@ -684,7 +684,10 @@ k_level_colpass(const float *__restrict__ rowf, float *__restrict__ img, int W, 
 // a time, packed), then the column pass (centre, then pairs outwards) and both lerps -- k_level_image's statements in
 // k_level_image's order.  Tile 64 x 32 level pixels = 264 x 134 staged bytes; a wave per eight level rows.
 // ---------------------------------------------------------------------------------
-constexpr int QI_TW = 64, QI_TH = 16;
+#ifndef TF_QI_TH
+#define TF_QI_TH 16
+#endif
+constexpr int QI_TW = 64, QI_TH = TF_QI_TH;
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_level_quarter_image(const uint8_t *__restrict__ frames, const int2 *__restrict__ pairs, float *__restrict__ img, int W, int H,

@@ -11,7 +11,10 @@ namespace {
 // double.  Clamped loads reproduce OpenCV's row clamping (vertical) and its
 // replication of the edge triple (horizontal).
 // ---------------------------------------------------------------------------------
-constexpr int PX_TW = 64, PX_TH = 16;
+#ifndef TF_PX_TH
+#define TF_PX_TH 16
+#endif
+constexpr int PX_TW = 64, PX_TH = TF_PX_TH;
 
 __global__ void k_polyexp(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
 {
@@ -118,7 +121,7 @@ template <int N>
 __global__ void __launch_bounds__(256)
 k_polyexp_t(const float *__restrict__ img, float *__restrict__ R, int Wk, int Hk, PolyConst pc)
 {
-    constexpr int TW = 64, TH = 16, LW = TW + 2 * N, LH = TH + 2 * N;
+    constexpr int TW = PX_TW, TH = PX_TH, LW = TW + 2 * N, LH = TH + 2 * N;
     __shared__ float sI[LH * LW];
     __shared__ float sT[3][TH][LW];
     const int pi = blockIdx.z;
