@@ -657,8 +657,10 @@ def flows_to_root_leg(job, host, rccl, plans):
     collect(False)
     job.sync()
     t_collect = time.perf_counter() - t0
-    if rank == 0:
-        paint(job.make_layer(), lambda j: clip.ptr + j * flow_bytes, total_pairs)
+    if rank == 0:     # the clip's remap steps as one call (the frames land in the pass's images in turn)
+        job.make_layer().steps_dev([job.comps[j % job.batch] for j in range(total_pairs)],
+                                   [clip.ptr + j * flow_bytes for j in range(total_pairs)], job.pixmap_dev, 3, clip_flow=True,
+                                   seed=SEED_U)
         job.sync()
     host.barrier()
     dt = host.max_over_ranks(time.perf_counter() - t0)
