@@ -690,7 +690,7 @@ TF_API int tf_fb_calc_slots(tf_fb *fb, int n_pairs, const int *prev_slots, const
         // stand side by side, through M in memory otherwise (4K: 7.0 against 9.3 ms per level-0 iteration with 32 pairs,
         // 2.9 against 2.5 with 8, 1.8 against 0.5 with one)
         const bool exact_one_kernel = !fb_exact(fb) || fb->fused > 0 || (long)cdiv(L.W, 112) * n_pairs >= 560;
-        const bool fused_here = fusable && !fb->gaussian() && exact_one_kernel && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 29) && L.W < (1 << 24) && L.H < (1 << 24) &&
+        const bool fused_here = fusable && !fb->gaussian() && exact_one_kernel && L.W >= 10 && L.H >= 10 && (size_t)L.W * L.H < (1u << 28) && L.W < (1 << 24) && L.H < (1 << 24) &&
                                 (fb->fused > 0 || (fb->fused < 0 && (long)L.W * L.H * n_pairs >= fuse_min_px));
         if (k == 0 && overlap && !fused_here)
             a = out_buf;

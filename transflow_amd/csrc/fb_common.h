@@ -35,56 +35,52 @@ typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---------------------------------------------------------------------------------
 // Layout of R, the polynomial coefficients of one image at one level (Nk pixels, 5 Nk floats, OpenCV's channel
-// order): three planes -- (c0, c1) pairs [Nk][2], (c2, c3) pairs [Nk][2], c4 [Nk].  FarnebackUpdateMatrices pairs
-// the channels exactly so ((c0, c1) feed h, (c2, c3) the diagonal of G, c4 its off-diagonal): the two taps of a
-// bilinear row arrive as ONE 16-byte load per channel pair (x1 and x1 + 1 are adjacent pixels), a pixel's own
-// coefficients as two 8-byte loads and a 4-byte one, and the arithmetic runs on register pairs as they were
-// loaded: 10 instead of 16 loads per pixel and no shuffling between loads and packed math.
+// order): two planes -- (c0, c1, c2, c3) quads [Nk][4] and c4 [Nk].  FarnebackUpdateMatrices pairs the channels
+// ((c0, c1) feed h, (c2, c3) the diagonal of G, c4 its off-diagonal), and the halves of a quad are those pairs: a
+// pixel's own coefficients arrive as ONE 16-byte load and a 4-byte one, the two taps of a bilinear row as two
+// 16-byte loads (x1 and x1 + 1 are adjacent pixels) and an 8-byte one, and the arithmetic runs on register pairs as
+// they were loaded: 9 loads per pixel (rounds 2 - 4 kept (c0, c1) and (c2, c3) in planes of their own: 10 loads; the
+// producers of the one-kernel iteration are bound by the instructions they issue, and the load less bought 0.6 % of
+// the whole step in same-box runs, round 5).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ size_t r_off23(size_t Nk) { return 2 * Nk; }
 __device__ __forceinline__ size_t r_off4(size_t Nk) { return 4 * Nk; }
 
 __device__ __forceinline__ void r_load_px(const float *__restrict__ R, size_t Nk, size_t o, float v[5])
 {
-    const float2u a = *reinterpret_cast<const float2u *>(R + 2 * o);
-    const float2u b = *reinterpret_cast<const float2u *>(R + r_off23(Nk) + 2 * o);
+    const float4u a = *reinterpret_cast<const float4u *>(R + 4 * o);
     v[0] = a.x;
     v[1] = a.y;
-    v[2] = b.x;
-    v[3] = b.y;
+    v[2] = a.z;
+    v[3] = a.w;
     v[4] = R[r_off4(Nk) + o];
 }
-// the taps at pixels q and q + 1 (row y1) and q + Wk, q + Wk + 1 (row y1 + 1): per channel (left, right)
 __device__ __forceinline__ void r_load_taps(const float *__restrict__ R, size_t Nk, size_t q, int Wk, float2u t[5], float2u b[5])
 {
-    const float4u t01 = *reinterpret_cast<const float4u *>(R + 2 * q), b01 = *reinterpret_cast<const float4u *>(R + 2 * (q + Wk));
-    const float4u t23 = *reinterpret_cast<const float4u *>(R + r_off23(Nk) + 2 * q);
-    const float4u b23 = *reinterpret_cast<const float4u *>(R + r_off23(Nk) + 2 * (q + Wk));
+    const float4u t0 = *reinterpret_cast<const float4u *>(R + 4 * q), t1 = *reinterpret_cast<const float4u *>(R + 4 * q + 4);
+    const float4u b0 = *reinterpret_cast<const float4u *>(R + 4 * (q + Wk)), b1 = *reinterpret_cast<const float4u *>(R + 4 * (q + Wk) + 4);
     const float2u t4 = *reinterpret_cast<const float2u *>(R + r_off4(Nk) + q), b4 = *reinterpret_cast<const float2u *>(R + r_off4(Nk) + q + Wk);
-    t[0] = float2u{t01.x, t01.z};
-    t[1] = float2u{t01.y, t01.w};
-    t[2] = float2u{t23.x, t23.z};
-    t[3] = float2u{t23.y, t23.w};
+    t[0] = float2u{t0.x, t1.x};
+    t[1] = float2u{t0.y, t1.y};
+    t[2] = float2u{t0.z, t1.z};
+    t[3] = float2u{t0.w, t1.w};
     t[4] = t4;
-    b[0] = float2u{b01.x, b01.z};
-    b[1] = float2u{b01.y, b01.w};
-    b[2] = float2u{b23.x, b23.z};
-    b[3] = float2u{b23.y, b23.w};
+    b[0] = float2u{b0.x, b1.x};
+    b[1] = float2u{b0.y, b1.y};
+    b[2] = float2u{b0.z, b1.z};
+    b[3] = float2u{b0.w, b1.w};
     b[4] = b4;
 }
 __device__ __forceinline__ void r_store_px(float *__restrict__ R, size_t Nk, size_t o, const float v[5])
 {
-    *reinterpret_cast<float2u *>(R + 2 * o) = float2u{v[0], v[1]};
-    *reinterpret_cast<float2u *>(R + r_off23(Nk) + 2 * o) = float2u{v[2], v[3]};
+    *reinterpret_cast<float4u *>(R + 4 * o) = float4u{v[0], v[1], v[2], v[3]};
     R[r_off4(Nk) + o] = v[4];
 }
 __device__ __forceinline__ void r_store_px2(float *__restrict__ R, size_t Nk, size_t o, const float v0[5], const float v1[5])
 {
-    *reinterpret_cast<float4u *>(R + 2 * o) = float4u{v0[0], v0[1], v1[0], v1[1]};
-    *reinterpret_cast<float4u *>(R + r_off23(Nk) + 2 * o) = float4u{v0[2], v0[3], v1[2], v1[3]};
+    *reinterpret_cast<float4u *>(R + 4 * o) = float4u{v0[0], v0[1], v0[2], v0[3]};
+    *reinterpret_cast<float4u *>(R + 4 * o + 4) = float4u{v1[0], v1[1], v1[2], v1[3]};
     *reinterpret_cast<float2u *>(R + r_off4(Nk) + o) = float2u{v0[4], v1[4]};
 }
-
 struct PolyConst {
     int n;
     float g[MAX_POLY_N + 1], xg[MAX_POLY_N + 1], xxg[MAX_POLY_N + 1];

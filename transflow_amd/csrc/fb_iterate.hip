@@ -13,25 +13,23 @@ namespace {
 // k_flow_iter_pc below.  Same statements as update_matrix_px, rounding for rounding (see gather1_finish).
 // ---------------------------------------------------------------------------------
 struct Gather1 {
-    float2u r0a, r0b;            // R0 at the pixel: (c0, c1), (c2, c3)
+    float4u r0;                  // R0 at the pixel: (c0, c1, c2, c3)
     float r0c;                   // ... and c4
-    float4u t01, t23, b01, b23;  // R1 on rows y1 / y1 + 1: a channel pair at x1 (.xy) and at x1 + 1 (.zw)
+    float4u t0, t1, b0, b1;      // R1 on rows y1 / y1 + 1 at x1 and x1 + 1: (c0, c1, c2, c3)
     float2u t4, b4;              // c4 at x1, x1 + 1
     float dx, dy, fx, fy;
     bool inb;
 };
-
-// The wave-uniform plane bases stay in SGPRs and every load is base + one 32-bit byte offset per lane: the
-// pair planes share one offset (8 bytes per pixel), the c4 planes another (4 bytes per pixel).
+// The wave-uniform plane bases stay in SGPRs and every load is base + one 32-bit byte offset per lane: the quad
+// planes share one offset (16 bytes per pixel), the c4 planes another (4 bytes per pixel).
 struct PlaneBases {
-    const float *r0_01, *r0_23, *r0_4;
-    const float *r1_01, *r1_23, *r1_4;
-    const float *r1_01b, *r1_23b, *r1_4b; // the same planes one row down: the bilinear bottom row shares the top row's offset
+    const float *r0_q, *r0_4;
+    const float *r1_q, *r1_q1, *r1_4;      // the quads at x1 and at x1 + 1 (one pixel = 16 bytes further)
+    const float *r1_qb, *r1_q1b, *r1_4b;   // the same one row down
 };
 __device__ __forceinline__ PlaneBases plane_bases(const float *R0, const float *R1, size_t Nk, int Wk)
 {
-    return PlaneBases{R0, R0 + r_off23(Nk), R0 + r_off4(Nk), R1, R1 + r_off23(Nk), R1 + r_off4(Nk),
-                      R1 + 2 * Wk, R1 + r_off23(Nk) + 2 * Wk, R1 + r_off4(Nk) + Wk};
+    return PlaneBases{R0, R0 + r_off4(Nk), R1, R1 + 4, R1 + r_off4(Nk), R1 + 4 * Wk, R1 + 4 * Wk + 4, R1 + r_off4(Nk) + Wk};
 }
 
 __device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
@@ -49,7 +47,7 @@ __device__ __forceinline__ float4u ld_f32x4(const float *base, unsigned byte_off
 
 // The addresses and weights of one pixel's gathers (everything that depends on the flow), apart from the loads.
 struct GatherPrep {
-    unsigned o8, o4, q8, q4; // byte offsets: the pixel in an 8-byte / 4-byte plane of R0, the top-left tap in R1's
+    unsigned o16, o4, q16, q4; // byte offsets: the pixel in the 16-byte / 4-byte plane of R0, the top-left tap in R1's
     float dx, dy, fx, fy;
     bool inb;
 };
@@ -57,7 +55,7 @@ __device__ __forceinline__ GatherPrep gather1_prep(int Wk, int Hk, int x, int y,
 {
     GatherPrep p;
     const unsigned o = (unsigned)y * Wk + x;
-    p.o8 = o * 8u;
+    p.o16 = o * 16u;
     p.o4 = o * 4u;
     const float fx = x + fl.x, fy = y + fl.y;
     const float flx = floorf(fx), fly = floorf(fy); // (float)(int)floor(f) == floor(f) wherever the int exists
@@ -70,24 +68,23 @@ __device__ __forceinline__ GatherPrep gather1_prep(int Wk, int Hk, int x, int y,
     // out-of-frame taps load from a clamped (valid) address and are discarded: no branch around the loads
     // (rows and widths are far below 2^24: the 24-bit multiply-add is exact and a single full-rate instruction)
     const unsigned qt = __umul24((unsigned)med3i(y1, 0, Hk - 2), (unsigned)Wk) + (unsigned)med3i(x1, 0, Wk - 2);
-    p.q8 = qt * 8u;
+    p.q16 = qt * 16u;
     p.q4 = qt * 4u;
     return p;
 }
 __device__ __forceinline__ void gather1_load(Gather1 &g, const PlaneBases &pb, const GatherPrep &p)
 {
-    g.r0a = ld_f32x2(pb.r0_01, p.o8);
-    g.r0b = ld_f32x2(pb.r0_23, p.o8);
+    g.r0 = ld_f32x4(pb.r0_q, p.o16);
     g.r0c = ld_f32(pb.r0_4, p.o4);
     g.dx = p.dx;
     g.dy = p.dy;
     g.fx = p.fx;
     g.fy = p.fy;
     g.inb = p.inb;
-    g.t01 = ld_f32x4(pb.r1_01, p.q8);
-    g.b01 = ld_f32x4(pb.r1_01b, p.q8);
-    g.t23 = ld_f32x4(pb.r1_23, p.q8);
-    g.b23 = ld_f32x4(pb.r1_23b, p.q8);
+    g.t0 = ld_f32x4(pb.r1_q, p.q16);
+    g.t1 = ld_f32x4(pb.r1_q1, p.q16);
+    g.b0 = ld_f32x4(pb.r1_qb, p.q16);
+    g.b1 = ld_f32x4(pb.r1_q1b, p.q16);
     g.t4 = ld_f32x2(pb.r1_4, p.q4);
     g.b4 = ld_f32x2(pb.r1_4b, p.q4);
 }
@@ -113,16 +110,17 @@ __device__ __forceinline__ void gather1_finish(const Gather1 &g, float wx, float
 {
     const float fx = g.fx, fy = g.fy, dx = g.dx, dy = g.dy;
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    float2u r23 = a00 * g.t01.xy + a01 * g.t01.zw + a10 * g.b01.xy + a11 * g.b01.zw;
-    float2u r45 = a00 * g.t23.xy + a01 * g.t23.zw + a10 * g.b23.xy + a11 * g.b23.zw;
+    const float2u r0a = g.r0.xy, r0b = g.r0.zw;
+    float2u r23 = a00 * g.t0.xy + a01 * g.t1.xy + a10 * g.b0.xy + a11 * g.b1.xy;
+    float2u r45 = a00 * g.t0.zw + a01 * g.t1.zw + a10 * g.b0.zw + a11 * g.b1.zw;
     float r6 = a00 * g.t4.x + a01 * g.t4.y + a10 * g.b4.x + a11 * g.b4.y;
-    r45 = (g.r0b + r45) * 0.5f;
+    r45 = (r0b + r45) * 0.5f;
     r6 = (g.r0c + r6) * 0.25f;
     const float o6 = g.r0c * 0.5f;
     r23 = g.inb ? r23 : float2u{0.f, 0.f};
-    r45 = g.inb ? r45 : g.r0b;
+    r45 = g.inb ? r45 : r0b;
     r6 = g.inb ? r6 : o6;
-    r23 = (g.r0a - r23) * 0.5f;
+    r23 = (r0a - r23) * 0.5f;
     float r2 = r23.x, r3 = r23.y, r4 = r45.x, r5 = r45.y;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
