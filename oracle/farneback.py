@@ -27,6 +27,26 @@ def build(force: bool = False) -> str:
     return so
 
 
+VARIANTS = ("fma", "area", "polyf32")     # oracle/Makefile, target `variants`: sensitivity builds, never parity targets
+_VARIANT_LIBS = {}
+
+
+def variant_lib(name):
+    """A sensitivity build of the same source (oracle/Makefile `variants`): "fma" = FMA contraction as an AVX2/FMA
+    OpenCV wheel contracts, "area" = [VERIFY] 4's scalar-tail order on a half-size level, "polyf32" = the
+    polynomial expansion's horizontal part in float.  Used to measure how far the default build (the parity
+    target) and the HIP library sit from builds a real OpenCV could be."""
+    if name not in VARIANTS:
+        raise ValueError(name)
+    if name not in _VARIANT_LIBS:
+        so = os.path.join(_HERE, f"libfbref_{name}.so")
+        src = os.path.join(_HERE, "farneback_ref.c")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+            subprocess.check_call(["make", "-C", _HERE, "-B", f"libfbref_{name}.so"], stdout=subprocess.DEVNULL)
+        _VARIANT_LIBS[name] = C.CDLL(so)
+    return _VARIANT_LIBS[name]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -166,9 +186,11 @@ def update_flow_gaussian(r0, r1, flow, m, winsize, update):
     return flow, m
 
 
-def calc(prev, nxt, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0, flow=None):
+def calc(prev, nxt, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0, flow=None,
+         variant=None):
     """Same argument meaning as cv2.calcOpticalFlowFarneback (reference cv.py:479-490); `flow` is the
-    initial flow read when flags has OPTFLOW_USE_INITIAL_FLOW (never modified: a new array is returned)."""
+    initial flow read when flags has OPTFLOW_USE_INITIAL_FLOW (never modified: a new array is returned).
+    `variant`: one of VARIANTS -- the same call through a sensitivity build (variant_lib); None = the parity target."""
     prev = np.ascontiguousarray(prev, np.uint8)
     nxt = np.ascontiguousarray(nxt, np.uint8)
     assert prev.shape == nxt.shape and prev.ndim == 2
@@ -178,7 +200,7 @@ def calc(prev, nxt, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5,
         assert flow.shape == (h, w, 2)
     else:
         flow = np.zeros((h, w, 2), np.float32)
-    rc = lib().fbref_calc(_p(prev), _p(nxt), C.c_int(w), C.c_int(h), _p(flow), C.c_double(pyr_scale), C.c_int(levels),
+    rc = (variant_lib(variant) if variant else lib()).fbref_calc(_p(prev), _p(nxt), C.c_int(w), C.c_int(h), _p(flow), C.c_double(pyr_scale), C.c_int(levels),
                           C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n), C.c_double(poly_sigma), C.c_int(flags))
     if rc != 0:
         raise ValueError("fbref_calc: unsupported arguments")

@@ -214,6 +214,19 @@ FB_EXPORT void fbref_resize_linear(const float *src, int sw, int sh, int cn, flo
         memcpy(dst, src, sizeof(float) * (size_t)sw * sh * cn);
         return;
     }
+#ifdef FBREF_AREA_TAIL
+    /* Sensitivity variant ([VERIFY] 4): at exactly half size cv::resize(INTER_LINEAR) takes INTER_AREA's fast
+     * path; this build gives EVERY column the order of its scalar tail, (((a + b) + c) + d) * 0.25f -- the
+     * widest a real build's mix of vector body and tail can be from the default build's bilinear statement. */
+    if (cn == 1 && sw == 2 * dw && sh == 2 * dh) {
+        for (int dy = 0; dy < dh; dy++) {
+            const float *s0 = src + (size_t)(2 * dy) * sw, *s1 = s0 + sw;
+            for (int dx = 0; dx < dw; dx++)
+                dst[(size_t)dy * dw + dx] = (((s0[2 * dx] + s0[2 * dx + 1]) + s1[2 * dx]) + s1[2 * dx + 1]) * 0.25f;
+        }
+        return;
+    }
+#endif
     lerp_tab tx, ty;
     make_lerp(sw, dw, &tx, 1);
     make_lerp(sh, dh, &ty, 0);
@@ -359,6 +372,42 @@ FB_EXPORT void fbref_polyexp(const float *src, int W, int H, int n, double sigma
             row[-1 - x] = row[2 - x];
             row[W * 3 + x] = row[W * 3 + x - 3];
         }
+#ifdef FBREF_POLY_F32
+        /* Sensitivity variant: the horizontal part accumulated in FLOAT with fused multiply-adds -- the
+         * arithmetic of the HIP library's default (non-exact) mode, restated here only to measure on the CPU
+         * how far such a build moves the flow (tests/test_oracle_farneback.py: the envelope).  Never the
+         * parity target: that is the default build below. */
+        for (int x = 0; x < W; x++) {
+            g0 = g[0];
+            float b1 = row[x * 3] * g0, b2 = 0, b3 = row[x * 3 + 1] * g0, b4 = 0, b5 = row[x * 3 + 2] * g0, b6 = 0;
+            for (int k = 1; k <= n; k++) {
+                float tg = row[(x + k) * 3] + row[(x - k) * 3];
+                g0 = g[k];
+                b1 = fmaf(tg, g0, b1);
+                b4 = fmaf(tg, xxg[k], b4);
+                b2 = fmaf(row[(x + k) * 3] - row[(x - k) * 3], xg[k], b2);
+                b3 = fmaf(row[(x + k) * 3 + 1] + row[(x - k) * 3 + 1], g0, b3);
+                b6 = fmaf(row[(x + k) * 3 + 1] - row[(x - k) * 3 + 1], xg[k], b6);
+                b5 = fmaf(row[(x + k) * 3 + 2] + row[(x - k) * 3 + 2], g0, b5);
+            }
+#if FBREF_POLY_F32 >= 2 /* ... and the combination with the inverse's entries in float as well */
+            const float f11 = (float)ig11, f03 = (float)ig03, f33 = (float)ig33, f55 = (float)ig55;
+            const float b103 = b1 * f03;
+            drow[x * 5 + 1] = b2 * f11;
+            drow[x * 5] = b3 * f11;
+            drow[x * 5 + 3] = fmaf(b4, f33, b103);
+            drow[x * 5 + 2] = fmaf(b5, f33, b103);
+            drow[x * 5 + 4] = b6 * f55;
+#else
+            drow[x * 5 + 1] = (float)(b2 * ig11);
+            drow[x * 5] = (float)(b3 * ig11);
+            drow[x * 5 + 3] = (float)(b1 * ig03 + b4 * ig33);
+            drow[x * 5 + 2] = (float)(b1 * ig03 + b5 * ig33);
+            drow[x * 5 + 4] = (float)(b6 * ig55);
+#endif
+        }
+        continue;
+#endif
         for (int x = 0; x < W; x++) { /* horizontal part, double accumulators */
             g0 = g[0];
             double b1 = row[x * 3] * g0, b2 = 0, b3 = row[x * 3 + 1] * g0, b4 = 0, b5 = row[x * 3 + 2] * g0, b6 = 0;

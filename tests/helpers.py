@@ -95,3 +95,65 @@ def capture_frame_numbers(prm, t, ns):
     next() calls - 1): one call per frame in which the layer introduced, i.e. every frame, or only
     the first with introduce_once."""
     return [0 if prm.introduce_once else t] * ns
+
+
+# Farneback shapes / parameter sets shared by the GPU parity tests and the oracle's envelope test
+FB_CASES = [
+    ((270, 480), dict()),                                   # transflow defaults (cv.py:273-281)
+    ((480, 854), dict()),                                   # configs[0] geometry (River.mp4 854x480)
+    ((135, 241), dict(levels=2)),                           # odd sizes: non-integer resize ratios
+    ((200, 260), dict(levels=0)),                           # one scale
+    ((96, 128), dict(levels=5, winsize=9, iterations=2, poly_n=7, poly_sigma=1.5)),
+    ((40, 50), dict(levels=3)),                             # below min_size: K = 0
+    ((64, 300), dict(levels=1, pyr_scale=0.8)),
+]
+
+
+FB_SWEEP = [
+    ((360, 642), dict(levels=4, pyr_scale=0.7)),                 # non-dyadic pyramid: every level resized with fractions
+    ((358, 639), dict(levels=3, pyr_scale=0.5, winsize=21)),     # odd sizes, window half-width 10
+    ((240, 320), dict(levels=2, winsize=25, iterations=5)),      # half-width 12, more iterations
+    ((300, 400), dict(levels=3, winsize=5, iterations=1)),       # half-width 2, a single iteration
+    ((270, 482), dict(levels=5, poly_n=7, poly_sigma=1.5)),      # width % 4 != 0: no split level images
+    ((540, 960), dict(levels=5, poly_n=5, poly_sigma=1.1)),      # quarter-4K: the bench's level structure
+    ((128, 4096), dict(levels=2)),                               # wide and flat
+    ((2048, 64), dict(levels=1)),                                # tall and narrow
+    ((90, 130), dict(levels=1, pyr_scale=0.3)),                  # a big step between two scales
+]
+
+
+# ---- fixtures made by tools/pin_with_cv2.py on a machine with a real OpenCV (none is committed until one was) ----------
+
+def cv2_fixture_files(directory=None):
+    return sorted(glob.glob(os.path.join(directory or GOLDEN, "farneback_cv2_*.npz")))
+
+
+def cv2_fixture_cases(path):
+    """(meta, [(case dict, prev, next, initial flow or None, cv2's flow)], skipped) of one fixture.  The inputs are
+    regenerated from the stored seeds; a case whose regenerated frames do not have the stored CRCs is listed in
+    `skipped` (another numpy drawing other numbers), never compared."""
+    import json
+    import zlib
+    z = np.load(path)
+    meta = json.loads(str(z["meta_json"]))
+    out, skipped = [], []
+    for c in meta["cases"]:
+        a, b = synth_pair(c["h"], c["w"], seed=c["seed"])
+        if (zlib.crc32(a.tobytes()) & 0xFFFFFFFF, zlib.crc32(b.tobytes()) & 0xFFFFFFFF) != (c["crc_prev"], c["crc_next"]):
+            skipped.append(c["key"])
+            continue
+        init = z[c["initial_flow"]] if c.get("initial_flow") else None
+        out.append((c, a, b, init, z[c["key"]]))
+    return meta, out, skipped
+
+
+def cv2_fixture_grey(path):
+    """(bgr frame, [(width, height, cv2's grey frame)]) of one fixture, or None when the frame does not regenerate."""
+    import json
+    import zlib
+    z = np.load(path)
+    g = json.loads(str(z["meta_json"]))["grey"]
+    bgr = np.random.default_rng(g["seed"]).integers(0, 256, tuple(g["shape"]) + (3,), dtype=np.uint8)
+    if zlib.crc32(bgr.tobytes()) & 0xFFFFFFFF != g["crc_bgr"]:
+        return None
+    return bgr, [(o["width"], o["height"], z[o["key"]]) for o in g["outputs"]]

@@ -129,6 +129,67 @@ def test_single_scale_and_small_frames():
         F.calc(a, b, flags=8)          # only OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256) exist
 
 
+def test_sensitivity_variants_stay_within_a_quarter_of_the_tolerance():
+    """The envelope: the parity target is the scalar statement built without FMA contraction, and
+    nothing pins it to a real OpenCV build.  What a real build may legitimately do differently -- contract
+    multiply-adds in its SIMD bodies (`fma`), run INTER_AREA's scalar tail over more or fewer columns of a half-size
+    level ([VERIFY] 4, `area`) -- and what a cheaper expansion would do (`polyf32`) moves the flow by a few percent of
+    the 1e-4 tolerance on every shape of the GPU suites: the tolerance has an order of magnitude of headroom over
+    build-level rounding.  (At 4K one discontinuity of the algorithm -- FarnebackUpdateMatrices' in-frame test at a
+    border pixel whose sample point sits within float resolution of the last row -- can be decided the other way by
+    such a build and move a patch of a few hundred pixels beyond the tolerance: tools/oracle_envelope.py,
+    profiles/r06_oracle_envelope.txt.  The shapes here hold no such pixel.)"""
+    from tests.helpers import FB_CASES, FB_SWEEP, synth_pair
+    worst = {}
+    for (h, w), kw in FB_CASES + FB_SWEEP:
+        a, b = synth_pair(h, w, seed=70)
+        ref = F.calc(a, b, **kw)
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        for v in F.VARIANTS:
+            got = F.calc(a, b, variant=v, **kw)
+            dev = float(np.abs(got - ref).max()) / tol
+            worst[v] = max(worst.get(v, 0.0), dev)
+            assert dev <= 0.25, f"{v} build at {w}x{h} {kw}: {dev:.3f} of the tolerance"
+    # the builds do differ (the variants are not no-ops), except that `area` needs a half-size level to act on
+    assert worst["fma"] > 0 and worst["polyf32"] > 0 and worst["area"] > 0
+
+
+def test_area_variant_acts_only_on_exactly_half_size_levels():
+    from tests.helpers import synth_pair
+    a, b = synth_pair(135, 241, seed=3)                     # odd sizes: no level is exactly half the frame
+    np.testing.assert_array_equal(F.calc(a, b, levels=2, variant="area"), F.calc(a, b, levels=2))
+    a, b = synth_pair(128, 192, seed=3)
+    assert not np.array_equal(F.calc(a, b, levels=2, variant="area"), F.calc(a, b, levels=2))
+
+
+def check_oracle_against_cv2_fixture(path):
+    """The oracle against one file of tools/pin_with_cv2.py: every stored flow within 1e-4 * max(1, max|cv2|) -- the
+    day such a file exists under tests/golden/ the Farneback half of the parity story is pinned to that OpenCV build.
+    Returns (cases compared, cases bit-identical, largest deviation in units of the tolerance)."""
+    from tests.helpers import cv2_fixture_cases
+    meta, cases, skipped = cv2_fixture_cases(path)
+    assert cases, f"{path}: no case regenerates its inputs here (numpy {np.__version__} vs {meta['numpy_version']}): {skipped}"
+    identical, worst = 0, 0.0
+    for c, a, b, init, ref in cases:
+        got = F.calc(a, b, flags=c["flags"], flow=init, **c["params"])
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        dev = float(np.abs(got - ref).max()) / tol
+        assert dev <= 1.0, f"{path} {c['key']}: oracle {dev:.3f} x the tolerance from cv2 {meta['cv2_version']}"
+        identical += bool(np.array_equal(got, ref))
+        worst = max(worst, dev)
+    return len(cases), identical, worst
+
+
+def test_against_cv2_fixtures_when_present():
+    from tests.helpers import cv2_fixture_files
+    files = cv2_fixture_files()
+    if not files:
+        pytest.skip("no tests/golden/farneback_cv2_*.npz: run tools/pin_with_cv2.py where `import cv2` works (PARITY UNPINNED until then)")
+    for path in files:
+        n, same, worst = check_oracle_against_cv2_fixture(path)
+        print(f"{path}: {n} flows, {same} bit-identical, worst {worst:.3f} of the tolerance")
+
+
 def test_against_cv2_when_available():
     cv2 = pytest.importorskip("cv2")
     a, b = _texture(240, 320), _texture(240, 320, 2.5, -1.5)
