@@ -247,10 +247,11 @@ def gate_pairs(batch, n_check=2):
     return sorted({round(j * (batch - 1) / (n_check - 1)) for j in range(n_check)})
 
 
-def parity_gate(job, n_check=2):
+def parity_gate(job, n_check=3):
     """The calls the timed loop makes (one batched Farnebäck pass over the first batch, shared expansions;
     then the fused remap step per pair with the uniform drawn on the GPU) against the CPU oracle on
-    `n_check` pairs of the batch, the first and the last (gate_pairs).
+    `n_check` pairs of the batch: the first, the middle one and the last (gate_pairs; round 6 -- rounds 1-5 checked
+    two).  The exact mode's leg stays at the first and the last.
 
     Flow, default mode (what is timed): EVERY pixel within TOL_REL * max(1, max|ref|) of the oracle.  (Rounds 2 and 3
     excused a few border pixels -- FarnebackUpdateMatrices' in-frame test is discontinuous in the flow and the kernels'
@@ -286,11 +287,11 @@ def parity_gate(job, n_check=2):
            "outliers_default": 0, "flow_pixels_differing": 0, "lanes_bit_identical": True,
            "outliers_exact": 0, "exact_max_abs_err": 0.0, "exact_bit_identical": True,
            "flow_ok": True, "remap_bit_exact": True,
-           "what": "the first and the last pair of the first batch (`pairs`: ticket lists 0 and 7 of the one-kernel iteration's "
-                   "launches) through the timed loop's own calls vs the CPU oracle.  flow_ok = NO pixel "
+           "what": "the first, the middle and the last pair of the first batch (`pairs`: ticket lists 0, 4 and 7 of the one-kernel "
+                   "iteration's launches) through the timed loop's own calls vs the CPU oracle.  flow_ok = NO pixel "
                    f"beyond {TOL_REL:g} * max(1, max|ref|) (outliers_default == 0; no allowance), the other lane's flow of "
-                   "the same pairs bit-identical to the first lane's, AND the same pairs in the handle's exact mode "
-                   "(tf_fb_set_exact: the window summed in OpenCV's own order) bit-identical to the oracle"}
+                   "the same pairs bit-identical to the first lane's, AND the first and the last of them (`exact_pairs`) in the "
+                   "handle's exact mode (tf_fb_set_exact: the window summed in OpenCV's own order) bit-identical to the oracle"}
     t_fb = t_rm = 0.0
     refs, firsts = [], []
     for i in idx:
@@ -329,18 +330,22 @@ def parity_gate(job, n_check=2):
     for j, i in enumerate(idx):
         rep["lanes_bit_identical"] = rep["lanes_bit_identical"] and bool(np.array_equal(job.fb.get_flow(i), firsts[j]))
     job.gate_flows = dict(zip(idx, firsts))      # pass 0, synchronised: what the timed region's re-check compares with
-    # the same pairs with the window summed in OpenCV's own order (the handle's mode, tf_fb_set_exact)
+    job.gate_oracle = {"flow_max_abs_err": rep["flow_max_abs_err"], "flow_tol": rep["flow_tol"],
+                       "flow_pixels_differing": rep["flow_pixels_differing"], "outliers": rep["outliers_default"]}
+    # the first and the last of them with the window summed in OpenCV's own order (the handle's mode, tf_fb_set_exact)
+    ex = sorted({0, n_check - 1})                # positions in idx / refs
+    rep["exact_pairs"] = [idx[j] for j in ex]
     job.fb.set_exact(True)
     try:
-        job.fb.calc_slots([prev[i] for i in idx], [nxt[i] for i in idx])
+        job.fb.calc_slots([prev[idx[j]] for j in ex], [nxt[idx[j]] for j in ex])
         job.sync()
-        for i in range(n_check):
-            got = job.fb.get_flow(i)
-            d = np.abs(got - refs[i]).max(axis=2)
-            tol = TOL_REL * max(1.0, float(np.abs(refs[i]).max()))
+        for k, j in enumerate(ex):
+            got = job.fb.get_flow(k)
+            d = np.abs(got - refs[j]).max(axis=2)
+            tol = TOL_REL * max(1.0, float(np.abs(refs[j]).max()))
             rep["outliers_exact"] += int((d > tol).sum())
             rep["exact_max_abs_err"] = max(rep["exact_max_abs_err"], float(d.max()))
-            rep["exact_bit_identical"] = rep["exact_bit_identical"] and bool(np.array_equal(got, refs[i]))
+            rep["exact_bit_identical"] = rep["exact_bit_identical"] and bool(np.array_equal(got, refs[j]))
     finally:
         job.fb.set_exact(None)
     # the pass's remap steps as ONE call (what the timed loop does on a BACKWARD workload) against the same steps one by one:
@@ -378,7 +383,8 @@ def timed_region_recheck(job, lanes):
     also with the flows the gate compared with the oracle.  No oracle work: a few milliseconds."""
     last = job.n_steps - 1
     which = last % len(job.passes)
-    idx = gate_pairs(job.batch)
+    gate = getattr(job, "gate_flows", None)
+    idx = sorted(gate) if gate else gate_pairs(job.batch, 3)      # the gate's own pairs (rank 0); the same rule elsewhere
     timed = [job.fb.get_flow(i) for i in idx]
     same = True
     for _ in range(max(1, lanes)):
@@ -389,9 +395,15 @@ def timed_region_recheck(job, lanes):
     out = {"step": last, "pass": which, "pairs": idx, "lanes_recomputed": max(1, lanes),
            "equals_synchronised_recomputation": bool(same),
            "what": "flows of the last step of the overlapped timed region vs the same pass computed alone on each lane"}
-    gate = getattr(job, "gate_flows", None)
     if which == 0 and gate is not None:
         out["equals_gate_flows"] = bool(all(np.array_equal(gate[i], t) for i, t in zip(idx, timed)))
+        if out["equals_gate_flows"]:
+            # the timed region's flows ARE the arrays the gate compared with the oracle: its verdict holds for them as it stands
+            out["vs_oracle"] = dict(getattr(job, "gate_oracle", {}),
+                                    what="the last timed step's flows of these pairs are bit for bit the arrays the parity gate "
+                                         "compared with the CPU oracle before the timed region: this is their distance from "
+                                         "the oracle (max |d|, the tolerance it was held to, pixels that differ at all, pixels "
+                                         "beyond the tolerance)")
     out["ok"] = bool(same and out.get("equals_gate_flows", True))
     return out
 
@@ -675,7 +687,7 @@ def flows_to_root_leg(job, host, rccl, plans):
             "clip_pairs": total_pairs, "gathers": len(calls), "bytes_into_root": into_root,
             "ms_passes_and_gathers": t_collect * 1e3, "ms_root_remap": (dt - t_collect) * 1e3, "ms": dt * 1e3,
             "frames_per_s": total_pairs / dt, "verified_flow_crc": bool(ok_flows), "verified_stream": bool(ok_stream),
-            "remap_out_of_frame": oob}
+            "remap_out_of_frame": oob, "ok": bool(ok_flows and ok_stream and not oob)}
 
 
 FLOWS_TO_ROOT_LEG = flows_to_root_leg
@@ -707,6 +719,88 @@ def run_with_timeout(fn, seconds):
 
 STUCK_THREADS = False
 EXIT_CODE = 0
+
+
+EXIT_NO_RCCL = 6
+
+
+def rccl_or_nothing(host, rank, wl, lib, check, timeout=None):
+    """The communicator and the shared inputs it brings from rank 0 (one-off broadcast, outside the timed region), or
+    nothing on EVERY rank when it did not come up on any one of them: (group, pixmap buffer, pixmap, reset mask, None) or
+    (None, None, None, None, the first rank's error).  A communicator that never comes up must not hang the run -- the
+    path itself needs no collective -- but the run is then not the one that was asked for: main() prints the line and
+    leaves with EXIT_NO_RCCL unless --allow-no-rccl was given."""
+    global STUCK_THREADS
+    from transflow_amd import batch as B
+    w, h = wl["w"], wl["h"]
+
+    def rccl_setup():
+        g = B.RcclGroup(host)
+        from transflow_amd.device import DevBuffer
+        pix_buf = DevBuffer(h * w * 3)
+        if rank == 0:
+            pix_buf.upload(np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8))
+        g.broadcast_dev(pix_buf.ptr, h * w * 3)
+        check(lib.tf_sync())
+        mask = None
+        if wl["reset"]:
+            m_buf = DevBuffer(h * w * 4)
+            if rank == 0:
+                m_buf.upload(np.random.default_rng(1238).random((h, w), dtype=np.float32))
+            g.broadcast_dev(m_buf.ptr, h * w * 4)
+            check(lib.tf_sync())
+            mask = m_buf.download((h, w), np.float32)
+            m_buf.close()
+        return g, pix_buf, pix_buf.download((h, w, 3), np.uint8), mask
+
+    rccl = pix_buf = pixmap = reset_mask = rccl_error = None
+    try:
+        if timeout is None:
+            timeout = float(os.environ.get("TF_BENCH_RCCL_TIMEOUT", 180))
+        rccl, pix_buf, pixmap, reset_mask = run_with_timeout(rccl_setup, timeout)
+    except BaseException as err:    # noqa: BLE001 -- say so loudly and carry on with inputs generated per rank
+        if isinstance(err, TimeoutError):
+            STUCK_THREADS = True
+        rccl_error = f"{type(err).__name__}: {err}"
+        print(f"[bench] rank {rank}: RCCL leg failed ({rccl_error}); shared inputs generated per rank instead",
+              file=sys.stderr)
+        rccl = pix_buf = pixmap = reset_mask = None
+    errs = host.allgather(rccl_error)
+    if any(errs):                             # all or nothing
+        if any("TimeoutError" in e for e in errs if e):
+            STUCK_THREADS = True              # a peer never answered: the communicator is abandoned, not destroyed
+            if rccl is not None:
+                rccl.abandon()
+        elif rccl is not None:
+            rccl.close()
+        rccl = pix_buf = pixmap = reset_mask = None
+    return rccl, pix_buf, pixmap, reset_mask, next((e for e in errs if e), None)
+
+
+def missing_rccl_exit_code(world, asked_for_rccl, rccl_ranks, allow_no_rccl):
+    """A run that was to use RCCL (more than one rank, or --rccl) and ended without a communicator of all its ranks has
+    measured something else than it was asked to: the line is still printed (rccl_ranks, rccl_error say what happened)
+    and the process leaves with EXIT_NO_RCCL, so that nobody mistakes the fallback for the result.  --allow-no-rccl
+    (rehearsals on a box with fewer GPUs than ranks) makes it 0 again."""
+    if (world > 1 or asked_for_rccl) and rccl_ranks != world and not allow_no_rccl:
+        return EXIT_NO_RCCL
+    return 0
+
+
+def step_counters(rf, workload, wl, pairs, steps_per_s):
+    """north_star's "rocprof HBM GB/s against the chip's peak" for the WHOLE step: the HBM-side bytes of one step by the
+    counters (every kernel of the step: profiles/r06_traffic_step.json, made by tools/traffic_step.py from separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at this pass size) times this run's steps per second."""
+    t = rf.profile_step_traffic(workload, wl["w"], wl["h"], wl["levels"], pairs)
+    if t is None:
+        return {"counter_bytes": None, "counter_GBs": None, "counter_frac": None,
+                "counter_source": "no counter table for this workload at this pass size under profiles/"}
+    gbs = t["bytes_per_step"] * steps_per_s / 1e9
+    return {"counter_bytes": t["bytes_per_step"], "counter_GBs": gbs, "counter_frac": gbs / rf.HBM_PEAK_GBS,
+            "counter_source": f"profile constant: HBM-side bytes of one step, all its kernels, by the counters ({t['table']}: "
+                              "2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same step at this pass "
+                              "size) x this run's steps per second; not a measurement of this run",
+            "counter_kernels_GB_per_step": t["kernels_GB_per_step"]}
 
 
 def level_fracs(rf, dominant, by_level, wl, pairs):
@@ -791,6 +885,11 @@ def main():
     ap.add_argument("--equal-batches", action="store_true",
                     help="trim every rank's pass to the shortest one (T=256 over 8 ranks: 31 pairs everywhere instead of 32 x 7 + 31)")
     ap.add_argument("--rccl", action="store_true", help="use the RCCL legs (broadcast, gather) even with one rank")
+    ap.add_argument("--allow-no-rccl", action="store_true",
+                    help="with --gpus N > 1 or --rccl: a run whose communicator did not come up on all N ranks still prints "
+                         "its line (rccl_ranks 0, rccl_error) but leaves with exit code 6 -- unless this flag says that the "
+                         "fallback (every rank makes the shared inputs itself, no gather legs) is what was wanted, e.g. ranks "
+                         "sharing one GPU in a rehearsal")
     ap.add_argument("--dry-run", action="store_true", help="ranks meet, shard the clip and report the plan; no GPU call")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="a run-time option of the library (tf_set_option; include/tfhip.h) for A/B runs; recorded in the JSON line")
@@ -819,6 +918,7 @@ def main():
             line.update({"rccl_ranks": None, "rccl_version": None, "per_rank_frames_per_s": None,
                          "parity_gate": "skipped (--dry-run)", "timed_region_recheck": None, "roofline": None, "cpu_baseline": None,
                          "kernels_ms_per_step": None, "remap_out_of_frame": None, "gather": None, "flows_to_root": None,
+                         "gather_verified_crc": None, "flows_to_root_ok": None, "untimed_steps_before_timed_region": None,
                          "dry_run": True, "clip_frames": args.clip_frames, "plans": plans})
             print(json.dumps(line))
         host.close()
@@ -840,54 +940,14 @@ def main():
         _lib.set_option(name, int(value))
         options[name] = int(value)
     rccl, rccl_error = None, None
-    pixmap = reset_mask = pixmap_dev = None
+    pixmap = reset_mask = pixmap_dev = pix_buf = None
     if world > 1 or args.rccl:
-        # shared inputs come from rank 0 over RCCL (one-off broadcast, outside the timed region)
-        from transflow_amd.device import DevBuffer
-
-        def rccl_setup():
-            g = B.RcclGroup(host)
-            pix_buf = DevBuffer(h * w * 3)
-            if rank == 0:
-                pix_buf.upload(np.random.default_rng(1237).integers(0, 256, (h, w, 3), dtype=np.uint8))
-            g.broadcast_dev(pix_buf.ptr, h * w * 3)
-            check(lib.tf_sync())
-            mask = None
-            if wl["reset"]:
-                m_buf = DevBuffer(h * w * 4)
-                if rank == 0:
-                    m_buf.upload(np.random.default_rng(1238).random((h, w), dtype=np.float32))
-                g.broadcast_dev(m_buf.ptr, h * w * 4)
-                check(lib.tf_sync())
-                mask = m_buf.download((h, w), np.float32)
-                m_buf.close()
-            return g, pix_buf, pix_buf.download((h, w, 3), np.uint8), mask
-
-        try:
-            # a communicator that never comes up must not hang the run: the path itself needs no collective
-            rccl, pix_buf, pixmap, reset_mask = run_with_timeout(rccl_setup, float(os.environ.get("TF_BENCH_RCCL_TIMEOUT", 180)))
-            pixmap_dev = pix_buf.ptr
-        except BaseException as err:    # say so loudly and carry on with inputs generated per rank
-            if isinstance(err, TimeoutError):
-                STUCK_THREADS = True
-            rccl_error = f"{type(err).__name__}: {err}"
-            print(f"[bench] rank {rank}: RCCL leg failed ({rccl_error}); shared inputs generated per rank instead",
-                  file=sys.stderr)
-            rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
-        errs = host.allgather(rccl_error)
-        if any(errs):                             # all or nothing
-            if any("TimeoutError" in e for e in errs if e):
-                STUCK_THREADS = True              # a peer never answered: the communicator is abandoned, not destroyed
-                if rccl is not None:
-                    rccl.abandon()
-            elif rccl is not None:
-                rccl.close()
-            rccl, pixmap, reset_mask, pixmap_dev = None, None, None, None
-        rccl_error = next((e for e in errs if e), None)
+        rccl, pix_buf, pixmap, reset_mask, rccl_error = rccl_or_nothing(host, rank, wl, lib, check)
+        pixmap_dev = pix_buf.ptr if pix_buf is not None else None
     lanes = args.lanes or pick_lanes(w, h, plan["pairs_per_pass"])     # this rank's
     job = Job(wl, args.batch, plan, args.clip_frames, seed=2000, device=device, pixmap=pixmap, reset_mask=reset_mask,
               pixmap_dev=pixmap_dev, lanes=lanes)
-    if pixmap_dev is not None:
+    if pix_buf is not None:
         job.pixmap_buffer = pix_buf     # the job gathers from this buffer: it lives as long as the job
 
     gate, gate_times = None, None
@@ -1014,7 +1074,10 @@ def main():
     step_built = rf.built_step_bytes(w, h, wl["levels"], P, reset_mask=wl["reset"], forward=wl["direction"] == 0)
     per_gpu_s = args.steps / elapsed
     out = line_skeleton(args, wl, world, plans)
-    out.update({"value": fps, "ms_per_step": elapsed / args.steps * 1e3, "burn_in_steps": burn_in_steps})
+    out.update({"value": fps, "ms_per_step": elapsed / args.steps * 1e3, "burn_in_steps": burn_in_steps,
+                # `warmup` is the W that was asked for; what ran in front of the timed region is this many untimed steps
+                # (about three seconds of passes for the clocks, then the W warm-up steps, the last of them profiled)
+                "untimed_steps_before_timed_region": burn_in_steps + n_warm})
     per_launch = built / max(1, dom_cnt)
     timed = {"launches": dom_cnt, "avg_launch_ms": avg_ms, "achieved": achieved, "frac": achieved / rf.HBM_PEAK_GBS}
     alone = None
@@ -1067,10 +1130,11 @@ def main():
                                          "bytes_per_launch": model / max(1, dom_cnt),
                                          "achieved": (model / max(1, dom_cnt)) / (own["avg_launch_ms"] * 1e-3) / 1e9 if own else None,
                                          "frac": (model / max(1, dom_cnt)) / (own["avg_launch_ms"] * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if own else None},
-                     "whole_step": {"built_bytes": step_built, "achieved": step_built * per_gpu_s / 1e9,
-                                    "frac": step_frac,
-                                    "model_bytes": step_model, "model_work_rate": step_model * per_gpu_s / 1e9,
-                                    "model_frac": step_model * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS}},
+                     "whole_step": dict({"built_bytes": step_built, "achieved": step_built * per_gpu_s / 1e9,
+                                         "frac": step_frac,
+                                         "model_bytes": step_model, "model_work_rate": step_model * per_gpu_s / 1e9,
+                                         "model_frac": step_model * per_gpu_s / 1e9 / rf.HBM_PEAK_GBS},
+                                        **step_counters(rf, args.workload, wl, P, per_gpu_s))},
         "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
         "remap_out_of_frame": any(oob),
     })
@@ -1082,6 +1146,9 @@ def main():
         out["gather"] = gather
     if flows_to_root is not None:
         out["flows_to_root"] = flows_to_root
+    # the multi-GPU legs' verdicts where nobody can miss them (null: the leg did not run)
+    out["gather_verified_crc"] = gather.get("verified_crc") if isinstance(gather, dict) else None
+    out["flows_to_root_ok"] = flows_to_root.get("ok") if isinstance(flows_to_root, dict) else None
     leg_limit = float(os.environ.get("TF_BENCH_LEG_TIMEOUT", 240))
     if not args.no_cpu_baseline and gate_times is not None:      # rank 0, at every N (the other ranks are done)
         try:
@@ -1160,6 +1227,12 @@ def main():
     if out["roofline"].get("exceeds_copy_ceiling"):
         print("[bench] roofline.achieved exceeds the copy ceiling measured in this run: check the byte model", file=sys.stderr)
         EXIT_CODE = 5
+    no_rccl = missing_rccl_exit_code(world, args.rccl, out["rccl_ranks"], args.allow_no_rccl)
+    if no_rccl:
+        print(f"[bench] this run was to use RCCL on {world} rank(s) and had {out['rccl_ranks']}: the line above is the fallback's "
+              f"(every rank made the shared inputs itself, no gather legs), exit code {no_rccl}; --allow-no-rccl accepts it",
+              file=sys.stderr)
+        EXIT_CODE = no_rccl
 
 
 def run_as_main():

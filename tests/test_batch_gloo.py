@@ -413,3 +413,84 @@ def test_host_group_survives_a_stale_rendezvous_file(tmp_path):
     assert box["r0"] == 3.0
     g0.close()
     g1.close()
+
+
+NO_RCCL_WORKER = """
+import json, os, sys, types
+sys.path.insert(0, %r)
+import numpy as np
+import bench
+from transflow_amd import batch as B
+import transflow_amd.device as D
+
+rank, _, world = B.env_world()
+
+class FakeGroup:                      # stands in for B.RcclGroup: comes up on rank 0, raises on rank 1
+    closed = False
+    def __init__(self, host):
+        if host.rank == 1:
+            raise RuntimeError("stub: ncclCommInitRank refused (two ranks on one device)")
+    def broadcast_dev(self, ptr, n):
+        pass
+    def close(self):
+        FakeGroup.closed = True
+    def abandon(self):
+        FakeGroup.closed = True
+
+class FakeBuffer:                     # stands in for transflow_amd.device.DevBuffer: no GPU in this test
+    ptr = 4096
+    def __init__(self, n):
+        self.n = n
+    def upload(self, a):
+        self.a = a
+    def download(self, shape, dtype):
+        return np.zeros(shape, dtype)
+    def close(self):
+        pass
+
+B.RcclGroup = FakeGroup
+D.DevBuffer = FakeBuffer
+lib = types.SimpleNamespace(tf_sync=lambda: 0)
+host = B.HostGroup(rank, world)
+wl = dict(bench.WORKLOADS["4k"], w=64, h=48)
+got = bench.rccl_or_nothing(host, rank, wl, lib, lambda rc: None, timeout=30)
+res = {"rank": rank, "all_none": all(v is None for v in got[:4]), "error": got[4], "closed": FakeGroup.closed,
+       "code": bench.missing_rccl_exit_code(world, False, 0 if got[0] is None else world, False),
+       "code_allowed": bench.missing_rccl_exit_code(world, False, 0 if got[0] is None else world, True)}
+print("RESULT " + json.dumps(res), flush=True)
+host.close()
+"""
+
+
+def test_a_communicator_that_fails_on_one_rank_is_dropped_on_all_and_costs_the_exit_code(tmp_path):
+    """SURVEY 8e / BASELINE configs[4]: `bench.py --gpus N` whose RCCL communicator does not come up still measures
+    (the path needs no collective) and prints its line, but it is not the run that was asked for: all or nothing --
+    the rank whose communicator DID come up closes it -- and exit code 6 unless --allow-no-rccl.  RcclGroup and the
+    device buffer are stand-ins here (no GPU); the real thing runs in tests/test_gpu_batch.py."""
+    script = tmp_path / "worker.py"
+    script.write_text(NO_RCCL_WORKER % ROOT)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", TF_BATCH_RDZV=str(tmp_path / "rdzv"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    results = {}
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        r = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:])
+        results[r["rank"]] = r
+    for r in (0, 1):
+        assert results[r]["all_none"] and "ncclCommInitRank refused" in results[r]["error"]
+        assert results[r]["code"] == 6 and results[r]["code_allowed"] == 0
+    assert results[0]["closed"] and not results[1]["closed"]      # rank 0 had a communicator and gave it up
+
+
+def test_missing_rccl_exit_code_rules():
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.missing_rccl_exit_code
+    assert f(1, False, 0, False) == 0                       # one rank, no --rccl: nothing was asked for
+    assert f(1, True, 1, False) == 0 and f(1, True, 0, False) == 6 and f(1, True, 0, True) == 0
+    assert f(8, False, 8, False) == 0 and f(8, False, 0, False) == 6 and f(8, False, 0, True) == 0
+    assert bench.EXIT_NO_RCCL == 6

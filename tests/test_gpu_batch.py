@@ -187,6 +187,18 @@ def test_bench_with_three_ranks_sharing_the_one_gpu():
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert lines, out.stderr[-3000:]
     d = json.loads(lines[-1])
+    # round 6: a multi-rank run without its communicator still prints the line, and leaves with exit code 6 so that the
+    # fallback cannot be mistaken for the result (--allow-no-rccl, the rehearsal's flag, makes it 0: second run below)
+    assert out.returncode == (6 if d["rccl_ranks"] == 0 else 0), (out.returncode, out.stderr[-2000:])
+    assert d["gather_verified_crc"] is None and d["flows_to_root_ok"] is None or d["rccl_ranks"] == 3
+    assert d["untimed_steps_before_timed_region"] == d["burn_in_steps"] + 1
+    if d["rccl_ranks"] == 0:
+        assert "exit code 6" in out.stderr
+        again = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--size", "640x360",
+                                "--clip-frames", "40", "--batch", "7", "--steps", "2", "--warmup", "1", "--no-extra",
+                                "--no-cpu-baseline", "--no-gate", "--burn-in", "0", "--allow-no-rccl"],
+                               env=env, capture_output=True, text=True, timeout=900)
+        assert again.returncode == 0, again.stderr[-2000:]
     assert d["n_gpus"] == 3 and d["config"]["pairs_per_rank"] == [13, 13, 13]
     assert d["config"]["frame_pairs_per_step_per_gpu"] == [7, 7, 7] and d["config"]["frame_pairs_per_step"] == 21
     assert len(d["per_rank_frames_per_s"]) == 3 and all(v > 0 for v in d["per_rank_frames_per_s"])

@@ -9,12 +9,17 @@ out=../../build_abl
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result -DTF_EXPERIMENT"
 mkdir -p $out/_common $out/$name
 COMMON="runtime remap remap_step flowops batch"
+pids=""
 for f in $COMMON; do
-  if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ] || [ remap_common.h -nt $out/_common/$f.o ]; then $CC -c $f.hip -o $out/_common/$f.o & fi
+  if [ ! -f $out/_common/$f.o ] || [ $f.hip -nt $out/_common/$f.o ] || [ common.h -nt $out/_common/$f.o ] || [ remap_common.h -nt $out/_common/$f.o ]; then
+    rm -f $out/_common/$f.o; $CC -c $f.hip -o $out/_common/$f.o & pids="$pids $!"
+  fi
 done
 FB="farneback fb_level_image fb_pyramid fb_matrices fb_iterate fb_exact fb_postprocess fb_stages"
-for f in $FB; do $CC "$@" -c $f.hip -o $out/$name/$f.o & done
-wait
+# a unit that fails to compile must fail the build: old objects go first, and every job is waited for by pid
+# (a bare `wait` returns 0 whatever the jobs did)
+for f in $FB; do rm -f $out/$name/$f.o; $CC "$@" -c $f.hip -o $out/$name/$f.o & pids="$pids $!"; done
+for p in $pids; do wait $p || { echo "build_fb_variant: a compile job failed" >&2; exit 1; }; done
 objs=""; for f in $FB; do objs="$objs $out/$name/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libtfhip_$name.so $(for f in $COMMON; do echo $out/_common/$f.o; done) $objs -ldl
 echo built $out/libtfhip_$name.so

@@ -224,3 +224,21 @@ def profile_traffic(name, width, height, levels, pairs, launches_per_step, itera
         entry = batched
     total = entry["bytes_per_px"] * sum(n) * pairs * images * per_level_launches
     return total / max(1.0, launches_per_step)
+
+
+def profile_step_traffic(workload, width, height, levels, pairs):
+    """HBM bytes of one whole step by the counters (profiles/r06_traffic_step.json: tools/traffic_step.py over separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at the bench's own pass size), with the per-kernel table's path -- or
+    None when the table was made for another workload or another number of pairs per pass (no scaling: a step's
+    traffic depends on which levels fill the chip and on what consecutive pairs share in L2).  A PROFILE CONSTANT."""
+    for fname in ("r06_traffic_step.json",):
+        path = os.path.join(_ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            t = json.load(f)
+        if (t.get("width"), t.get("height"), t.get("levels"), t.get("pairs")) == (width, height, levels, pairs) \
+                and t.get("workload") == workload:
+            return {"bytes_per_step": t["bytes_per_step"], "table": "profiles/" + fname,
+                    "kernels_GB_per_step": {k: round(v["bytes_per_step"] / 1e9, 4) for k, v in t["kernels"].items()}}
+    return None
