@@ -127,6 +127,11 @@ int tf_dev_free(void *dev);
 int tf_dev_upload(void *dev, const void *host, size_t bytes);
 int tf_dev_download(void *host, const void *dev, size_t bytes);
 int tf_dev_copy(void *dst_dev, const void *src_dev, size_t bytes); /* device to device, on the library stream */
+/* One 64-bit word stored at `dev` (8-byte aligned) in stream order on the calling thread's library stream: the
+   generation word at the head of a flow buffer that crosses the reference's queue as an IPC token
+   (transflow/pipeline.py:85-86, 326) -- bumped before the buffer is written again, compared by the consumer after
+   its copy, so that a buffer rewritten too early raises instead of passing for the flow it no longer holds. */
+int tf_dev_store_u64(void *dev, uint64_t value);
 /* The same as one kernel, 16 bytes per lane: bench.py measures the practical HBM ceiling with it. */
 int tf_dev_stream_copy(void *dst_dev, const void *src_dev, size_t bytes);
 
@@ -457,6 +462,13 @@ int tf_comp_create_on(tf_comp **out, int height, int width, const uint8_t backgr
 void tf_comp_destroy(tf_comp *comp);
 int tf_comp_begin(tf_comp *comp);                      /* image = background.copy() (:35) */
 int tf_comp_download(tf_comp *comp, uint8_t *rgb_out); /* uint8 [H][W][3] (:40) */
+/* The same download beside whatever the caller queues next (pipeline.py:518 hands the frame to the outputs' queue,
+   pipeline.py:565 goes on to the next update; output/ffmpeg.py:32-54 writes it to the encoder's pipe): the copy starts
+   when the caller's stream reaches this point, on the library's download stream; tf_comp_download_end returns once
+   rgb_out (page-locked: tf_host_alloc) is filled.  The image must not be written again before _end: a caller that
+   wants frame t on its way down while it renders frame t + 1 alternates two images.  _end without _begin: no-op. */
+int tf_comp_download_begin(tf_comp *comp, uint8_t *rgb_out);
+int tf_comp_download_end(tf_comp *comp);
 int tf_comp_image_ptr(tf_comp *comp, void **dev);
 
 /* ---- batch-of-frames mode over the GPUs of one node ----------------------

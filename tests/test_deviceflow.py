@@ -67,27 +67,87 @@ def test_through_a_multiprocessing_pickler_without_ipc_it_is_the_array_too():
     assert type(back) is np.ndarray
 
 
-def test_a_buffer_that_left_as_an_ipc_token_stays_out_of_rotation(monkeypatch):
-    """A flow that crosses a multiprocessing queue as an IPC handle is garbage in the producer as soon as it is pickled;
-    the other process reads the buffer later, inside its queue.get().  The ring must not hand that buffer out again until
-    EXPORT_HOLD more flows have left the same way (CPU: the device buffers and events are stood in for)."""
+@pytest.fixture()
+def cpu_ring(monkeypatch):
+    """FlowRing on the CPU: the device buffer, the events and tf_dev_store_u64 are stood in for; the generation words a
+    ring stores are recorded in `stores` as (buffer address, generation)."""
+    import types
+
     from transflow_amd import deviceflow as DF
+    stores = []
 
     class Slot:
+        count = 0
+
         def __init__(self, nbytes, index):
-            self.index, self.used, self.exported_at, self.ipc_handle = index, None, None, None
+            Slot.count += 1
+            self.buf = types.SimpleNamespace(ptr=0x1000 * Slot.count)
+            self.flow_ptr = self.buf.ptr + DF.HEADER
+            self.index, self.used, self.ipc_handle, self.ready = index, None, None, None
+            self.generation, self.exported_gen = 0, None
+
+    stub = types.SimpleNamespace(tf_dev_store_u64=lambda p, v: stores.append((p.value, int(v))) or 0)
     monkeypatch.setattr(DF, "_Slot", Slot)
+    monkeypatch.setattr(DF, "_lib", types.SimpleNamespace(load=lambda: stub))
+    monkeypatch.setattr(DF, "check", lambda rc: None)
+    return DF, stores
+
+
+def test_a_buffer_that_left_as_an_ipc_token_stays_out_of_rotation_until_it_is_acknowledged(cpu_ring):
+    """A flow that crosses a multiprocessing queue as an IPC handle is garbage in the producer as soon as it is pickled;
+    the other process reads the buffer later, inside its queue.get().  The ring does not hand that buffer out again
+    until the consumer has acknowledged the generation that left (rounds 1-5: until eight more exports had happened --
+    an assumption about the queue's depth); it grows meanwhile.  Every hand-out starts a new generation, stored on the
+    device before anything else is queued for the buffer."""
+    DF, stores = cpu_ring
     ring = DF.FlowRing((4, 5, 2), slots=4)
     a = ring.take()
+    assert (a.generation, stores) == (1, [(a.buf.ptr, 1)])
     ring.give_back(a)
-    assert ring.take() is a                       # an ordinary buffer: back at once
-    ring.exported(a)                              # a flow in it left as a token ...
-    ring.give_back(a)                             # ... and was dropped by the producer
-    seen = []
-    for _ in range(DF.FlowRing.EXPORT_HOLD - 1):
+    assert ring.take() is a and a.generation == 2          # an ordinary buffer: back at once, in a new generation
+    gen, board = ring.exported(a)                          # a flow in it leaves as a token ...
+    assert gen == 2 and board and ring.unacknowledged() == [a.index]
+    ring.give_back(a)                                      # ... and is dropped by the producer
+    others = []
+    for _ in range(12):                                    # however many flows follow: not this buffer
         s = ring.take()
         assert s is not a
-        seen.append(s)
-        ring.exported(s)
+        others.append(s)
+    for s in others:
         ring.give_back(s)
-    assert ring.take() is a                       # EXPORT_HOLD exports later it is in rotation again
+    assert not ring.drain(timeout=0.05)                    # the producer may not let go yet
+    DF._acknowledge(board, a.index, 1)                     # an older generation's acknowledgement does not count
+    assert ring.unacknowledged() == [a.index]
+    DF._acknowledge(board, a.index, gen)                   # the consumer has copied it
+    assert ring.unacknowledged() == [] and ring.drain(timeout=0.05)
+    assert ring.take() is a and a.generation == 3 and stores[-1] == (a.buf.ptr, 3)
+    # the test switch: a ring told not to wait hands the buffer out again at once (tests/test_gpu_a_forked_pipeline.py
+    # uses it to overrun a consumer on purpose)
+    fast = DF.FlowRing((4, 5, 2), slots=2, wait_for_acks=False)
+    b = fast.take()
+    fast.exported(b)
+    fast.give_back(b)
+    assert fast.take() is b
+    DF._acknowledge("/nonexistent/tfhip-ack", 0, 1)        # a board that is gone is not an error
+    DF._acknowledge(board, DF._AckBoard.WORDS + 3, 1)      # nor is a buffer beyond the board
+
+
+def test_drain_waits_for_flows_on_their_way_into_a_token(cpu_ring):
+    """multiprocessing pickles in a feeder thread, after put() has returned: a flow of the "ipc" kind counts as on its
+    way from its creation until it has been exported, read on the host, or dropped."""
+    DF, _ = cpu_ring
+    ring = DF.FlowRing((4, 5, 2), slots=2)
+    s = ring.take()
+    f = DF.DeviceFlow((4, 5, 2), s.flow_ptr, None, ring=ring, slot=s, cross_process="ipc")
+    assert ring._in_transit == 1 and not ring.drain(timeout=0.02)
+    f._left_transit()                                      # what the queue's reducer does once the token is made
+    assert ring._in_transit == 0
+    f._left_transit()                                      # idempotent
+    assert ring._in_transit == 0 and ring.drain(timeout=0.02)
+    g = DF.DeviceFlow((4, 5, 2), s.flow_ptr, None, ring=ring, slot=s, cross_process="ipc")
+    assert ring._in_transit == 1
+    del g                                                  # a flow nobody sent anywhere
+    assert ring._in_transit == 0
+    h = DF.DeviceFlow((4, 5, 2), s.flow_ptr, None, ring=ring, slot=s)      # in-process flows never count
+    assert ring._in_transit == 0
+    del h, f

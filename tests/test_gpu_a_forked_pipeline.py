@@ -26,7 +26,36 @@ def _child_flow_process(frames, queue, meta, device_flows=None):
         queue.put(err)
 
 
-def test_forked_flow_process_and_main_compositor():
+@pytest.fixture(scope="module")
+def forked():
+    """Every child process of this file, forked BEFORE this process touches the GPU (HIP cannot be used in a child
+    forked after the parent initialised it): the two flow processes of the first test and the two hand-made producers
+    of the second.  They fill their queues and wait there until their test reads them."""
+    import multiprocessing as mp
+
+    from transflow_amd import _lib
+    if _lib.load().tf_is_initialized():
+        pytest.skip("this process already initialised HIP; a forked child could not use the GPU")
+    h, w = 96, 128
+    frames = _frames(h, w, 5, seed=33)
+    ctx = mp.get_context("fork")
+    out = {"frames": frames, "h": h, "w": w}
+    out["queue"], out["meta"] = ctx.Queue(maxsize=1), ctx.Queue()
+    out["child"] = ctx.Process(target=_child_flow_process, args=(frames, out["queue"], out["meta"]))
+    out["queue2"], out["meta2"] = ctx.Queue(maxsize=1), ctx.Queue()
+    out["child2"] = ctx.Process(target=_child_flow_process, args=(frames, out["queue2"], out["meta2"], "ipc"))
+    for tag, overrun in (("bad", True), ("good", False)):
+        q, r, go = ctx.Queue(), ctx.Queue(), ctx.Event()
+        out[tag] = (ctx.Process(target=_child_ring_producer, args=(q, r, go, overrun)), q, r, go)
+    for proc in (out["child"], out["child2"], out["bad"][0], out["good"][0]):
+        proc.start()
+    yield out
+    for proc in (out["child"], out["child2"], out["bad"][0], out["good"][0]):
+        if proc.is_alive():
+            proc.terminate()
+
+
+def test_forked_flow_process_and_main_compositor(forked):
     """The reference's process layout: the flow source lives in a forked child (its own HIP
     context, created after the fork), flows cross a multiprocessing.Queue(maxsize=1) as pickled
     numpy arrays (pipeline.py:326-328), the compositor runs in the parent.
@@ -34,24 +63,14 @@ def test_forked_flow_process_and_main_compositor():
     (transflow_amd/deviceflow.py), the parent's compositor reads the flows in HBM -- same frames bit for bit, same flows
     when brought down, and a pickled checkpoint of such a flow holds the host array, never a device address.  Both
     children are forked before this process touches the GPU."""
-    import multiprocessing as mp
     import pickle
 
-    from transflow_amd import _lib
-    if _lib.load().tf_is_initialized():
-        pytest.skip("this process already initialised HIP; a forked child could not use the GPU")
     from transflow_amd.compositor import HipCompositor
     from transflow_amd.config import LayerConfig
     from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
-    h, w = 96, 128
-    frames = _frames(h, w, 5, seed=33)
-    ctx = mp.get_context("fork")
-    queue, meta = ctx.Queue(maxsize=1), ctx.Queue()
-    child = ctx.Process(target=_child_flow_process, args=(frames, queue, meta))
-    child.start()            # forked BEFORE this process touches the GPU in this test's objects
-    queue2, meta2 = ctx.Queue(maxsize=1), ctx.Queue()
-    child2 = ctx.Process(target=_child_flow_process, args=(frames, queue2, meta2, "ipc"))
-    child2.start()           # (it fills its queue and waits there until the first run is over)
+    h, w, frames = forked["h"], forked["w"], forked["frames"]
+    queue, meta, child = forked["queue"], forked["meta"], forked["child"]
+    queue2, meta2, child2 = forked["queue2"], forked["meta2"], forked["child2"]   # (fills its queue and waits there)
     assert meta.get(timeout=120) == (w, h, 25.0, 4)
     pixmap = np.random.default_rng(4).integers(0, 256, (h, w, 3), dtype=np.uint8)
     comp = HipCompositor.from_args(h, w, [LayerConfig(0)], "#000000")
@@ -100,3 +119,96 @@ def test_forked_flow_process_and_main_compositor():
             np.testing.assert_array_equal(flow_child, flow)
             comp2.update(flow)
             np.testing.assert_array_equal(frame_child, comp2.render())
+
+
+def _child_ring_producer(queue, report, go, overrun):
+    """A producer process that makes flows by hand in a FlowRing of two buffers and sends them as IPC tokens.
+    overrun = True: the ring is told not to wait for acknowledgements (the test switch) and writes buffer 0 again while
+    its first token is still in the queue.  overrun = False: the ordinary ring; the producer sends its last flow, drains
+    and ENDS while the consumer has not looked at the queue yet."""
+    import ctypes as C
+    import time
+
+    from transflow_amd import _lib, deviceflow as DF
+    try:
+        lib = _lib.load()
+        _lib.check(lib.tf_init(0))
+        shape = (24, 40, 2)
+        ring = DF.FlowRing(shape, slots=2, wait_for_acks=not overrun)
+
+        def make(value):
+            slot = ring.take()
+            a = np.full(shape, value, np.float32)
+            _lib.check(lib.tf_dev_upload(C.c_void_p(slot.flow_ptr), C.c_void_p(a.ctypes.data), a.nbytes))
+            slot.ready.record()
+            return DF.DeviceFlow(shape, slot.flow_ptr, slot.ready, ring=ring, slot=slot, cross_process="ipc"), slot.index
+
+        indices = []
+        flow, i = make(1.0)
+        indices.append(i)
+        queue.put(flow)
+        del flow
+        t0 = time.monotonic()
+        while ring.exports < 1 and time.monotonic() - t0 < 30:       # the feeder thread has made the token
+            time.sleep(0.001)
+        for v in (2.0, 3.0):                                           # more flows while the first token waits in the queue
+            flow, i = make(v)
+            indices.append(i)
+            _lib.check(lib.tf_sync())
+            del flow
+        report.put(("indices", indices, ring.unacknowledged()))
+        if overrun:
+            go.wait(900)                                               # the consumer reads the (stale) token now
+            report.put(("drained", ring.drain(timeout=20.0)))
+        else:
+            flow, i = make(4.0)
+            queue.put(flow)
+            del flow
+            report.put(("drained", ring.drain(timeout=900.0)))         # returns only once BOTH tokens were copied
+        queue.put(None)
+    except Exception as err:      # surfaces in the parent instead of hanging it
+        report.put(("error", repr(err)))
+        queue.put(err)
+
+
+def test_ipc_tokens_are_acknowledged_and_an_overrun_raises_instead_of_passing_a_wrong_flow(forked):
+    """transflow_amd/deviceflow.py's two guards for a flow that crosses the reference's queue (pipeline.py:85-86, 326) as
+    an IPC token.  (1) A producer that overruns its consumer -- forced here with the ring's test switch: buffer 0 is
+    written again while its first token still waits in the queue -- makes the consumer's queue.get() raise a RuntimeError
+    that names the buffer, not hand out the newer flow under the older one's name.  (2) The ordinary ring never does
+    that: with the first token unacknowledged it takes other buffers, and its drain() -- what HipFlowSource.close() runs
+    before the producer lets go -- returns only after the consumer, which looks at the queue a second late, has copied
+    both flows out intact (multiprocessing's Queue.get() frees the queue's slot before it unpickles, so without the
+    wait the producer could end first)."""
+    import time
+
+    from transflow_amd.deviceflow import DeviceFlow
+    bad, q1, r1, go1 = forked["bad"]
+    good, q2, r2, go2 = forked["good"]
+    # (1) the overrun
+    kind, indices, pending = r1.get(timeout=120)
+    assert kind == "indices", indices
+    assert indices[0] == 0 and 0 in indices[1:], indices          # buffer 0 was handed out again, unacknowledged
+    with pytest.raises(RuntimeError, match=r"device flow buffer 0 of process \d+ was written again"):
+        q1.get(timeout=120)
+    go1.set()
+    assert r1.get(timeout=120) == ("drained", True)               # the failed read still acknowledged: nobody waits for it
+    assert q1.get(timeout=120) is None
+    bad.join(timeout=60)
+    assert bad.exitcode == 0
+    # (2) the ordinary ring, and a consumer that comes late
+    kind, indices, pending = r2.get(timeout=120)
+    assert kind == "indices", indices
+    assert indices[0] == 0 and 0 not in indices[1:] and pending == [0], (indices, pending)
+    time.sleep(0.5)                                               # the producer sent its last flow long ago and sits in drain()
+    assert good.is_alive()
+    first = q2.get(timeout=120)
+    second = q2.get(timeout=120)
+    for flow, value in ((first, 1.0), (second, 4.0)):
+        assert isinstance(flow, DeviceFlow) and flow._host is None
+        a = np.asarray(flow)
+        assert a.shape == (24, 40, 2) and float(a.min()) == float(a.max()) == value
+    assert r2.get(timeout=120) == ("drained", True)
+    assert q2.get(timeout=120) is None
+    good.join(timeout=60)
+    assert good.exitcode == 0

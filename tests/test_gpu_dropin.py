@@ -560,3 +560,74 @@ def test_two_sources_of_one_process_disagree_about_exactness(lib_option):
         walkers = sum(n for name, (n, _) in rep.items() if name.startswith("fb_exact_hsolve"))
         assert walkers == 6 * 4 * 3, rep                    # levels=3: four scales, three iterations, six flows
         assert any(name.startswith(("fb_flow_iter", "fb_blur_solve")) for name in rep), rep   # the default source's
+
+
+def test_lazy_frames_are_the_frames_of_the_synchronous_path():
+    """HipCompositor(..., lazy_frames=True): render() returns a DeviceFrame (transflow_amd/deviceframe.py) whose download
+    is under way -- frame t comes down (pipeline.py:518, output/ffmpeg.py:32-54) beside frame t + 1's uploads and
+    kernels (pipeline.py:565).  The frames are those of the synchronous path bit for bit, whether they are read at once,
+    one frame late (an output thread), or all at the end (more frames held than the compositor has images: the pool's
+    arrays are never handed out twice); an ordinary pickle is the host array; a compositor pickled with lazy frames
+    comes back with them; multi-layer compositors and host-array flows work the same."""
+    import pickle
+
+    from transflow_amd.compositor import HipCompositor
+    from transflow_amd.config import FlowConfig, LayerConfig
+    from transflow_amd.deviceframe import DeviceFrame
+    from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
+    h, w = 120, 168
+    frames = _bgr_frames(h, w, 10)
+    pix = [np.random.default_rng(80 + i).integers(0, 256, (h, w, 3), dtype=np.uint8) for i in range(3)]
+
+    class Src:
+        introduction_mask = np.ones((h, w), bool)
+
+        def __init__(self):
+            self.n = 0
+
+        def next(self, timeout=1):
+            self.n += 1
+            return pix[self.n % 3]
+
+    def run(lazy, cfg, read, layers=1):
+        comp = HipCompositor.from_args(h, w, [LayerConfig(i, reset_mode="random", reset_random_factor=0.05) for i in range(layers)],
+                                       rng="device", lazy_frames=lazy)
+        comp.set_sources({i: [Src()] for i in range(layers)})
+        out, held = [], []
+        with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
+            for t, flow in enumerate(source):
+                comp.update(flow)
+                frame = comp.render()
+                if lazy:
+                    assert isinstance(frame, DeviceFrame) and frame.shape == (h, w, 3) and frame.dtype == np.uint8
+                if read == "at once":
+                    out.append(np.array(frame))
+                elif read == "one late":
+                    if held:
+                        out.append(np.array(held.pop()))
+                    held.append(frame)
+                else:
+                    held.append(frame)
+                if t == 4 and lazy:
+                    again = pickle.loads(pickle.dumps(comp))
+                    assert again.lazy_frames and again._comp is None and again._comp2 is None
+        out.extend(np.array(f) for f in held)
+        if lazy and read == "at the end":
+            assert sum(f.arrived for f in held) == len(held)
+            back = pickle.loads(pickle.dumps(held[2]))
+            assert type(back) is np.ndarray
+            np.testing.assert_array_equal(back, out[2])
+            held[3][0, 0] = (1, 2, 3)                                    # once down it is an ordinary writable array
+            assert tuple(np.asarray(held[3])[0, 0]) == (1, 2, 3) and held[3].tobytes()[:3] == bytes([1, 2, 3])
+            assert int((held[5] // 2).max()) <= 127 and held[5].mean() > 0
+        comp.close()
+        return out
+
+    for cfg, layers in ((None, 1), (FlowConfig(hip_device_flows=True, hip_prefetch=2), 1), (FlowConfig(hip_device_flows=True), 2)):
+        plain = run(False, cfg, "at once", layers)
+        assert len(plain) == 9
+        for read in ("at once", "one late", "at the end"):
+            got = run(True, cfg, read, layers)
+            assert len(got) == len(plain)
+            for t, (a, b) in enumerate(zip(plain, got)):
+                np.testing.assert_array_equal(a, b, err_msg=f"{read}, frame {t}, layers {layers}")

@@ -514,6 +514,18 @@ def test_steps_call_equals_the_single_steps(tf, lib_option, case, keep):
     np.testing.assert_array_equal(many.get_state()[1], one.get_state()[1])
     with pytest.raises(ValueError):
         many.steps_dev(compn[:2], [fbuf[0].ptr], [pbuf[0].ptr, pbuf[1].ptr], ch)
+    # a step whose arguments are bad is refused BEFORE the first step runs: an error once rgba stores have been left
+    # out would leave the layer's state ahead of its rgba (round 6; a compositor image of another size in step 1)
+    before = many.get_state()
+    other = remap.CompImage(h + 1, w, (9, 9, 9))
+    with pytest.raises(ValueError):
+        many.steps_dev([compn[0], other], [fbuf[0].ptr, fbuf[1].ptr], [pbuf[0].ptr, pbuf[1].ptr], ch, seed=77)
+    with pytest.raises(ValueError):
+        many.steps_dev(compn[:2], [fbuf[0].ptr, 0], [pbuf[0].ptr, pbuf[1].ptr], ch, seed=77)
+    after = many.get_state()
+    np.testing.assert_array_equal(after[0], before[0])
+    np.testing.assert_array_equal(after[1], before[1])
+    other.close()
 
 
 def test_flow_presteps_golden_gpu(tf):

@@ -10,7 +10,10 @@ what the reference's child process + queue give it, pipeline.py:56-64): flow t +
 works on flow t.
 `device` (FlowConfig.hip_device_flows): the flows stay in HBM between the source and the compositor (DeviceFlow) -- the
 frame still goes up and the rendered frame still comes down, the 66 MB per 4K flow no longer travel at all.
-Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch] [device] [batch=n] [reps=r]"""
+`frame` (HipCompositor lazy_frames): render() returns a DeviceFrame whose download is under way; the loop reads frame
+t - 1 (as the reference's output process would, behind its queue) after it has issued frame t, so a frame's 25 MB come
+down beside the next frame's uploads.
+Usage on the GPU box:  python tools/bench_host_path.py [1080p|4k] [frames] [bgr|grey] [exact] [prefetch] [device] [frame] [batch=n] [reps=r]"""
 import os
 import sys
 import time
@@ -32,6 +35,7 @@ kind = sys.argv[3] if len(sys.argv) > 3 else "bgr"
 exact = "exact" in sys.argv[4:]          # flows bit-identical to the CPU path's (option fb_exact_sums)
 prefetch = "prefetch" in sys.argv[4:]
 device = "device" in sys.argv[4:]
+lazy = "frame" in sys.argv[4:]
 if "nobeside" in sys.argv[4:]:        # A/B: the pixmap's upload on the caller's stream even behind a device-flow update
     from transflow_amd import remap as _remap
     _g = _remap.RemapLayer.gather
@@ -53,7 +57,7 @@ class Src:
         return pix
 
 
-comp = HipCompositor.from_args(h, w, [LayerConfig(0)])
+comp = HipCompositor.from_args(h, w, [LayerConfig(0)], lazy_frames=lazy)
 comp.set_sources({0: [Src()]})
 t_flow = t_comp = 0.0
 cfg = None
@@ -67,7 +71,7 @@ with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backwa
         flow = next(it)
         comp.update(flow)
         comp.render()
-    k = 0
+    k, img = 0, None
     while True:
         t0 = time.perf_counter()
         try:
@@ -76,10 +80,12 @@ with HipFlowSource.from_args(ArrayFrameProvider(frames, 30.0), direction="backwa
             break
         t1 = time.perf_counter()
         comp.update(flow)
-        img = comp.render()
+        img, before = comp.render(), (img if k else None)
+        if lazy and before is not None:
+            checksum = int(np.asarray(before)[0, 0, 0])      # the frame before this one: in host memory now (waits if not)
         t2 = time.perf_counter()
         t_flow += t1 - t0
         t_comp += t2 - t1
         k += 1
-print(f"{name} ({kind} frames in{', exact sums' if exact else ''}{', flow source prefetching' if prefetch else ''}{', flows stay on the device' if device else ''}{f', {batch} pairs per call' if batch > 1 else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
+print(f"{name} ({kind} frames in{', exact sums' if exact else ''}{', flow source prefetching' if prefetch else ''}{', flows stay on the device' if device else ''}{', frames read one late (lazy)' if lazy else ''}{f', {batch} pairs per call' if batch > 1 else ''}): {k} frames; flow source {t_flow / k * 1e3:.1f} ms/frame, compositor {t_comp / k * 1e3:.1f} ms/frame, "
       f"{k / (t_flow + t_comp):.1f} frames/s end to end {'(frames in, frames out)' if device else 'through host arrays'} (one process)")

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "tf_dev_upload": (_I, [_P, _P, C.c_size_t]),
     "tf_dev_download": (_I, [_P, _P, C.c_size_t]),
     "tf_dev_copy": (_I, [_P, _P, C.c_size_t]),
+    "tf_dev_store_u64": (_I, [_P, C.c_uint64]),
     "tf_dev_stream_copy": (_I, [_P, _P, C.c_size_t]),
     "tf_fb_create": (_I, [_PP, _I, _I, C.POINTER(TfFbParams), _I, _I]),
     "tf_host_alloc": (_I, [_PP, C.c_size_t]),
@@ -150,6 +151,8 @@ PROTOTYPES = {
     "tf_comp_destroy": (None, [_P]),
     "tf_comp_begin": (_I, [_P]),
     "tf_comp_download": (_I, [_P, _P]),
+    "tf_comp_download_begin": (_I, [_P, _P]),
+    "tf_comp_download_end": (_I, [_P]),
     "tf_comp_image_ptr": (_I, [_P, _PP]),
     "tf_batch_unique_id": (_I, [_P]),
     "tf_batch_init": (_I, [_PP, _I, _I, _P]),

@@ -310,20 +310,33 @@ LAYER_CLASSES = {"moveref": HipMoveReferenceLayer, "sum": HipSumLayer, "static":
 class HipCompositor:
     """Same constructor, methods and attributes as transflow.compositor.Compositor."""
 
-    def __init__(self, height: int, width: int, layers, background_color: str = "#ffffff"):
+    def __init__(self, height: int, width: int, layers, background_color: str = "#ffffff", lazy_frames: bool = False):
+        """lazy_frames: render() returns a DeviceFrame (transflow_amd/deviceframe.py) -- the uint8 (H, W, 3) array to
+        everything numpy, its download started but not waited for, so that frame t comes down (pipeline.py:518,
+        output/ffmpeg.py:32-54) beside frame t + 1's uploads and kernels (pipeline.py:565).  Default: a plain ndarray."""
         self.height, self.width = int(height), int(width)
         self.background_color = parse_color(background_color)
         self.background = np.zeros((self.height, self.width, 3), dtype=np.uint8)
         self.background[:, :] = self.background_color
         self.layers = list(layers)
+        self.lazy_frames = bool(lazy_frames)
         self._comp = None
+        self._comp2 = None          # lazy frames: the second image (frame t downloads from one while t + 1 is rendered into the other)
+        self._flip = False
         self._frame_pool = None
 
     def _image(self):
+        from .remap import CompImage
         if self._comp is None:
-            from .remap import CompImage
             self._comp = CompImage(self.height, self.width, self.background_color)
-        return self._comp
+        if not self.lazy_frames:
+            return self._comp
+        if self._comp2 is None:
+            self._comp2 = CompImage(self.height, self.width, self.background_color)
+        self._flip = not self._flip
+        comp = self._comp2 if self._flip else self._comp
+        comp.download_end()         # the frame before last, long in host memory: its image may be written again
+        return comp
 
     def update(self, flow):
         for layer in self.layers:
@@ -343,7 +356,11 @@ class HipCompositor:
         if self._frame_pool is None:
             from .device import ArrayPool
             self._frame_pool = ArrayPool((self.height, self.width, 3), np.uint8, pinned=True)
-        frame = comp.download(self._frame_pool.take())
+        if self.lazy_frames:
+            from .deviceframe import DeviceFrame
+            frame = DeviceFrame(comp.download_begin(self._frame_pool.take()), comp)
+        else:
+            frame = comp.download(self._frame_pool.take())
         for layer in self.layers:
             # updates from flows that stayed on the device (DeviceFlow) could not raise when they were queued: the
             # reference's IndexError for a flow vector that leaves the frame (movement.py:33, 39) comes here, at the
@@ -357,30 +374,36 @@ class HipCompositor:
         return frame
 
     @classmethod
-    def from_args(cls, height: int, width: int, layer_configs, background_color: str = "#ffffff", rng: str = "numpy"):
+    def from_args(cls, height: int, width: int, layer_configs, background_color: str = "#ffffff", rng: str = "numpy",
+                  lazy_frames: bool = False):
         layers = []
         for config in layer_configs:
             classname = getattr(config, "classname", "moveref")
             if classname not in LAYER_CLASSES:
                 raise ValueError(f"Unknown layer classname {classname}")                # layer.py:56
             layers.append(LAYER_CLASSES[classname](config, height, width, [], rng=rng))
-        return cls(height, width, layers, background_color=background_color)
+        return cls(height, width, layers, background_color=background_color, lazy_frames=lazy_frames)
 
     def set_sources(self, pixmap_interfaces: dict):
         for i, layer in enumerate(self.layers):
             layer.set_sources(pixmap_interfaces.get(i, []))
 
     def __getstate__(self):
-        return {k: v for k, v in self.__dict__.items() if k not in ("_comp", "_frame_pool")}
+        return {k: v for k, v in self.__dict__.items() if k not in ("_comp", "_comp2", "_frame_pool")}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.lazy_frames = bool(state.get("lazy_frames", False))
         self._comp = None
+        self._comp2 = None
+        self._flip = False
         self._frame_pool = None
 
     def close(self):
         for layer in self.layers:
             layer.close()
-        if self._comp is not None:
-            self._comp.close()
-            self._comp = None
+        for name in ("_comp", "_comp2"):
+            comp = getattr(self, name, None)
+            if comp is not None:
+                comp.close()
+                setattr(self, name, None)

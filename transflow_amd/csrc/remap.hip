@@ -486,6 +486,37 @@ TF_API int tf_comp_download(tf_comp *comp, uint8_t *rgb_out)
     return TF_OK;
 }
 
+TF_API int tf_comp_download_begin(tf_comp *comp, uint8_t *rgb_out)
+{
+    TF_REQUIRE(comp && rgb_out, "tf_comp_download_begin: null pointer");
+    TF_TRY(ensure_init());
+    TF_TRY(tf_comp_download_end(comp)); // one transfer per image at a time
+    if (!comp->N)
+        return TF_OK;
+    if (!comp->image_ready) {
+        TF_HIP(hipEventCreateWithFlags(&comp->image_ready, hipEventDisableTiming));
+        TF_HIP(hipEventCreateWithFlags(&comp->download_done, hipEventDisableTiming));
+    }
+    hipStream_t down;
+    TF_TRY(tf::side_stream(4, &down));
+    TF_HIP(hipEventRecord(comp->image_ready, stream()));
+    TF_HIP(hipStreamWaitEvent(down, comp->image_ready, 0));
+    TF_HIP(hipMemcpyAsync(rgb_out, comp->image.p, (size_t)comp->N * 3, hipMemcpyDeviceToHost, down));
+    TF_HIP(hipEventRecord(comp->download_done, down));
+    comp->download_pending = true;
+    return TF_OK;
+}
+
+TF_API int tf_comp_download_end(tf_comp *comp)
+{
+    TF_REQUIRE(comp, "tf_comp_download_end: null handle");
+    if (comp->download_pending) {
+        TF_HIP(hipEventSynchronize(comp->download_done));
+        comp->download_pending = false;
+    }
+    return TF_OK;
+}
+
 TF_API int tf_comp_image_ptr(tf_comp *comp, void **dev)
 {
     TF_REQUIRE(comp && dev, "tf_comp_image_ptr: null pointer");

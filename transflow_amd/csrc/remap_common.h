@@ -54,6 +54,18 @@ struct tf_comp {
     int H, W, N;
     uchar4 bg;
     DevBuf image;
+    // tf_comp_download_begin / _end: the image on its way down on the library's download stream
+    hipEvent_t image_ready = nullptr, download_done = nullptr;
+    bool download_pending = false;
+    ~tf_comp()
+    {
+        if (download_pending)
+            (void)hipEventSynchronize(download_done);
+        if (image_ready)
+            (void)hipEventDestroy(image_ready);
+        if (download_done)
+            (void)hipEventDestroy(download_done);
+    }
 };
 
 struct tf_remap {

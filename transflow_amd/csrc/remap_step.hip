@@ -559,13 +559,25 @@ TF_API int tf_remap_steps_dev(tf_remap *L, int n, tf_comp *const *comps, const v
                               const void *const *uniforms_dev, uint64_t seed, const void *const *pixmaps_dev, int channels)
 {
     TF_REQUIRE(L && n >= 0 && (n == 0 || (comps && flows_dev && pixmaps_dev)), "tf_remap_steps_dev: null argument");
+    // every step's arguments are checked BEFORE the first step runs: once stores of the layer's rgba have been left out
+    // (below) no later step may fail on an argument and leave the layer's state ahead of its rgba
+    TF_REQUIRE(channels == 3 || channels == 4, "tf_remap_steps_dev: pixmap must have 3 or 4 channels, got %d", channels);
+    TF_REQUIRE(clip_flow >= 0 && clip_flow <= 2, "tf_remap_steps_dev: clip_flow must be 0, 1 or 2, got %d", clip_flow);
+    TF_REQUIRE(n == 0 || L->cfg.layer_class == TF_LAYER_MOVEREF, "tf_remap_steps_dev: moveref layers only");
+    TF_REQUIRE(n == 0 || L->n_sources == 1, "tf_remap_steps_dev: the layer has %d sources; the one-call step serves exactly one",
+               L->n_sources);
+    for (int i = 0; i < n; i++) {
+        TF_REQUIRE(comps[i] && (L->N == 0 || (flows_dev[i] && pixmaps_dev[i])), "tf_remap_steps_dev: null pointer in step %d", i);
+        TF_REQUIRE(L->H == comps[i]->H && L->W == comps[i]->W, "tf_remap_steps_dev: layer is %dx%d, step %d's compositor %dx%d",
+                   L->W, L->H, i, comps[i]->W, comps[i]->H);
+    }
     TF_TRY(ensure_init());
     const int *dead = nullptr;
     if (n >= 2 && L->N > 0 && L->cfg.layer_class == TF_LAYER_MOVEREF && L->n_sources == 1 && step_fusable(L) &&
         option(OPT_REMAP_KEEP_RGBA) == 0) {
         if (!L->sel_flag.p)
             TF_TRY(L->sel_flag.alloc(sizeof(int)));
-        TF_HIP(hipMemsetD32Async((hipDeviceptr_t)L->sel_flag.p, 1, 1, main_stream()));
+        TF_HIP(hipMemsetD32Async((hipDeviceptr_t)L->sel_flag.p, 1, 1, stream())); // the stream the check and the steps run on
         const dim3 grid((unsigned)std::min<size_t>(cdiv((size_t)L->N, BLOCK), 4096)), block(BLOCK);
         if (const int kind = state_can_pack(L)) { // the form the steps will keep the state in
             TF_TRY(state_packed(L, kind));

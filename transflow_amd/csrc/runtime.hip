@@ -480,6 +480,18 @@ TF_API int tf_dev_stream_copy(void *dst_dev, const void *src_dev, size_t bytes)
                       (float4 *)dst_dev, n);
 }
 
+__global__ void k_store_u64(unsigned long long *dst, unsigned long long v)
+{
+    *dst = v;
+}
+
+TF_API int tf_dev_store_u64(void *dev, uint64_t value)
+{
+    TF_REQUIRE(dev && ((uintptr_t)dev & 7) == 0, "tf_dev_store_u64: null or misaligned pointer");
+    TF_TRY(ensure_init());
+    return tf::launch("store_u64", k_store_u64, dim3(1), dim3(1), 0, (unsigned long long *)dev, (unsigned long long)value);
+}
+
 TF_API int tf_dev_copy(void *dst_dev, const void *src_dev, size_t bytes)
 {
     TF_REQUIRE(dst_dev && src_dev, "tf_dev_copy: null pointer");

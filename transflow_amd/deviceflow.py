@@ -17,11 +17,28 @@ multiprocessing queue when the source runs in its child process (transflow/pipel
   consumer's process opens the allocation, takes a private copy of the flow (device to device, ~30 us at 4K) and is done
   with the producer's buffer before `queue.get()` returns, so the producer's small ring of buffers never waits for a
   consumer.  Anything else (plain `hip_device_flows`, an export that fails) crosses a process boundary as the host array.
+
+What keeps an exported buffer valid until the consumer has copied it (round 6; rounds 1-5 counted exports and hoped):
+
+* every ring buffer starts with a 64-bit GENERATION word (HEADER bytes in front of the flow).  The producer bumps it in
+  stream order (tf_dev_store_u64) before the buffer is written again; the token carries the generation the flow was
+  written under; the consumer reads the word AFTER its private copy and raises RuntimeError naming the buffer if it has
+  moved on -- a flow that was overwritten under the consumer's hands is an error, never a wrong frame;
+* the consumer ACKNOWLEDGES every token it has copied in a small file both processes map (_AckBoard; its path travels in
+  the token).  A buffer that left as a token comes back into the producer's rotation only once its generation is
+  acknowledged (the ring grows meanwhile), and `FlowRing.drain()` -- what `HipFlowSource.close()` calls before the source
+  lets go of its buffers -- waits, with a time limit, until nothing is on its way any more: multiprocessing's
+  `Queue.get()` frees the queue's slot BEFORE it unpickles, so the producer's last `put()` can return, and its process
+  end, while the consumer has not yet opened the last flow's handle;
+* a consumer closes its mapping of a producer's buffer (tf_ipc_close) once that producer's process is gone.
 """
 from __future__ import annotations
 
 import ctypes as C
+import mmap
 import os
+import tempfile
+import time
 
 import numpy as np
 from numpy.lib.mixins import NDArrayOperatorsMixin
@@ -59,18 +76,81 @@ class _Event:
             pass
 
 
+HEADER = 256     # bytes in front of the flow in a ring buffer; the first eight are its generation word
+
+
+class _AckBoard:
+    """Producer side of the acknowledgements: a page of 64-bit words, one per ring buffer, in a file both processes map
+    (in /dev/shm where there is one).  Word i = the highest generation of buffer i a consumer has copied."""
+
+    WORDS = 512
+
+    def __init__(self):
+        d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        fd, self.path = tempfile.mkstemp(prefix=f"tfhip-ack-{os.getpid()}-", dir=d)
+        try:
+            os.ftruncate(fd, 8 * self.WORDS)
+            self._mm = mmap.mmap(fd, 8 * self.WORDS)
+        finally:
+            os.close(fd)
+        self._words = np.frombuffer(self._mm, dtype=np.uint64)
+
+    def acked(self, index: int) -> int:
+        return int(self._words[index])
+
+    def close(self):
+        self._words = None
+        try:
+            self._mm.close()
+        except (BufferError, ValueError):
+            pass
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
+
+
+_ACK_VIEWS: dict = {}     # consumer side: path -> (mmap, words)
+
+
+def _acknowledge(path: str, index: int, generation: int) -> None:
+    """Consumer side: buffer `index` of the producer whose board lives at `path` has been copied up to `generation`.
+    A board that is gone (the producer stopped waiting) is not an error."""
+    if not path or index >= _AckBoard.WORDS:
+        return
+    view = _ACK_VIEWS.get(path)
+    if view is None:
+        try:
+            fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
+        except OSError:
+            return
+        try:
+            mm = mmap.mmap(fd, 8 * _AckBoard.WORDS)
+        except (OSError, ValueError):
+            return
+        finally:
+            os.close(fd)
+        view = _ACK_VIEWS[path] = (mm, np.frombuffer(mm, dtype=np.uint64))
+    if int(view[1][index]) < generation:
+        view[1][index] = generation
+
+
 class _Slot:
-    """One device buffer of a flow ring: the allocation, the event behind the flow that was last written into it
-    (`ready`) and the event behind the last kernel that read it (`used`; None until somebody did)."""
+    """One device buffer of a flow ring: the allocation (HEADER bytes, then the flow), the event behind the flow that
+    was last written into it (`ready`), the event behind the last kernel that read it (`used`; None until somebody
+    did), the generation it is in (the word at its head says the same on the device) and the generation under which a
+    flow in it last left this process as an IPC token (None: never)."""
 
     def __init__(self, nbytes: int, index: int):
         from .device import DevBuffer
-        self.buf = DevBuffer(nbytes)
+        self.buf = DevBuffer(nbytes + HEADER)
+        self.flow_ptr = self.buf.ptr + HEADER
         self.index = index
         self.ready = _Event()
         self.used = None
         self.ipc_handle = None          # exported once, on first use
-        self.exported_at = None         # the ring's export count when a flow in this buffer last left as an IPC token
+        self.generation = 0
+        self.exported_gen = None
 
     def close(self):
         self.buf.close()
@@ -82,28 +162,48 @@ class _Slot:
 class FlowRing:
     """The device buffers a flow source's DeviceFlows live in.  A buffer goes back into rotation when the DeviceFlow over
     it is garbage; the producer's stream then waits (on the device) for the last kernel that read it.  A flow that left
-    as an IPC token is garbage here as soon as it is pickled, long before the other process has read it (it copies the flow
-    out inside its queue.get(), see the module text): such a buffer stays out of rotation until EXPORT_HOLD more flows
-    have left the same way -- a producer can only be that far ahead of its consumer through a queue deeper than
-    EXPORT_HOLD - 2 (transflow/pipeline.py:326: maxsize = 1)."""
+    as an IPC token is garbage here as soon as it is pickled, long before the other process has read it (it copies the
+    flow out inside its queue.get(), see the module text): such a buffer stays out of rotation until the consumer has
+    acknowledged that generation of it, the ring growing meanwhile.  `wait_for_acks = False` switches that rule off --
+    for the test that makes a producer overrun its consumer and shows the consumer's generation check catching it."""
 
-    EXPORT_HOLD = 8
+    DRAIN_TIMEOUT = 10.0     # seconds drain() waits for tokens on their way and for their acknowledgements
+    TRANSIT_TIMEOUT = 1.0    # ... of which for flows that were handed out but never became a token (nothing else pending)
 
-    def __init__(self, shape, slots: int = 4):
+    def __init__(self, shape, slots: int = 4, wait_for_acks: bool = True):
         self.shape = tuple(int(v) for v in shape)
         self.nbytes = int(np.prod(self.shape)) * 4
         self.slots = max(2, int(slots))
+        self.wait_for_acks = bool(wait_for_acks)
         self._all: list[_Slot] = []
         self._free: list[_Slot] = []
+        self._board: _AckBoard | None = None
+        self._in_transit = 0             # DeviceFlows of the "ipc" kind alive and not yet exported
         self.exports = 0
 
-    def exported(self, slot: "_Slot") -> None:
-        slot.exported_at = self.exports
+    # ---- the exporting side's bookkeeping ------------------------------------------------------------------------
+    def exported(self, slot: "_Slot"):
+        """A flow in `slot` leaves as a token (called by the queue's pickler, in its feeder thread): returns what the
+        token carries besides the handle -- the buffer's generation and the acknowledgement board's path."""
+        if self._board is None:
+            self._board = _AckBoard()
+        slot.exported_gen = slot.generation
         self.exports += 1
+        return slot.generation, (self._board.path if slot.index < _AckBoard.WORDS else "")
+
+    def _acked(self, slot: "_Slot") -> bool:
+        if slot.exported_gen is None:
+            return True
+        if self._board is None or slot.index >= _AckBoard.WORDS:
+            return False
+        return self._board.acked(slot.index) >= slot.exported_gen
+
+    def unacknowledged(self) -> list:
+        """Indices of the buffers whose last token no consumer has acknowledged yet."""
+        return [s.index for s in self._all if not self._acked(s)]
 
     def take(self) -> _Slot:
-        slot = next((s for s in self._free
-                     if s.exported_at is None or self.exports - s.exported_at >= self.EXPORT_HOLD), None)
+        slot = next((s for s in self._free if not self.wait_for_acks or self._acked(s)), None)
         if slot is not None:
             self._free.remove(slot)
         else:
@@ -111,16 +211,49 @@ class FlowRing:
             self._all.append(slot)           # (more flows held -- or on their way to another process -- than `slots`: the ring grows)
         if slot.used is not None:
             slot.used.stream_wait()          # the producer's writes stay behind the consumer's last read
+        # a new generation, on the device BEFORE anything of the new flow is written (same stream): a consumer of another
+        # process that still copies the old flow out of this buffer will find the word changed and say so
+        slot.generation += 1
+        slot.exported_gen = None
+        check(_lib.load().tf_dev_store_u64(C.c_void_p(slot.buf.ptr), slot.generation))
         return slot
 
     def give_back(self, slot: _Slot) -> None:
         if slot in self._all and slot not in self._free:
             self._free.append(slot)
 
+    def drain(self, timeout: float | None = None) -> bool:
+        """Before the producer lets go of its buffers (or ends): wait until no flow of the "ipc" kind is still on its way
+        into a token (the queue pickles in a feeder thread, after put() has returned) and every token that left has
+        been acknowledged by its consumer.  True if that happened within `timeout` seconds (default DRAIN_TIMEOUT); False
+        leaves a consumer that comes later with an error from tf_ipc_open or the generation check, not with a wrong flow."""
+        limit = self.DRAIN_TIMEOUT if timeout is None else timeout
+        start = time.monotonic()
+        while self._in_transit > 0 or self.unacknowledged():
+            waited = time.monotonic() - start
+            # a flow nobody ever sends anywhere (the caller's loop variable still holds the last one) stays "on its way"
+            # for as long as it lives: the feeder thread needs milliseconds, so that part of the wait is cut short
+            if waited > limit or (self._in_transit > 0 and not self.unacknowledged() and waited > min(limit, self.TRANSIT_TIMEOUT)):
+                return False
+            time.sleep(0.0005)
+        return True
+
     def close(self):
+        """Frees every buffer NOW (callers that know no flow of the ring is in use any more); drain() first where tokens
+        may be on their way."""
         for s in self._all:
             s.close()
         self._all, self._free = [], []
+        if self._board is not None:
+            self._board.close()
+            self._board = None
+
+    def __del__(self):
+        try:
+            if self._board is not None:
+                self._board.close()
+        except Exception:
+            pass
 
 
 class DeviceFlow(NDArrayOperatorsMixin):
@@ -140,6 +273,9 @@ class DeviceFlow(NDArrayOperatorsMixin):
         self._host = None
         self._dirty = False                # the host values were modified in place: the device copy is stale
         self._cross = cross_process        # "ipc": a multiprocessing queue carries the IPC handle, not the array
+        self._transit = bool(cross_process == "ipc" and ring is not None)
+        if self._transit:
+            ring._in_transit += 1          # until it is exported, read on the host, or garbage (FlowRing.drain waits for that)
         self.in_frame = False              # set by a source whose post_process clipped the flow on the device: no rounded
                                            # vector of it can leave the frame (the compositor need not look for one)
 
@@ -251,8 +387,14 @@ class DeviceFlow(NDArrayOperatorsMixin):
         # checkpoints, copy.deepcopy, any ordinary pickler: the host array and nothing else
         return (np.array, (self.host(),))
 
+    def _left_transit(self) -> None:
+        if self._transit:
+            self._transit = False
+            self._ring._in_transit -= 1
+
     def __del__(self):
         try:
+            self._left_transit()
             if self._ring is not None and self._slot is not None:
                 self._ring.give_back(self._slot)
         except Exception:
@@ -274,30 +416,52 @@ def _reduce_for_queue(flow: DeviceFlow):
                 slot.ipc_handle = bytes(h.raw)
             if flow._ready is not None:
                 flow._ready.synchronize()            # the flow is complete before another process may read it
-            if flow._ring is not None:
-                flow._ring.exported(slot)            # ... and its buffer stays untouched until that process has had time to
-            return (_open_from_queue, (slot.ipc_handle, os.getpid(), slot.index, flow.shape, flow.in_frame))
+            generation, board = flow._ring.exported(slot) if flow._ring is not None else (slot.generation, "")
+            flow._left_transit()
+            return (_open_from_queue, (slot.ipc_handle, os.getpid(), slot.index, flow.shape, flow.in_frame, generation, board))
         except Exception:                            # no IPC on this system: the array crosses instead
             flow._cross = None
-    return (np.array, (flow.host(),))
+    out = (np.array, (flow.host(),))
+    flow._left_transit()
+    return out
 
 
-def _open_from_queue(handle: bytes, pid: int, index: int, shape, in_frame: bool = False):
+def _close_mappings_of_dead_producers(keep_pid: int) -> None:
+    lib = _lib.load()
+    for key in [k for k in _OPENED if k[0] != keep_pid]:
+        try:
+            os.kill(key[0], 0)
+        except ProcessLookupError:
+            lib.tf_ipc_close(C.c_void_p(_OPENED.pop(key)))
+        except OSError:
+            pass
+
+
+def _open_from_queue(handle: bytes, pid: int, index: int, shape, in_frame: bool = False, generation: int = 0,
+                     board: str = ""):
     """In the consumer's process: map the producer's buffer (once per buffer), copy the flow out of it into memory of
-    our own and hand that out -- the producer's buffer is free again when queue.get() returns."""
+    our own, check that the buffer is still in the generation the token was made under, acknowledge, hand the copy
+    out -- the producer's buffer is free again when queue.get() returns."""
     lib = _lib.load()
     key = (pid, index, handle)
     src = _OPENED.get(key)
     if src is None:
+        _close_mappings_of_dead_producers(pid)
         p = C.c_void_p()
         check(lib.tf_ipc_open(handle, C.byref(p)))
         src = _OPENED[key] = p.value
     ring = _CONSUMER_RINGS.setdefault(tuple(shape), FlowRing(shape, slots=3))
     slot = ring.take()
-    check(lib.tf_dev_copy(C.c_void_p(slot.buf.ptr), C.c_void_p(src), ring.nbytes))
-    check(lib.tf_sync())                             # done with the producer's memory
+    check(lib.tf_dev_copy(C.c_void_p(slot.flow_ptr), C.c_void_p(src + HEADER), ring.nbytes))
+    seen = np.zeros(1, np.uint64)
+    check(lib.tf_dev_download(C.c_void_p(seen.ctypes.data), C.c_void_p(src), 8))   # same stream: after the copy; synchronises
+    _acknowledge(board, index, generation)           # done with the producer's memory, whatever we found there
+    if generation and int(seen[0]) != generation:
+        ring.give_back(slot)
+        raise RuntimeError(f"device flow buffer {index} of process {pid} was written again (generation {int(seen[0])}, the "
+                           f"token says {generation}) before this process had copied the flow out of it")
     slot.ready.record()
-    flow = DeviceFlow(shape, slot.buf.ptr, slot.ready, ring=ring, slot=slot)
+    flow = DeviceFlow(shape, slot.flow_ptr, slot.ready, ring=ring, slot=slot)
     flow.in_frame = bool(in_frame)
     return flow
 

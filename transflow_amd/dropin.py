@@ -54,19 +54,22 @@ def _flow_from_args(original):
     return classmethod(from_args)
 
 
-def _compositor_from_args(original):
+def _compositor_from_args(original, lazy_frames=False):
     from .compositor import LAYER_CLASSES, HipCompositor
 
     def from_args(cls, height, width, layer_configs, background_color="#ffffff"):
         if all(getattr(c, "classname", None) in LAYER_CLASSES for c in layer_configs):
-            return HipCompositor.from_args(height, width, layer_configs, background_color=background_color)
+            return HipCompositor.from_args(height, width, layer_configs, background_color=background_color,
+                                           lazy_frames=lazy_frames)
         return original(height, width, layer_configs, background_color=background_color)
 
     return classmethod(from_args)
 
 
-def install(flow: bool = True, compositor: bool = True) -> None:
-    """Needs `transflow` importable.  Idempotent."""
+def install(flow: bool = True, compositor: bool = True, lazy_frames: bool = False) -> None:
+    """Needs `transflow` importable.  Idempotent.  lazy_frames: the compositors built for the pipeline return
+    DeviceFrames from render() (transflow_amd/deviceframe.py): the pipeline's `oq.put(frame)` (pipeline.py:518-522) then
+    pickles the frame -- and waits for its download -- in the queue's feeder thread, beside the next update."""
     if flow and "flow" not in _saved:
         from transflow.flow.sources.source import FlowSource as RefFlowSource
         _saved["flow"] = (RefFlowSource, RefFlowSource.__dict__["from_args"])
@@ -77,7 +80,7 @@ def install(flow: bool = True, compositor: bool = True) -> None:
         from .compositor import bind_reference_data_layer
         bind_reference_data_layer()    # extra/control.py:155 asks isinstance(layer, DataLayer) of checkpointed layers
         _saved["compositor"] = (RefCompositor, RefCompositor.__dict__["from_args"])
-        RefCompositor.from_args = _compositor_from_args(RefCompositor.from_args)
+        RefCompositor.from_args = _compositor_from_args(RefCompositor.from_args, lazy_frames)
 
 
 def uninstall() -> None:

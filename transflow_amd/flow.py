@@ -623,6 +623,7 @@ class HipFlowSource(FlowSource):
     def prev_gray(self, value):
         self._prev_frame = value
         self._prev_slot = None
+        self._batch_left = self._batch_pos = 0     # flows of a hip_batch call made before the seek are not handed out after it
 
     def _ingest(self, slot: int, frame) -> None:
         a = np.asarray(frame)
@@ -643,6 +644,7 @@ class HipFlowSource(FlowSource):
         self._prev_frame = frame
         self.prev_flow = None
         self._prev_slot = None
+        self._batch_left = self._batch_pos = 0     # (an external rewind while a hip_batch call still had flows queued)
 
     def _batch_size(self) -> int:
         return max(1, int(getattr(self.config, "hip_batch", 1))) if self._resident_ok() else 1
@@ -724,7 +726,7 @@ class HipFlowSource(FlowSource):
             if self._flow_ring is None:
                 self._flow_ring = FlowRing((self.height, self.width, 2), slots=4 + self.config.hip_prefetch)
             slot = self._flow_ring.take()
-            self._pending = DeviceFlow((self.height, self.width, 2), slot.buf.ptr, slot.ready, ring=self._flow_ring, slot=slot,
+            self._pending = DeviceFlow((self.height, self.width, 2), slot.flow_ptr, slot.ready, ring=self._flow_ring, slot=slot,
                                        cross_process="ipc" if self.config.hip_device_flows == "ipc" else None)
             return self._pending
         if self._flow_pool is None:
@@ -793,6 +795,13 @@ class HipFlowSource(FlowSource):
             self._mask_dev.close()
             self._mask_dev = None
         self._pending = None
+        if self._flow_ring is not None:
+            # flows that left this process as IPC tokens: multiprocessing's Queue.get() frees the queue's slot before it
+            # unpickles, so the last put() of SourceProcess.run (pipeline.py:85-86) can return -- and this process end --
+            # before the consumer has opened the last flow's handle.  Wait (bounded) until every token on its way has
+            # been made and acknowledged; our own reference to the last flow goes first.
+            self.prev_flow = None
+            self._flow_ring.drain()
         self._flow_ring = None      # (buffers live as long as a DeviceFlow the caller still holds)
         if self._fb is not None:
             self._fb.close()

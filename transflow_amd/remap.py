@@ -40,6 +40,19 @@ class CompImage:
         check(self._lib.tf_comp_download(self._h, _ptr(out)))
         return out
 
+    def download_begin(self, out: np.ndarray) -> np.ndarray:
+        """The download started on the library's download stream behind what the caller's stream has been given;
+        `out` (page-locked, C-contiguous uint8 (H, W, 3)) is filled once download_end() has returned.  The image
+        must not be rendered into again before that."""
+        if out.dtype != np.uint8 or not out.flags.c_contiguous or out.shape != (self.height, self.width, 3):
+            raise ValueError("download_begin needs a C-contiguous uint8 array of shape (H, W, 3)")
+        check(self._lib.tf_comp_download_begin(self._h, _ptr(out)))
+        return out
+
+    def download_end(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            check(self._lib.tf_comp_download_end(self._h))
+
     def image_ptr(self) -> int:
         p = C.c_void_p()
         check(self._lib.tf_comp_image_ptr(self._h, C.byref(p)))
