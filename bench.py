@@ -468,8 +468,33 @@ def cpu_baseline(job, gate_times):
     fa = [frame(prev[i % job.batch]) for i in range(n)]
     fb_ = [frame(nxt[i % job.batch]) for i in range(n)]
     t0 = time.perf_counter()
-    OF.calc_batch(fa, fb_, cores, levels=wl["levels"])
+    sample_flows = OF.calc_batch(fa, fb_, cores, levels=wl["levels"])
     t_all = time.perf_counter() - t0
+    # The sample's oracle flows are those of the first min(cores, pairs per pass) pairs of pass 0: compared with the GPU's
+    # flows of the same pass they widen the in-run parity check from the gate's three pairs at no extra oracle time.
+    wide = None
+    try:
+        m = min(n, job.batch)
+        job.calc_pass(0)
+        job.sync()
+        wide = {"pairs": m, "pairs_bit_identical": 0, "pixels_differing": 0, "outliers": 0, "max_err_over_tol": 0.0,
+                "what": f"the C port's flows of the multi-core sample (pairs 0 .. {m - 1} of the first pass) against the GPU's "
+                        f"flows of the same pass, default mode: NO pixel may lie beyond {TOL_REL:g} * max(1, max|ref|)"}
+        got = np.empty((wl["h"], wl["w"], 2), np.float32)
+        for i in range(m):
+            job.fb.get_flow_into(i, got)
+            if np.array_equal(got, sample_flows[i]):
+                wide["pairs_bit_identical"] += 1
+                continue
+            d = np.abs(got - sample_flows[i]).max(axis=2)
+            tol = TOL_REL * max(1.0, float(np.abs(sample_flows[i]).max()))
+            wide["pixels_differing"] += int((d > 0).sum())
+            wide["outliers"] += int((d > tol).sum()) + int((~np.isfinite(got)).sum())
+            wide["max_err_over_tol"] = max(wide["max_err_over_tol"], float(d.max()) / tol)
+        wide["ok"] = wide["outliers"] == 0
+    except Exception as err:   # noqa: BLE001 -- reported, the baseline's numbers stand
+        wide = {"error": f"{type(err).__name__}: {err}", "ok": None}
+    del sample_flows
     remap_per_frame = gate_times["remap_s"] / n1
     key = "all_cores" if cores == host["usable_cores"] else "multi_core"
     out = {"value": one, "unit": "frames/s", "cores": 1, "kind": "port", "host": host,
@@ -481,6 +506,7 @@ def cpu_baseline(job, gate_times):
                  "sample": f"{n} frame pairs, one per OpenMP thread on {cores} of the host's {host['usable_cores']} usable "
                            f"cores, {t_all:.2f} s for the C port of Farneback; the numpy remap ({remap_per_frame:.2f} "
                            "s/frame, serial: it is a recurrence) added per frame"}}
+    out["parity_of_the_multi_core_sample"] = wide
     try:
         import cv2
     except ImportError:
@@ -919,6 +945,7 @@ def main():
                          "parity_gate": "skipped (--dry-run)", "timed_region_recheck": None, "roofline": None, "cpu_baseline": None,
                          "kernels_ms_per_step": None, "remap_out_of_frame": None, "gather": None, "flows_to_root": None,
                          "gather_verified_crc": None, "flows_to_root_ok": None, "untimed_steps_before_timed_region": None,
+                         "parity_wide": None,
                          "dry_run": True, "clip_frames": args.clip_frames, "plans": plans})
             print(json.dumps(line))
         host.close()
@@ -1221,6 +1248,9 @@ def main():
             leg_errors["extras"] = f"{type(err).__name__}: {err}"
     if leg_errors:
         out["side_leg_errors"] = leg_errors
+    # the wide parity check rides on the CPU baseline's multi-core sample (its oracle flows are pass 0's): where nobody can miss it
+    wide = (out.get("cpu_baseline") or {}).get("parity_of_the_multi_core_sample") if isinstance(out.get("cpu_baseline"), dict) else None
+    out["parity_wide"] = wide
     print(json.dumps(out, allow_nan=False), flush=True)
     if not STUCK_THREADS:
         host.close()
@@ -1233,6 +1263,9 @@ def main():
               f"(every rank made the shared inputs itself, no gather legs), exit code {no_rccl}; --allow-no-rccl accepts it",
               file=sys.stderr)
         EXIT_CODE = no_rccl
+    if isinstance(wide, dict) and wide.get("ok") is False:      # (last: a parity failure outranks the other codes)
+        print(f"[bench] parity FAILED on the wide sample after the timed region: {json.dumps(wide)}", file=sys.stderr)
+        EXIT_CODE = 3
 
 
 def run_as_main():
