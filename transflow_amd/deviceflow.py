@@ -38,6 +38,7 @@ import ctypes as C
 import mmap
 import os
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -179,16 +180,18 @@ class FlowRing:
         self._free: list[_Slot] = []
         self._board: _AckBoard | None = None
         self._in_transit = 0             # DeviceFlows of the "ipc" kind alive and not yet exported
+        XX
         self.exports = 0
 
     # ---- the exporting side's bookkeeping ------------------------------------------------------------------------
     def exported(self, slot: "_Slot"):
         """A flow in `slot` leaves as a token (called by the queue's pickler, in its feeder thread): returns what the
         token carries besides the handle -- the buffer's generation and the acknowledgement board's path."""
-        if self._board is None:
-            self._board = _AckBoard()
-        slot.exported_gen = slot.generation
-        self.exports += 1
+        with self._count_lock:
+            if self._board is None:
+                self._board = _AckBoard()
+            slot.exported_gen = slot.generation
+            self.exports += 1
         return slot.generation, (self._board.path if slot.index < _AckBoard.WORDS else "")
 
     def _acked(self, slot: "_Slot") -> bool:
@@ -275,7 +278,8 @@ class DeviceFlow(NDArrayOperatorsMixin):
         self._cross = cross_process        # "ipc": a multiprocessing queue carries the IPC handle, not the array
         self._transit = bool(cross_process == "ipc" and ring is not None)
         if self._transit:
-            ring._in_transit += 1          # until it is exported, read on the host, or garbage (FlowRing.drain waits for that)
+            with ring._count_lock:
+                ring._in_transit += 1      # until it is exported, read on the host, or garbage (FlowRing.drain waits for that)
         self.in_frame = False              # set by a source whose post_process clipped the flow on the device: no rounded
                                            # vector of it can leave the frame (the compositor need not look for one)
 
@@ -389,8 +393,10 @@ class DeviceFlow(NDArrayOperatorsMixin):
 
     def _left_transit(self) -> None:
         if self._transit:
-            self._transit = False
-            self._ring._in_transit -= 1
+            with self._ring._count_lock:
+                if self._transit:
+                    self._transit = False
+                    self._ring._in_transit -= 1
 
     def __del__(self):
         try:
