@@ -180,7 +180,8 @@ class FlowRing:
         self._free: list[_Slot] = []
         self._board: _AckBoard | None = None
         self._in_transit = 0             # DeviceFlows of the "ipc" kind alive and not yet exported
-        XX
+        self._count_lock = threading.RLock()    # the queue's feeder thread and the producer's thread both count (re-entrant:
+                                                # a flow's __del__ may run while its own thread holds the lock)
         self.exports = 0
 
     # ---- the exporting side's bookkeeping ------------------------------------------------------------------------
