@@ -89,6 +89,34 @@ def test_bench_runs_its_rccl_legs_with_one_rank():
     assert f["verified_flow_crc"] is True and f["verified_stream"] is True and f["frames_per_s"] > 0
 
 
+def test_bench_line_carries_the_round_6_keys_at_a_small_size():
+    """bench.py with its CPU baseline at a small frame size: the gate on three pairs (first, middle, last), the re-check's
+    oracle statement, `parity_wide` (the multi-core sample's oracle flows against the GPU's flows of the same pass), the
+    untimed steps, the top-level verdict keys of the multi-GPU legs, and no counter figure where profiles/ holds no
+    table for the workload."""
+    env = dict(os.environ, TF_BENCH_CPU_THREADS="5")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "640x360", "--clip-frames", "17", "--batch",
+                          "8", "--steps", "3", "--warmup", "2", "--burn-in", "4", "--no-extra"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    g = d["parity_gate"]
+    assert g["ok"] and g["pairs"] == [0, 4, 7] and g["pairs_checked"] == 3 and g["exact_pairs"] == [0, 7]
+    assert g["outliers_default"] == 0 and g["exact_bit_identical"] and g["remap_bit_exact"]
+    r = d["timed_region_recheck"]["per_rank"][0]
+    assert r["ok"] and r["pairs"] == [0, 4, 7]
+    if r["pass"] == 0:
+        assert r["equals_gate_flows"] and r["vs_oracle"]["outliers"] == 0 and r["vs_oracle"]["flow_tol"] > 0
+    w = d["parity_wide"]
+    assert w == d["cpu_baseline"]["parity_of_the_multi_core_sample"]
+    assert w["ok"] and w["pairs"] == 5 and w["outliers"] == 0 and w["pairs_bit_identical"] + (w["pixels_differing"] > 0) >= 1
+    assert d["untimed_steps_before_timed_region"] == 6 and d["burn_in_steps"] == 4 and d["warmup"] == 2
+    assert d["rccl_ranks"] == 0 and d["gather_verified_crc"] is None and d["flows_to_root_ok"] is None
+    ws = d["roofline"]["whole_step"]
+    assert ws["counter_GBs"] is None and ws["counter_frac"] is None and "no counter table" in ws["counter_source"]
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["multi_core"]["cores"] == 5
+
+
 def test_flows_to_root_paints_the_clip_as_one_compositor_would():
     """SURVEY 8e mode F end to end on a communicator of one rank: the passes' flows gathered to their clip positions
     (the last pass repeats a pair of the one before), ONE remap recurrence over the clip in order on the root; layer
