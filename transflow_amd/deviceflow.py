@@ -34,6 +34,7 @@ What keeps an exported buffer valid until the consumer has copied it (round 6; r
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import mmap
 import os
@@ -95,9 +96,10 @@ class _AckBoard:
         finally:
             os.close(fd)
         self._words = np.frombuffer(self._mm, dtype=np.uint64)
+        atexit.register(self.close)      # the file does not outlive the process (close() is idempotent)
 
     def acked(self, index: int) -> int:
-        return int(self._words[index])
+        return int(self._words[index]) if self._words is not None else 0
 
     def close(self):
         self._words = None
@@ -108,6 +110,10 @@ class _AckBoard:
         try:
             os.unlink(self.path)
         except OSError:
+            pass
+        try:
+            atexit.unregister(self.close)
+        except Exception:
             pass
 
 
