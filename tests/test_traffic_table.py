@@ -52,3 +52,24 @@ def test_the_lines_figure_follows_from_the_table_and_its_own_step_time():
     ws = line["roofline"]["whole_step"]
     assert ws["counter_frac"] == pytest.approx(table["bytes_per_step"] / (line["ms_per_step"] * 1e-3) / 8e12, rel=1e-9)
     assert 0.45 < ws["counter_frac"] < ws["frac"] < 0.65    # counters below built bytes below the kernel's own figure
+
+
+def test_rocprof_summary_agrees_with_the_line_printed_under_it():
+    """profiles/r06_bench_4k_one_lane_kernel_stats.csv is `rocprofv3 --kernel-trace --stats` of the very command whose line
+    is profiles/r06_bench_4k_one_lane_under_rocprof.json: the dominant kernel's average launch duration by the profiler
+    (every launch of the process) and by HIP events (the timed region's launches) agree, and the line's `achieved` /
+    `frac` are its algorithmic bytes per launch over that duration."""
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_bench_4k_one_lane_kernel_stats.csv"))))
+    it = [r for r in rows if "k_flow_iter_pc" in r["Name"]]
+    assert len(it) == 2                                        # <7, 1> and <7, 2> (the first iteration of a level)
+    calls = sum(int(r["Calls"]) for r in it)
+    avg_ms = sum(float(r["TotalDurationNs"]) for r in it) / calls / 1e6
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_4k_one_lane_under_rocprof.json")).read().strip().splitlines()[-1])
+    r = line["roofline"]
+    assert r["kernel"] == "fb_flow_iter" and calls % 15 == 0   # 15 launches per pass: levels 0 - 4 x 3 iterations
+    assert avg_ms == pytest.approx(r["avg_launch_ms"], rel=0.01)
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-9)
+    assert r["frac"] == pytest.approx(r["achieved"] / 8000.0, rel=1e-9) and r["peak"] == 8000.0
+    share = sum(float(x["Percentage"]) for x in it)
+    assert share > 55.0                                        # it IS the dominant kernel of the profiled process
