@@ -1095,6 +1095,18 @@ def main():
     achieved = built / (dom_ms * 1e-3) / 1e9
     launches_per_step = dom_cnt / max(1, args.steps)
     traffic = rf.profile_traffic(dominant, wl["w"], wl["h"], wl["levels"], P, launches_per_step)
+    traffic_source = ("profile constant: B/px from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes under profiles/ scaled to this "
+                      "workload's launches, not a measurement of this run")
+    # where the whole-step table (round 6) was made for exactly this workload and pass size, the dominant kernel's row of it
+    # is the fresher and unscaled figure: its bytes per step over its launches per step
+    step_table = rf.profile_step_traffic(args.workload, wl["w"], wl["h"], wl["levels"], P)
+    kernel_row = {"fb_flow_iter": "k_flow_iter_pc"}.get(dominant)
+    if step_table is not None and kernel_row in step_table.get("kernels_launches_per_step", {}) and \
+            step_table["kernels_launches_per_step"][kernel_row] == round(launches_per_step):
+        traffic = step_table["kernels_bytes_per_step"][kernel_row] / step_table["kernels_launches_per_step"][kernel_row]
+        traffic_source = (f"profile constant: the kernel's row of {step_table['table']} (2*FETCH_SIZE + WRITE_SIZE of separate "
+                          "rocprofv3 --pmc passes over the same step at this pass size) over its launches per step, not a "
+                          "measurement of this run")
     avg_ms = dom_ms / max(1, dom_cnt)
     step_model = P * (rf.farneback_bytes(w, h, 0.5, wl["levels"], 3)
                       + rf.remap_bytes(w, h, reset_mask=wl["reset"], forward=wl["direction"] == 0))
@@ -1143,9 +1155,7 @@ def main():
                                     "SURVEY §8(d)'s stage-once model charges the reference's stages 96 B/px (M stored and "
                                     "read back): on those bytes the same launches read > 1 of peak by construction "
                                     "(`model_work_rate`: a work rate, not utilisation)",
-                     "traffic": traffic, "traffic_source": "profile constant: B/px from the rocprofv3 FETCH_SIZE/WRITE_SIZE "
-                                                           "passes under profiles/ scaled to this workload's launches, "
-                                                           "not a measurement of this run",
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "counter_GBs": traffic / (own["avg_launch_ms"] * 1e-3) / 1e9 if traffic and own else None,
                      "counter_frac": traffic / (own["avg_launch_ms"] * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if traffic and own else None,
                      "launches": dom_cnt,

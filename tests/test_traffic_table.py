@@ -73,3 +73,15 @@ def test_rocprof_summary_agrees_with_the_line_printed_under_it():
     assert r["frac"] == pytest.approx(r["achieved"] / 8000.0, rel=1e-9) and r["peak"] == 8000.0
     share = sum(float(x["Percentage"]) for x in it)
     assert share > 55.0                                        # it IS the dominant kernel of the profiled process
+
+
+def test_dominant_kernels_traffic_is_its_row_of_the_step_table():
+    sys.path.insert(0, ROOT)
+    from transflow_amd import roofline as rf
+    table = json.load(open(TABLE))
+    t = rf.profile_step_traffic("4k", 3840, 2160, 5, 128)
+    row = table["kernels"]["k_flow_iter_pc"]
+    assert t["kernels_bytes_per_step"]["k_flow_iter_pc"] == row["bytes_per_step"] and t["kernels_launches_per_step"]["k_flow_iter_pc"] == 15
+    per_launch = row["bytes_per_step"] / 15
+    built = rf.built_kernel_bytes("fb_flow_iter", 3840, 2160, 5, 128) / 15
+    assert 0.7 < per_launch / built < 0.9                      # 12.3 GB by the counters against 15.3 GB loaded and stored

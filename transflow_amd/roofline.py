@@ -240,5 +240,7 @@ def profile_step_traffic(workload, width, height, levels, pairs):
         if (t.get("width"), t.get("height"), t.get("levels"), t.get("pairs")) == (width, height, levels, pairs) \
                 and t.get("workload") == workload:
             return {"bytes_per_step": t["bytes_per_step"], "table": "profiles/" + fname,
-                    "kernels_GB_per_step": {k: round(v["bytes_per_step"] / 1e9, 4) for k, v in t["kernels"].items()}}
+                    "kernels_GB_per_step": {k: round(v["bytes_per_step"] / 1e9, 4) for k, v in t["kernels"].items()},
+                    "kernels_bytes_per_step": {k: float(v["bytes_per_step"]) for k, v in t["kernels"].items()},
+                    "kernels_launches_per_step": {k: int(v["launches_per_step"]) for k, v in t["kernels"].items()}}
     return None
