@@ -12,7 +12,9 @@ tool measures the sensitivity variants of oracle/Makefile (`make -C oracle varia
 
 on the test suites' shapes, on 1080p levels = 5 and on pairs of bench.py's 4K clip, and prints per case the largest
 deviation in units of the tolerance 1e-4 * max(1, max|ref|), the pixels beyond a quarter of it and beyond it, and where
-those lie.   usage: tools/oracle_envelope.py [--no-4k] > profiles/r06_oracle_envelope.txt"""
+those lie.   usage: tools/oracle_envelope.py [--no-4k] > profiles/r06_oracle_envelope.txt
+`--clip-sample N`: only N pairs of the 4K clip, evenly spaced, and how many of them each variant moves beyond the tolerance
+(how often the border discontinuity of DESIGN.md section 4 is met): > profiles/r06_oracle_envelope_clip_sample.txt"""
 import os
 import sys
 import time
@@ -24,6 +26,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from oracle import farneback as F  # noqa: E402
 from tests.helpers import FB_CASES, FB_SWEEP, synth_pair  # noqa: E402
+
+
+BEYOND = {}      # variant -> cases with a pixel beyond the tolerance
 
 
 def report(name, prev, nxt, kw):
@@ -38,6 +43,7 @@ def report(name, prev, nxt, kw):
         far = d > tol
         cell = f"{v}: max {d.max() / tol:6.3f} tol, > tol/4: {int((d > tol / 4).sum())}, > tol: {int(far.sum())}"
         if far.any():
+            BEYOND[v] = BEYOND.get(v, 0) + 1
             ys, xs = np.nonzero(far)
             cell += f" (rows {ys.min()}-{ys.max()}, columns {xs.min()}-{xs.max()} of {ref.shape[0]} x {ref.shape[1]})"
         cells.append(cell)
@@ -46,6 +52,15 @@ def report(name, prev, nxt, kw):
 
 def main():
     t0 = time.time()
+    if "--clip-sample" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--clip-sample") + 1])
+        clip = bench.ClipSynth(2160, 3840, 256, 2000)
+        pairs = sorted({round(j * 254 / (n - 1)) for j in range(n)})
+        for t in pairs:
+            report(f"bench 4k clip, pair {t} (BACKWARD order), levels=5", clip.frame(t + 1), clip.frame(t), dict(levels=5))
+        print(f"# {len(pairs)} pairs of the 4K clip: pairs with a pixel beyond the tolerance -- " +
+              ", ".join(f"{v}: {BEYOND.get(v, 0)}" for v in F.VARIANTS) + f"; {time.time() - t0:.0f} s")
+        return
     for (h, w), kw in FB_CASES + FB_SWEEP:
         a, b = synth_pair(h, w, seed=70)
         report(f"{w}x{h} {kw}", a, b, kw)
