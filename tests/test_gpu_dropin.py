@@ -441,9 +441,10 @@ def test_batched_look_ahead_gives_the_flows_of_single_calls(direction):
             np.testing.assert_array_equal(a, b)
 
 
-def test_device_flow_that_leaves_the_frame_raises_at_the_next_render():
-    """movement.py:33, 39: the reference raises IndexError when a rounded flow vector leaves the frame.  An update from a
-    DeviceFlow is only queued; the error comes at the first synchronisation behind it, HipCompositor.render."""
+def test_device_flow_that_leaves_the_frame_raises_at_update_like_a_host_flow():
+    """movement.py:33, 39: the reference raises IndexError inside update() when a rounded flow vector leaves the frame.
+    A DeviceFlow that no post_process clipped (not marked in_frame) is checked there too -- one synchronisation -- so the
+    error comes out of HipCompositor.update, not out of a later render (round 6); the compositor goes on afterwards."""
     from transflow_amd.compositor import HipCompositor
     from transflow_amd.config import LayerConfig
     from transflow_amd.device import DevBuffer
@@ -455,12 +456,21 @@ def test_device_flow_that_leaves_the_frame_raises_at_the_next_render():
     bad = np.zeros((h, w, 2), np.float32)
     bad[0, 0] = (-3.0, 0.0)
     buf = DevBuffer.from_array(bad)
-    comp.update(DeviceFlow(bad.shape, buf.ptr, None))
     with pytest.raises(IndexError):
-        comp.render()
+        comp.update(DeviceFlow(bad.shape, buf.ptr, None))
+    comp.render()
     good = DevBuffer.from_array(np.zeros((h, w, 2), np.float32))
     comp.update(DeviceFlow(bad.shape, good.ptr, None))
     comp.render()
+    for cls in ("sum", "introduction"):                   # every layer class takes the same path
+        other = HipCompositor.from_args(h, w, [LayerConfig(0, classname=cls)])
+        other.set_sources({0: [FakeSource([pix], np.ones((h, w), bool))]})
+        if cls == "sum":
+            other.update(DeviceFlow(bad.shape, buf.ptr, None))       # sum.py adds floor(flow): nothing to leave
+        else:
+            with pytest.raises(IndexError):
+                other.update(DeviceFlow(bad.shape, buf.ptr, None))
+        other.close()
 
 
 def test_prefetching_flow_source_passes_errors_on_and_stops_cleanly():

@@ -121,6 +121,7 @@ class _HipLayer:
     def _defer_step(self, layer, flow) -> bool:
         if not (self._alone and self.LAYER_CLASS == "moveref" and len(self.sources) == 1
                 and getattr(flow, "dev_ptr", None) is not None and not flow.on_host
+                and getattr(flow, "in_frame", False)     # (an unclipped flow is checked at update time: RemapLayer.update)
                 and tuple(flow.shape) == (self.height, self.width, 2)):
             return False
         if self.HAS_RESET and self.config.reset_mode == "random" and self.rng == "numpy":
@@ -152,8 +153,6 @@ class _HipLayer:
             layer.gather_dev(0, ptr, channels)
         flow.mark_used()
         layer.staged_used()
-        if not getattr(flow, "in_frame", False):
-            layer.device_updates = getattr(layer, "device_updates", 0) + 1
 
     def render_into(self, comp):
         self._run_deferred()
@@ -361,16 +360,6 @@ class HipCompositor:
             frame = DeviceFrame(comp.download_begin(self._frame_pool.take()), comp)
         else:
             frame = comp.download(self._frame_pool.take())
-        for layer in self.layers:
-            # updates from flows that stayed on the device (DeviceFlow) could not raise when they were queued: the
-            # reference's IndexError for a flow vector that leaves the frame (movement.py:33, 39) comes here, at the
-            # first synchronisation behind them
-            dev = getattr(layer, "_dev", None)
-            if dev is not None and getattr(dev, "device_updates", 0):
-                dev.device_updates = 0
-                if dev.out_of_frame():
-                    raise IndexError("a rounded flow vector left the frame in an update since the last render "
-                                     "(run post_process first)")
         return frame
 
     @classmethod

@@ -123,9 +123,10 @@ class RemapLayer:
 
     def update(self, flow: np.ndarray, uniform: np.ndarray | None = None, seed: int = 0) -> None:
         if getattr(flow, "dev_ptr", None) is not None and not flow.on_host:
-            # a DeviceFlow nobody brought down (transflow_amd/deviceflow.py): the kernels read it where it is.  A flow
-            # vector that leaves the frame cannot raise here (nothing waits for the kernel): `device_updates` tells the
-            # compositor to look at the layer's flag when it next synchronises (HipCompositor.render).
+            # a DeviceFlow nobody brought down (transflow_amd/deviceflow.py): the kernels read it where it is.  A flow a
+            # source's post_process clipped (`in_frame`) cannot leave the frame and is only queued; any other is checked
+            # here, at the price of one synchronisation, so that the reference's IndexError (movement.py:33, 39) comes
+            # out of update() as it does for a host array (round 6; before, it came at the next render()).
             if tuple(flow.shape) != (self.height, self.width, 2):
                 raise ValueError(f"flow shape {tuple(flow.shape)} != {(self.height, self.width, 2)}")
             u_dev = None
@@ -142,8 +143,8 @@ class RemapLayer:
             self.update_dev(flow.dev_ptr, u_dev, seed)
             flow.mark_used()
             self.flow_was_on_device = True
-            if not getattr(flow, "in_frame", False):
-                self.device_updates = getattr(self, "device_updates", 0) + 1
+            if not getattr(flow, "in_frame", False) and self.out_of_frame():
+                raise IndexError("a rounded flow vector leaves the frame (run post_process first)")
             return
         self.flow_was_on_device = False
         flow = np.asarray(flow)
