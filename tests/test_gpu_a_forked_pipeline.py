@@ -17,10 +17,19 @@ def _child_flow_process(frames, queue, meta, device_flows=None):
     from transflow_amd.flow import ArrayFrameProvider, HipFlowSource
     try:
         cfg = FlowConfig(hip_device_flows=device_flows) if device_flows else None
+        ring_report = None
         with HipFlowSource.from_args(ArrayFrameProvider(frames, 25.0), direction="backward", cv_config=cfg) as source:
             meta.put((source.width, source.height, source.framerate, source.length))
             for flow in source:
                 queue.put(flow)
+            del flow
+            ring = getattr(source, "_flow_ring", None)
+            if ring is not None:
+                # what close() is about to do: wait until every token has been made and acknowledged by the consumer
+                source.prev_flow = None
+                ring_report = (bool(ring.drain(timeout=120.0)), len(ring._all), ring.exports, ring.unacknowledged())
+        if ring_report is not None:
+            meta.put(ring_report)
         queue.put(None)
     except Exception as err:  # surfaces in the parent instead of hanging it
         queue.put(err)
@@ -101,6 +110,10 @@ def test_forked_flow_process_and_main_compositor(forked):
         assert isinstance(item, DeviceFlow) and item._host is None      # a token crossed, nothing was brought down
         comp3.update(item)
         got_ipc.append((item, comp3.render()))
+    # the producer's side of the protocol: all four tokens were acknowledged before it let go of its buffers, and its
+    # ring stayed small (a buffer returns to rotation as soon as its token has been copied)
+    drained, n_buffers, exports, pending = meta2.get(timeout=120)
+    assert drained and exports == 4 and pending == [] and n_buffers <= 6, (drained, n_buffers, exports, pending)
     child2.join(timeout=60)
     assert child2.exitcode == 0 and len(got_ipc) == 4
     for (flow_host, frame_host), (flow_dev, frame_dev) in zip(got, got_ipc):
