@@ -18,8 +18,8 @@ done
 FB="farneback fb_level_image fb_pyramid fb_matrices fb_iterate fb_exact fb_postprocess fb_stages"
 # a unit that fails to compile must fail the build: old objects go first, and every job is waited for by pid
 # (a bare `wait` returns 0 whatever the jobs did)
-# (fb_iterate.hip is built without the post-RA machine scheduler, as transflow_amd/csrc/Makefile builds it)
-for f in $FB; do extra=""; [ $f = fb_iterate ] && extra="-mllvm -enable-post-misched=0"; rm -f $out/$name/$f.o; $CC $extra "$@" -c $f.hip -o $out/$name/$f.o & pids="$pids $!"; done
+# (fb_iterate.hip is built without the SLP vectoriser, as transflow_amd/csrc/Makefile builds it)
+for f in $FB; do extra=""; [ $f = fb_iterate ] && extra="-fno-slp-vectorize"; rm -f $out/$name/$f.o; $CC $extra "$@" -c $f.hip -o $out/$name/$f.o & pids="$pids $!"; done
 for p in $pids; do wait $p || { echo "build_fb_variant: a compile job failed" >&2; exit 1; }; done
 objs=""; for f in $FB; do objs="$objs $out/$name/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libtfhip_$name.so $(for f in $COMMON; do echo $out/_common/$f.o; done) $objs -ldl
